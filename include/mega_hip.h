@@ -1,0 +1,130 @@
+/* mega_hip.h -- C ABI of libmega_hip.so: the MI355X (gfx950) native kernels behind MEGA's
+ * per-key-frame inference hot path.
+ *
+ * Boundary rules
+ *   - extern "C", plain device pointers + sizes, no torch / ATen types.
+ *   - every entry point returns int: 0 = MEGA_OK, 1 = bad argument, 2 = launch failure,
+ *     3 = workspace too small.  Nothing is allocated inside: the caller owns outputs and workspaces.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All work is
+ *     enqueued on that stream; no call synchronises the device or copies to the host.
+ *   - dtype codes: MEGA_F32 = 0 (exact-f32 MFMA path, parity mode), MEGA_BF16 = 1.
+ *   - activations are NHWC; GEMM weights are OHWI ([Cout][R][S][Cin]) so both operands are K-contiguous.
+ *
+ * Each prototype cites the reference interface it replaces (paths relative to the reference tree
+ * Scalsol/mega.pytorch).
+ */
+#ifndef MEGA_HIP_H
+#define MEGA_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MEGA_F32 0
+#define MEGA_BF16 1
+
+#define MEGA_OK 0
+#define MEGA_ERR_ARG 1
+#define MEGA_ERR_LAUNCH 2
+#define MEGA_ERR_WS 3
+
+/* Conv2d (+ FrozenBatchNorm2d scale/bias) (+ residual add) (+ ReLU), implicit GEMM on MFMA.
+ * Replaces torch Conv2d->cuDNN + the unfused FrozenBatchNorm2d / relu_ / += of
+ * mega_core/modeling/backbone/resnet.py:324-344 (Bottleneck.forward), :155-204 (ResNetHead),
+ * mega_core/layers/batch_norm.py:19-31, modeling/rpn/rpn.py:99-106 (RPNHead), and every nn.Linear
+ * of the box head (H = W = R = S = 1, N = rows): roi_box_feature_extractors.py:894,:907,:826,
+ * roi_box_predictors.py:50-57.
+ *   in  [N][H][W][Cin]      (in_dtype)        w [Cout][R][S][Cin] (in_dtype)
+ *   out [N*Ho*Wo][ldo]      (out_dtype)       y = acc*scale[c] + bias[c] (+ residual[m][c]) (relu)
+ *   scale / bias: f32 [Cout] or NULL (1 / 0); residual [M][ldr] in_dtype or NULL; ldo/ldr <= 0 -> Cout.
+ *   Cin must be a multiple of 64 (bf16) / 32 (f32).  out_dtype may be MEGA_F32 with bf16 inputs. */
+int mega_conv2d_nhwc(const void* in, const void* w, const float* scale, const float* bias, const void* residual,
+                     void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil,
+                     int relu, int ldo, int ldr, int in_dtype, int out_dtype, void* stream);
+
+/* ResNet stem: 7x7 stride-2 pad-3 conv (3->64) + FrozenBN + ReLU  (resnet.py:347-366 BaseStem.forward,
+ * without the max-pool).  in: NCHW f32 [N][3][H][W]; w_tap64: [147][64] f32 with tap = (c*7+r)*7+s;
+ * out: NHWC [N][Ho][Wo][64], Ho = (H-1)/2+1. */
+int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, const float* scale, const float* bias, void* out,
+                           int N, int H, int W, int out_dtype, void* stream);
+
+/* F.max_pool2d(kernel 3, stride 2, padding 1) on NHWC (resnet.py:365). */
+int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
+
+/* ROIAlign forward.  Replaces mega_core._C.roi_align_forward (csrc/ROIAlign.h:11-25,
+ * cuda/ROIAlign_cuda.cu:64-122, cpu/ROIAlign_cpu.cpp:113-219).  rois [K][5] f32 = (batch, x1, y1, x2, y2).
+ *   in_nhwc : feat is [B][H][W][C] (1) or the reference's [B][C][H][W] (0)
+ *   out_nhwc: out is bin-major [K][ph*pw][C] (1) or the reference's [K][C][ph][pw] (0) */
+int mega_roi_align_fwd(const void* feat, const float* rois, void* out, int K, int C, int H, int W,
+                       float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, int in_nhwc,
+                       int out_nhwc, int dtype, int out_dtype, void* stream);
+
+/* Greedy NMS.  Replaces mega_core._C.nms (csrc/nms.h:10-28): unsorted dets [n][4] + scores [n] ->
+ * kept ORIGINAL indices, ascending, int64 (cuda/nms.cu:127-130, cpu/nms_cpu.cpp:64); *keep_cnt is a device int.
+ * strict_gt = 1: suppress when IoU > thr (cuda/nms.cu:60); 0: IoU >= thr (cpu/nms_cpu.cpp:60).  n <= 8192. */
+size_t mega_nms_full_workspace_bytes(int n);
+int mega_nms(const float* dets, const float* scores, int n, float thr, int strict_gt, long long* keep_out,
+             int* keep_cnt, void* ws, size_t ws_bytes, void* stream);
+
+/* Batched NMS over P independent, already score-sorted problems (device-side counts, no host sync).
+ *   boxes [P][nmax][4]; counts [P]; valid [P][nmax] u8 or NULL; order [P][nmax] or NULL
+ *   keep_pos [P][max_keep] positions in sorted order (ascending); keep_cnt [P]
+ *   flags [P][nmax] (pre-zeroed) or NULL: flags[order[pos]] = 1 for every kept box. */
+size_t mega_nms_workspace_bytes(int P, int nmax);
+int mega_nms_sorted(const float* boxes, const int* counts, const unsigned char* valid, const int* order, int P,
+                    int nmax, float thr, int strict_gt, int max_keep, int* keep_pos, int* keep_cnt,
+                    unsigned char* flags, void* ws, size_t ws_bytes, void* stream);
+
+/* RPN proposal selection for B frames in one call.  Replaces RPNPostProcessor.forward_for_single_feature_map
+ * (modeling/rpn/inference.py:76-123) incl. AnchorGenerator.grid_anchors (rpn/anchor_generator.py:73-95),
+ * BoxCoder.decode (box_coder.py:52-95), clip_to_image (structures/bounding_box.py:214-219),
+ * remove_small_boxes + boxlist_nms (structures/boxlist_ops.py:9-50).
+ *   rpn_out [B][Hf*Wf][ldc] f32: channel a = objectness logit of anchor a, channel A + 4a + j = delta j
+ *   outputs: proposals [B][post_nms_top_n][4], prop_scores [B][post_nms_top_n], prop_cnt [B] (device) */
+size_t mega_rpn_select_workspace_bytes(int B, int pre_nms_top_n);
+int mega_rpn_select(const float* rpn_out, const float* cell_anchors, int B, int Hf, int Wf, int A, int ldc,
+                    int anchor_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int strict_gt,
+                    float min_size, float im_w, float im_h, float* proposals, float* prop_scores, int* prop_cnt,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* Box-head post-processor for one image.  Replaces PostProcessor.forward / filter_results
+ * (modeling/roi_heads/box_head/inference.py:45-149): softmax, per-class decode with (wx,wy,ww,wh), clip,
+ * score > score_thresh, per-class NMS, detections_per_img k-th value cut (>= kth, ties kept).
+ *   logits [R][NC], deltas [R][NC*4], props [R][4], nprop device int or NULL (= R); R <= 1024
+ *   outputs have capacity (NC-1)*R rows; out_cnt is a device int; probs_out [R][NC] optional. */
+size_t mega_postprocess_workspace_bytes(int R, int NC);
+int mega_postprocess(const float* logits, const float* deltas, const float* props, const int* nprop, int R, int NC,
+                     float wx, float wy, float ww, float wh, float im_w, float im_h, float score_thresh,
+                     float nms_thresh, int strict_gt, int max_det, float* out_boxes, float* out_scores,
+                     long long* out_labels, int* out_cnt, float* probs_out, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* Position-embedding logits of the relation module: log(relu(Wg . pe(q,k) + bg) + 1e-6).
+ * Replaces extract_position_matrix + extract_position_embedding + the Wgs 1x1 conv + relu + log
+ * (roi_box_feature_extractors.py:147-176,:126-144,:593-597,:630) without materialising the
+ * [64][Nq][Nk] embedding.  wg_t [64][16] (Wg transposed), bg [16], dim_mat [8] = 1000^(i/8);
+ * out [16][Nq][ldp] f32, ldp >= Nk (attention wants ldp % 32 == 0). */
+int mega_position_logits(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
+                         const float* dim_mat, float* out, int Nq, int Nk, int ldp, void* stream);
+
+/* Relation-attention core (roi_box_feature_extractors.py:599-646): per head h (64-wide)
+ *   out[q][h*64+j] = resid[q][h*64+j] + bias_v[h*64+j]
+ *                    + sum_k softmax_k( scale * q[q][h,:] . k[k][h,:] + pos[h][q][k] ) * vt[h*64+j][k]
+ * q already contains the learned u vector (folded into the Wq bias), vt is V projected by Wv and stored
+ * key-contiguous ([groups*64][ldv], pad columns zero).  pos / resid / bias_v may be NULL. */
+int mega_relation_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
+                            const float* pos, int ldp, const void* resid, int ldr, const float* bias_v, void* out,
+                            int ldo, int Nq, int Nk, int groups, float scale, int dtype, void* stream);
+
+/* Test-time frame transform on device: uint8 HWC RGB [N][H][W][3] -> f32 CHW [N][3][H][W],
+ * ToTensor -> (BGR*255 if to_bgr) -> minus mean, std 1.  Replaces the CPU chain
+ * mega_core/data/transforms/transforms.py:83-129 for frames already at the target size. */
+int mega_preprocess_frames(const unsigned char* in, float* out, int N, int H, int W, float mean0, float mean1,
+                           float mean2, int to_bgr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEGA_HIP_H */

@@ -1,0 +1,62 @@
+"""ctypes binding of libmega_hip.so (include/mega_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmega_hip.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+_ERR = {1: "bad argument", 2: "kernel launch failure", 3: "workspace too small"}
+
+# name -> (restype, argtypes).  Must list every symbol declared in include/mega_hip.h.
+SIGNATURES = {
+    "mega_conv2d_nhwc": (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_void_p]),
+    "mega_stem_conv_bn_relu": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "mega_maxpool3x3s2_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
+    "mega_roi_align_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] + [c_int] * 7 + [c_void_p]),
+    "mega_nms_full_workspace_bytes": (c_size_t, [c_int]),
+    "mega_nms": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mega_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mega_nms_sorted": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_int, c_int] + [c_void_p] * 4 +
+                        [c_size_t, c_void_p]),
+    "mega_rpn_select_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mega_rpn_select": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_float, c_float, c_float] +
+                        [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "mega_postprocess_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mega_postprocess": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_float] * 8 + [c_int, c_int] + [c_void_p] * 6 +
+                         [c_size_t, c_void_p]),
+    "mega_position_logits": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
+    "mega_relation_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                        c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                        c_int, c_void_p]),
+    "mega_preprocess_frames": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libmega_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the MEGA hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (code %d)" % (what, _ERR.get(rc, "unknown"), rc))

@@ -1,0 +1,71 @@
+"""Builds libmega_hip.so (the C-ABI kernel library) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
+gpurun snapshot.  Flags: boxes.hip is built with -ffp-contract=off (see its header).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmega_hip.so")
+STAMP = os.path.join(HERE, "csrc", ".build_stamp")
+SOURCES = {
+    "igemm.hip": [],
+    "spatial.hip": [],
+    "boxes.hip": ["-ffp-contract=off"],
+    "relation.hip": [],
+    "frames.hip": [],
+}
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(CSRC)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(CSRC, fn), "rb").read())
+    h.update(" ".join(BASE_FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip under csrc/ and link libmega_hip.so.  Returns the library path."""
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+        return LIB
+    if not os.path.exists(HIPCC):
+        if os.path.exists(LIB):
+            return LIB  # prebuilt library on a box without the compiler
+        raise RuntimeError("hipcc not found at %s and no prebuilt %s" % (HIPCC, LIB))
+    objs = []
+    procs = []
+    for src, extra in SOURCES.items():
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [HIPCC] + BASE_FLAGS + extra + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
+        if verbose and out:
+            print(out.decode())
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

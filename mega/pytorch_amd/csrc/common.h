@@ -1,0 +1,47 @@
+// Shared device helpers for the MEGA gfx950 kernels (wave64, CDNA4).  No CUDA-compat layer:
+// this header is HIP/gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MEGA_F32 0
+#define MEGA_BF16 1
+
+#define MEGA_OK 0
+#define MEGA_ERR_ARG 1
+#define MEGA_ERR_LAUNCH 2
+#define MEGA_ERR_WS 3
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (same rule torch uses for float -> bfloat16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VE = 4;  // elements per 16-byte vector
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VE = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+static inline int mega_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MEGA_OK : MEGA_ERR_LAUNCH;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

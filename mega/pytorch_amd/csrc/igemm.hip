@@ -1,0 +1,279 @@
+// Implicit-GEMM convolution / linear layer on the gfx950 matrix cores.
+//
+// Replaces (on the MEGA inference path) every dense contraction the reference hands to
+// cuDNN/cuBLAS through torch:  Conv2d + FrozenBatchNorm2d + ReLU (+ residual add) of the
+// ResNet bottlenecks (mega_core/modeling/backbone/resnet.py:324-344, layers/batch_norm.py:19-31),
+// the RPN head convs (modeling/rpn/rpn.py:99-106), the res5 head (resnet.py:155-204), and all
+// nn.Linear layers of the box head (roi_box_feature_extractors.py:894,:907,:826; roi_box_predictors.py:50-57).
+//
+// Layout: activations NHWC  [N][H][W][Cin], weights OHWI [Cout][R][S][Cin] -> both GEMM operands
+// are K-contiguous rows:   C[m][n] = sum_k A[m][k] * Bt[n][k],  m = (n_img, ho, wo), k = (r, s, c).
+// A linear layer is the R=S=1, H=W=1 case.  Epilogue: y = acc*scale[n] + bias[n] (+ residual) (ReLU).
+//
+// Tiling (wave64): 256 threads = 4 waves in a 2x2 grid; block tile BM x BN, K-tile = 128 bytes of K
+// per row (64 bf16 / 32 f32).  Global -> registers (16-B vectors, prefetched one K-tile ahead) ->
+// LDS (row stride 144 B: every 16-row ds_read_b128 group is bank-conflict free) -> MFMA
+// v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact f32).  Two LDS buffers, one
+// barrier per K-tile.  blockIdx -> tile map is XCD-aware (blocks of one XCD share A row panels in
+// that XCD's L2).
+#include "common.h"
+
+namespace {
+
+constexpr int KTB = 128;          // bytes of K per LDS row per K-tile
+constexpr int LDS_STRIDE = 144;   // bytes, 128 + 16 pad
+constexpr int NTHREADS = 256;
+
+struct ConvParams {
+  const void* in;
+  const void* w;
+  const float* scale;
+  const float* bias;
+  const void* res;
+  void* out;
+  int N, H, W, Cin, Cout, R, S, stride, pad, dil, Ho, Wo;
+  int M, K;
+  int ldo, ldr;
+  int relu;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  // a, b: 16 bytes = 8 bf16 along K for row (lane&31), K-half (lane>>5)
+  __device__ static __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+    bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
+    bf16x8_t bv = __builtin_bit_cast(bf16x8_t, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // a, b: 4 f32 along K; MFMA e consumes component e (K order is permuted identically for A and B)
+  __device__ static __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+
+template <typename T, typename OT, int BM, int BN>
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(ConvParams p) {
+  constexpr int KE = KTB / (int)sizeof(T);   // K elements per tile
+  constexpr int VE = 16 / (int)sizeof(T);    // elements per 16-B vector
+  constexpr int AV = BM / 32;                // A vectors per thread per tile
+  constexpr int BV = BN / 32;
+  constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                               // [2][BM][LDS_STRIDE]
+  unsigned char* Bs = smem + 2 * BM * LDS_STRIDE;         // [2][BN][LDS_STRIDE]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware block -> tile map (bijective for any grid size)
+  const int ntn = (p.Cout + BN - 1) / BN;
+  int lid;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tile_m = lid / ntn, tile_n = lid - tile_m * ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const T* __restrict__ in = (const T*)p.in;
+  const T* __restrict__ wt = (const T*)p.w;
+
+  // ---- per-thread load descriptors
+  const int vec = tid & 7;
+  const int lrow = tid >> 3;  // 0..31
+  int a_hi0[AV], a_wi0[AV];
+  size_t a_base[AV];
+  bool a_ok[AV];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int nimg = mm / HoWo;
+    const int rem = mm - nimg * HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    a_hi0[i] = ho * p.stride - p.pad;
+    a_wi0[i] = wo * p.stride - p.pad;
+    a_base[i] = (size_t)nimg * p.H * p.W;
+  }
+  size_t b_off[BV];
+  bool b_ok[BV];
+#pragma unroll
+  for (int j = 0; j < BV; ++j) {
+    const int n = n0 + lrow + 32 * j;
+    b_ok[j] = n < p.Cout;
+    b_off[j] = (size_t)(b_ok[j] ? n : 0) * p.K + vec * VE;
+  }
+
+  uint4 areg[AV], breg[BV];
+  int kr = 0, ks = 0, kc = 0;  // (r, s, c0) of the tile about to be loaded
+  int kk = 0;                  // k offset of that tile
+
+  auto load_tile = [&]() {
+    const int dh = kr * p.dil, dw = ks * p.dil;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
+      const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      if (ok) {
+        const size_t off = (a_base[i] + (size_t)hi * p.W + wi) * p.Cin + kc + vec * VE;
+        areg[i] = *reinterpret_cast<const uint4*>(in + off);
+      } else {
+        areg[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      if (b_ok[j]) breg[j] = *reinterpret_cast<const uint4*>(wt + b_off[j] + kk);
+      else breg[j] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // advance (r, s, c0)
+    kk += KE;
+    kc += KE;
+    if (kc >= p.Cin) {
+      kc = 0;
+      if (++ks == p.S) { ks = 0; ++kr; }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* a = As + buf * BM * LDS_STRIDE;
+    unsigned char* b = Bs + buf * BN * LDS_STRIDE;
+#pragma unroll
+    for (int i = 0; i < AV; ++i)
+      *reinterpret_cast<uint4*>(a + (lrow + 32 * i) * LDS_STRIDE + vec * 16) = areg[i];
+#pragma unroll
+    for (int j = 0; j < BV; ++j)
+      *reinterpret_cast<uint4*>(b + (lrow + 32 * j) * LDS_STRIDE + vec * 16) = breg[j];
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = p.K / KE;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * LDS_STRIDE + (lane >> 5) * 16;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1) < nkt;
+    if (more) load_tile();
+    const unsigned char* a = As + cur * BM * LDS_STRIDE + (wm * WTM) * LDS_STRIDE + frag_off;
+    const unsigned char* b = Bs + cur * BN * LDS_STRIDE + (wn * WTN) * LDS_STRIDE + frag_off;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      uint4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(a + i * 32 * LDS_STRIDE + s4 * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const uint4*>(b + j * 32 * LDS_STRIDE + s4 * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns column n = (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+  OT* __restrict__ out = (OT*)p.out;
+  const T* __restrict__ res = (const T*)p.res;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+    if (n >= p.Cout) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m < p.M) {
+          float v = acc[i][j][r] * sc + bi;
+          if (res) v += Elem<T>::ld(res + (size_t)m * p.ldr + n);
+          if (p.relu) v = fmaxf(v, 0.f);
+          Elem<OT>::st(out + (size_t)m * p.ldo + n, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, typename OT, int BM, int BN>
+int launch(const ConvParams& p, hipStream_t st) {
+  const int ntm = cdiv(p.M, BM), ntn = cdiv(p.Cout, BN);
+  const size_t smem = 2 * (BM + BN) * LDS_STRIDE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, OT, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_kernel<T, OT, BM, BN>), dim3(ntm * ntn), dim3(NTHREADS), smem, st, p);
+  return mega_check_launch();
+}
+
+template <typename T, typename OT>
+int dispatch_tile(const ConvParams& p, hipStream_t st) {
+  // Tile choice: big tiles when they still give >= ~1.5 waves of blocks over 256 CUs, else shrink.
+  const long b128 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 128);
+  const long b12864 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 64);
+  if (p.Cout > 64 && b128 >= 384) return launch<T, OT, 128, 128>(p, st);
+  if (b12864 >= 384) return launch<T, OT, 128, 64>(p, st);
+  return launch<T, OT, 64, 64>(p, st);
+}
+
+}  // namespace
+
+extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scale, const float* bias,
+                                const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
+                                int R, int S, int stride, int pad, int dil, int relu, int ldo, int ldr,
+                                int in_dtype, int out_dtype, void* stream) {
+  if (!in || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
+      dil <= 0 || pad < 0)
+    return MEGA_ERR_ARG;
+  ConvParams p;
+  p.in = in; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.out = out;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
+  p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) return MEGA_ERR_ARG;
+  p.M = N * p.Ho * p.Wo;
+  p.K = R * S * Cin;
+  p.ldo = ldo > 0 ? ldo : Cout;
+  p.ldr = ldr > 0 ? ldr : Cout;
+  p.relu = relu;
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == MEGA_BF16) {
+    if (Cin % 64 != 0) return MEGA_ERR_ARG;
+    if (out_dtype == MEGA_BF16) return dispatch_tile<bf16_t, bf16_t>(p, st);
+    if (out_dtype == MEGA_F32) return dispatch_tile<bf16_t, float>(p, st);
+    return MEGA_ERR_ARG;
+  }
+  if (in_dtype == MEGA_F32) {
+    if (Cin % 32 != 0 || out_dtype != MEGA_F32) return MEGA_ERR_ARG;
+    return dispatch_tile<float, float>(p, st);
+  }
+  return MEGA_ERR_ARG;
+}

@@ -1,0 +1,359 @@
+// MEGA relation module (multi-head relation attention over proposal features).
+//
+// Reference: mega_core/modeling/roi_heads/box_head/roi_box_feature_extractors.py
+//   :147-176 extract_position_matrix, :126-144 extract_position_embedding, :240-250 cal_position_embedding
+//   :567-646 MEGAFeatureExtractor.attention_module_multi_head
+//
+//   aff[q,h,k]  = ((q_h + u_h) . k_h) / sqrt(64)            (:613-627; u folded into the Q projection bias)
+//   w[q,h,k]    = log(relu(Wg_h . pe(q,k) + bg_h) + 1e-6)   (:593-597,:630)  -- "local"/"memory" only
+//   P           = softmax_k(aff + w)                         (:633)
+//   out[q, h*64+j] = sum_k P[q,h,k] * (V Wv_h^T)[k, j] + bv  (:638-644; the grouped 1x1 conv Wv is applied to
+//                    V *before* the PV contraction: sum_k P = 1, so the result is identical up to f32
+//                    reassociation and the [Nq*16, 1024] intermediate is never formed)
+//
+// Kernels:
+//   pos_logits_kernel : boxes -> w[h][q][k] (f32), one thread per (q,k) pair, 64-d sin/cos embedding and the
+//                       16x64 Wg contraction in registers (Wg read through the scalar cache).
+//   attn_kernel<T>    : flash-style streaming softmax.  One wave owns 32 query rows of one head; per 32-key tile
+//                       S^T = K Q^T on MFMA (so a lane holds 16 keys of ONE query: row max / sum are register
+//                       reductions + one cross-half shuffle), P feeds the PV MFMA straight from registers,
+//                       V is consumed from a key-contiguous (transposed) LDS image.  bf16 -> mfma_32x32x16_bf16,
+//                       f32 -> mfma_32x32x2_f32 (exact f32, parity mode).
+#include "common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------- position logits
+// rois_q [Nq][4], rois_k [Nk][4], wgt [64][16] (Wg transposed), bg [16], dim_mat [8]
+// out [16][Nq][ldp] f32
+__global__ __launch_bounds__(256) void pos_logits_kernel(const float4* __restrict__ rois_q,
+                                                         const float4* __restrict__ rois_k,
+                                                         const float* __restrict__ wgt, const float* __restrict__ bg,
+                                                         const float* __restrict__ dim_mat, float* __restrict__ out,
+                                                         int Nq, int Nk, int ldp) {
+  const int q = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= Nk) return;
+  const float4 bq = rois_q[q];
+  const float4 bk = rois_k[k];
+  // :147-176 (bbox = query rois, ref_bbox = key rois)
+  const float wq = bq.z - bq.x + 1.f, hq = bq.w - bq.y + 1.f;
+  const float cxq = 0.5f * (bq.x + bq.z), cyq = 0.5f * (bq.y + bq.w);
+  const float wk = bk.z - bk.x + 1.f, hk = bk.w - bk.y + 1.f;
+  const float cxk = 0.5f * (bk.x + bk.z), cyk = 0.5f * (bk.y + bk.w);
+  float pm[4];
+  pm[0] = logf(fabsf((cxq - cxk) / wq) + 1e-3f);
+  pm[1] = logf(fabsf((cyq - cyk) / hq) + 1e-3f);
+  pm[2] = logf(wq / wk);
+  pm[3] = logf(hq / hk);
+  float acc[16];
+#pragma unroll
+  for (int h = 0; h < 16; ++h) acc[h] = bg[h];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float pv = pm[d] * 100.0f;
+    for (int i = 0; i < 8; ++i) {
+      const float a = pv / dim_mat[i];
+      float sn, cs;
+      sincosf(a, &sn, &cs);
+      const float* ws = wgt + (d * 16 + i) * 16;      // embedding index d*16 + i     (sin block)
+      const float* wc = wgt + (d * 16 + 8 + i) * 16;  // embedding index d*16 + 8 + i (cos block)
+#pragma unroll
+      for (int h = 0; h < 16; ++h) acc[h] = fmaf(sn, ws[h], acc[h]);
+#pragma unroll
+      for (int h = 0; h < 16; ++h) acc[h] = fmaf(cs, wc[h], acc[h]);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 16; ++h)
+    out[((size_t)h * Nq + q) * ldp + k] = logf(fmaxf(acc[h], 0.f) + 1e-6f);
+}
+
+// ----------------------------------------------------------------------------------------------- attention
+template <typename T> struct AttnCfg;
+template <> struct AttnCfg<bf16_t> {
+  static constexpr int KROW = 144;   // Ks row stride (64 bf16 = 128 B + 16)
+  static constexpr int VROW = 72;    // Vs row stride (32 bf16 = 64 B + 8)
+  static constexpr int NQF = 4;      // 16-B vectors per lane for a 64-wide head slice
+  static constexpr int NPV = 2;      // P A-vectors per 32-key tile
+  static constexpr int NLD = 1;      // 16-B loads per thread per tile (K and V each)
+};
+template <> struct AttnCfg<float> {
+  static constexpr int KROW = 272;   // 256 B + 16
+  static constexpr int VROW = 144;   // 128 B + 16
+  static constexpr int NQF = 8;
+  static constexpr int NPV = 4;
+  static constexpr int NLD = 2;
+};
+
+template <typename T> struct Mma32;
+template <> struct Mma32<bf16_t> {
+  __device__ static __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
+                                                  0, 0, 0);
+  }
+};
+template <> struct Mma32<float> {
+  __device__ static __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+struct AttnParams {
+  const void* Q; int ldq;     // [Nq][ldq], head h in columns h*64 .. h*64+63  (u already folded in)
+  const void* K; int ldk;     // [Nk][ldk]
+  const void* Vt; int ldv;    // [G*64][ldv]  row h*64+dv, column = key (V already projected by Wv)
+  const float* pos; int ldp;  // [G][Nq][ldp] additive logits or null
+  const void* resid; int ldr; // [Nq][ldr] residual (feats_cur) or null
+  const float* bias_v;        // [G*64] or null
+  void* out; int ldo;         // [Nq][ldo]
+  int Nq, Nk;
+  float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+  using C = AttnCfg<T>;
+  constexpr int VE = 16 / (int)sizeof(T);
+  constexpr int KV_PER_ROW = 64 * (int)sizeof(T) / 16;  // 16-B vectors per K row
+  constexpr int VV_PER_ROW = 32 * (int)sizeof(T) / 16;  // 16-B vectors per V^T row (32 keys)
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[2][32 * C::KROW];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[2][64 * C::VROW];
+  __shared__ __attribute__((aligned(16))) float sRow[4][32];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y;
+  const int qw0 = blockIdx.x * 128 + wave * 32;  // first query row of this wave
+  const T* __restrict__ Qp = (const T*)p.Q;
+  const T* __restrict__ Kp = (const T*)p.K;
+  const T* __restrict__ Vp = (const T*)p.Vt;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): row q = qw0 + l31, vector v at bytes v*32 + h2*16
+  const int q_ld = min(qw0 + l31, p.Nq - 1);
+  uint4 qf[C::NQF];
+  {
+    const unsigned char* qrow = (const unsigned char*)(Qp + (size_t)q_ld * p.ldq + head * 64);
+#pragma unroll
+    for (int v = 0; v < C::NQF; ++v) qf[v] = *reinterpret_cast<const uint4*>(qrow + v * 32 + h2 * 16);
+  }
+
+  // ---- cooperative tile loads
+  uint4 kreg[C::NLD], vreg[C::NLD];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+      const int idx = tid + 256 * i;
+      {  // K tile: 32 keys x 64 d
+        const int row = idx / KV_PER_ROW, vec = idx - row * KV_PER_ROW;
+        const int key = k0 + row;
+        if (key < p.Nk) kreg[i] = *reinterpret_cast<const uint4*>(Kp + (size_t)key * p.ldk + head * 64 + vec * VE);
+        else kreg[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      {  // V^T tile: 64 dv x 32 keys
+        const int row = idx / VV_PER_ROW, vec = idx - row * VV_PER_ROW;
+        const int key = k0 + vec * VE;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (key < p.Nk) {
+          v = *reinterpret_cast<const uint4*>(Vp + (size_t)(head * 64 + row) * p.ldv + key);
+          if (key + VE > p.Nk) {  // zero the tail keys (pad columns of Vt are not guaranteed finite)
+            T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+            for (int t = 0; t < VE; ++t)
+              if (key + t >= p.Nk) e[t] = (T)0;
+          }
+        }
+        vreg[i] = v;
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+      const int idx = tid + 256 * i;
+      {
+        const int row = idx / KV_PER_ROW, vec = idx - row * KV_PER_ROW;
+        *reinterpret_cast<uint4*>(&Ks[buf][row * C::KROW + vec * 16]) = kreg[i];
+      }
+      {
+        const int row = idx / VV_PER_ROW, vec = idx - row * VV_PER_ROW;
+        unsigned char* dst = &Vs[buf][row * C::VROW + vec * 16];
+        if (sizeof(T) == 2) {  // 72-B rows: 8-B aligned only
+          *reinterpret_cast<uint2*>(dst) = make_uint2(vreg[i].x, vreg[i].y);
+          *reinterpret_cast<uint2*>(dst + 8) = make_uint2(vreg[i].z, vreg[i].w);
+        } else {
+          *reinterpret_cast<uint4*>(dst) = vreg[i];
+        }
+      }
+    }
+  };
+
+  f32x16_t o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const float* pos_row = p.pos ? p.pos + ((size_t)head * p.Nq + q_ld) * p.ldp : nullptr;
+  const int ntiles = (p.Nk + 31) / 32;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    const int k0 = kt * 32;
+    const bool more = (kt + 1) < ntiles;
+    if (more) load_tiles(k0 + 32);
+
+    // ---- S^T[key][q] = sum_d K[key][d] * Q[q][d]
+    f32x16_t st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    {
+      const unsigned char* kb = &Ks[cur][l31 * C::KROW + h2 * 16];
+#pragma unroll
+      for (int v = 0; v < C::NQF; ++v) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(kb + v * 32);
+        Mma32<T>::run(st, kf, qf[v]);
+      }
+    }
+    // lane: query q = qw0 + l31, keys k0 + (r&3) + 8*(r>>2) + 4*h2
+    float s[16];
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pos_row) pw = *reinterpret_cast<const float4*>(pos_row + k0 + 8 * rq + 4 * h2);
+      const float pe[4] = {pw.x, pw.y, pw.z, pw.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = k0 + 8 * rq + 4 * h2 + e;
+        const float v = st[4 * rq + e] * p.scale + pe[e];
+        s[4 * rq + e] = key < p.Nk ? v : -INFINITY;
+      }
+    }
+    float mt = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = expf(s[r] - m_new);
+      psum += s[r];
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+
+    // ---- rescale O: alpha is per query (lane&31) but O rows are (r&3)+8*(r>>2)+4*h2 -> exchange through LDS
+    if (h2 == 0) sRow[wave][l31] = alpha;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&sRow[wave][8 * rq + 4 * h2]);
+      o0[4 * rq + 0] *= a4.x; o0[4 * rq + 1] *= a4.y; o0[4 * rq + 2] *= a4.z; o0[4 * rq + 3] *= a4.w;
+      o1[4 * rq + 0] *= a4.x; o1[4 * rq + 1] *= a4.y; o1[4 * rq + 2] *= a4.z; o1[4 * rq + 3] *= a4.w;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- O[q][dv] += sum_key P[q][key] * V[key][dv]
+    {
+      const unsigned char* vb0 = &Vs[cur][l31 * C::VROW];
+      const unsigned char* vb1 = &Vs[cur][(32 + l31) * C::VROW];
+#pragma unroll
+      for (int u = 0; u < C::NPV; ++u) {
+        uint4 pa, v0, v1;
+        if (sizeof(T) == 2) {
+          pa.x = pack_bf16x2(s[8 * u + 0], s[8 * u + 1]);
+          pa.y = pack_bf16x2(s[8 * u + 2], s[8 * u + 3]);
+          pa.z = pack_bf16x2(s[8 * u + 4], s[8 * u + 5]);
+          pa.w = pack_bf16x2(s[8 * u + 6], s[8 * u + 7]);
+          const int off = (16 * u + 4 * h2) * 2;
+          const uint2 a0 = *reinterpret_cast<const uint2*>(vb0 + off);
+          const uint2 a1 = *reinterpret_cast<const uint2*>(vb0 + off + 16);
+          const uint2 b0 = *reinterpret_cast<const uint2*>(vb1 + off);
+          const uint2 b1 = *reinterpret_cast<const uint2*>(vb1 + off + 16);
+          v0 = make_uint4(a0.x, a0.y, a1.x, a1.y);
+          v1 = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        } else {
+          pa.x = __float_as_uint(s[4 * u + 0]);
+          pa.y = __float_as_uint(s[4 * u + 1]);
+          pa.z = __float_as_uint(s[4 * u + 2]);
+          pa.w = __float_as_uint(s[4 * u + 3]);
+          const int off = (8 * u + 4 * h2) * 4;
+          v0 = *reinterpret_cast<const uint4*>(vb0 + off);
+          v1 = *reinterpret_cast<const uint4*>(vb1 + off);
+        }
+        Mma32<T>::run(o0, pa, v0);
+        Mma32<T>::run(o1, pa, v1);
+      }
+    }
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and write: out[q'][head*64 + dv] = resid + O/l + bias_v
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (h2 == 0) sRow[wave][l31] = 1.f / l_tot;
+  __builtin_amdgcn_wave_barrier();
+  const T* __restrict__ resid = (const T*)p.resid;
+  T* __restrict__ out = (T*)p.out;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int col = head * 64 + jj * 32 + l31;
+    const float bv = p.bias_v ? p.bias_v[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = (r & 3) + 8 * (r >> 2) + 4 * h2;
+      const int q = qw0 + ql;
+      if (q < p.Nq) {
+        float v = (jj == 0 ? o0[r] : o1[r]) * sRow[wave][ql] + bv;
+        if (resid) v += Elem<T>::ld(resid + (size_t)q * p.ldr + col);
+        Elem<T>::st(out + (size_t)q * p.ldo + col, v);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// w[h][q][k] = log(relu(Wg_h . pe(q,k) + bg_h) + 1e-6);  out [16][Nq][ldp] f32, ldp >= Nk
+extern "C" int mega_position_logits(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
+                                    const float* dim_mat, float* out, int Nq, int Nk, int ldp, void* stream) {
+  if (Nq == 0 || Nk == 0) return MEGA_OK;
+  if (!rois_q || !rois_k || !wg_t || !bg || !dim_mat || !out || Nq < 0 || Nk < 0 || ldp < Nk) return MEGA_ERR_ARG;
+  hipLaunchKernelGGL(pos_logits_kernel, dim3(cdiv(Nk, 256), Nq), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)rois_q, (const float4*)rois_k, wg_t, bg, dim_mat, out, Nq, Nk, ldp);
+  return mega_check_launch();
+}
+
+// Multi-head relation attention core (16 heads x 64).  See header comment for the formula.
+extern "C" int mega_relation_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
+                                       const float* pos, int ldp, const void* resid, int ldr, const float* bias_v,
+                                       void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype,
+                                       void* stream) {
+  if (Nq == 0) return MEGA_OK;
+  if (!q || !k || !vt || !out || Nq < 0 || Nk <= 0 || groups <= 0) return MEGA_ERR_ARG;
+  const int ve = dtype == MEGA_BF16 ? 8 : 4;
+  if (ldq % ve || ldk % ve || ldv % ve || (pos && (ldp % 32 || ldp < Nk))) return MEGA_ERR_ARG;
+  if (ldv < ((Nk + ve - 1) / ve) * ve) return MEGA_ERR_ARG;
+  AttnParams p;
+  p.Q = q; p.ldq = ldq; p.K = k; p.ldk = ldk; p.Vt = vt; p.ldv = ldv; p.pos = pos; p.ldp = ldp;
+  p.resid = resid; p.ldr = ldr; p.bias_v = bias_v; p.out = out; p.ldo = ldo; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
+  dim3 grid(cdiv(Nq, 128), groups);
+  if (dtype == MEGA_BF16)
+    hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (dtype == MEGA_F32)
+    hipLaunchKernelGGL((attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else
+    return MEGA_ERR_ARG;
+  return mega_check_launch();
+}

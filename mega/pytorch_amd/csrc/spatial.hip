@@ -1,0 +1,232 @@
+// Spatial (non-GEMM) kernels of the backbone / box head:
+//   * stem: 7x7 stride-2 conv (3 -> 64) + FrozenBN + ReLU      (mega_core/modeling/backbone/resnet.py:347-366)
+//   * 3x3 stride-2 max-pool                                      (resnet.py:365)
+//   * ROIAlign forward                                           (mega_core/csrc/cuda/ROIAlign_cuda.cu:15-122,
+//                                                                 csrc/cpu/ROIAlign_cpu.cpp:18-219)
+// Activations are NHWC so that a pixel's channels are one contiguous, coalesced run.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ stem conv
+// in : NCHW f32 [N][3][H][W] (the reference's image tensor layout)
+// w  : [147][64] f32, tap = (c*7 + r)*7 + s   (host repack of OIHW [64][3][7][7])
+// out: NHWC [N][Ho][Wo][64]
+constexpr int ST_T = 16;                      // output tile edge
+constexpr int ST_P = ST_T * 2 + 5;            // 37 input rows/cols per tile
+constexpr int ST_PW = ST_P + 1;               // padded row length
+
+template <typename OT>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ bias, OT* __restrict__ out, int N,
+                                                        int H, int W, int Ho, int Wo) {
+  __shared__ float patch[3][ST_P][ST_PW];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.z;
+  const int oy0 = blockIdx.y * ST_T, ox0 = blockIdx.x * ST_T;
+  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+  for (int e = tid; e < 3 * ST_P * ST_P; e += 256) {
+    const int c = e / (ST_P * ST_P);
+    const int rem = e - c * ST_P * ST_P;
+    const int y = rem / ST_P, x = rem - y * ST_P;
+    const int iy = iy0 + y, ix = ix0 + x;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = in[((size_t)(n * 3 + c) * H + iy) * W + ix];
+    patch[c][y][x] = v;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  float acc[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) acc[k] = 0.f;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 7; ++r) {
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        const float v = patch[c][2 * ty + r][2 * tx + s];
+        const float* wp = w + ((c * 7 + r) * 7 + s) * 64;  // wave-uniform address -> scalar loads
+#pragma unroll
+        for (int k = 0; k < 64; ++k) acc[k] = fmaf(v, wp[k], acc[k]);
+      }
+    }
+  if (oy < Ho && ox < Wo) {
+    OT* o = out + (((size_t)n * Ho + oy) * Wo + ox) * 64;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      float v = acc[k] * scale[k] + bias[k];
+      v = fmaxf(v, 0.f);
+      Elem<OT>::st(o + k, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ max-pool 3x3 s2 p1
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H,
+                                                      int W, int C, int Ho, int Wo) {
+  constexpr int VE = Elem<T>::VE;
+  const int cv = C / VE;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % cv);
+    size_t pix = idx / cv;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    float m[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) m[e] = -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int hi = ho * 2 - 1 + dy;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int wi = wo * 2 - 1 + dx;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const uint4 raw = *reinterpret_cast<const uint4*>(in + (((size_t)n * H + hi) * W + wi) * C + v * VE);
+        const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) m[e] = fmaxf(m[e], Elem<T>::ld(rv + e));
+      }
+    }
+    uint4 o;
+    T* ov = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) Elem<T>::st(ov + e, m[e]);
+    *reinterpret_cast<uint4*>(out + (((size_t)n * Ho + ho) * Wo + wo) * C + v * VE) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------ ROIAlign forward
+// feat: NHWC [B][H][W][C] (in_nhwc=1) or NCHW [B][C][H][W] (in_nhwc=0)
+// rois: [K][5] f32 = (batch_idx, x1, y1, x2, y2)
+// out : bin-major [K][ph*pw][C] (out_nhwc=1; fc weights are permuted to match) or the reference's
+//       [K][C][ph][pw] (out_nhwc=0).
+// One block per (roi, ph, pw) bin; threads stride over channels.  The sample geometry is block-uniform.
+// Arithmetic follows ROIAlign_cuda.cu:64-122 term by term: no rounding of the scaled ROI, min size 1,
+// adaptive grid ceil(roi/pooled) when sampling_ratio <= 0, bilinear weights hy*hx.., mean over samples.
+template <typename T, typename OT>
+__global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ feat, const float* __restrict__ rois,
+                                                        OT* __restrict__ out, int K, int C, int H, int W,
+                                                        float spatial_scale, int PH, int PW, int sampling_ratio,
+                                                        int in_nhwc, int out_nhwc) {
+  const int bin = blockIdx.x;
+  const int pw = bin % PW;
+  const int ph = (bin / PW) % PH;
+  const int k = bin / (PW * PH);
+  const float* roi = rois + (size_t)k * 5;
+  const int b = (int)roi[0];
+  const float roi_start_w = roi[1] * spatial_scale;
+  const float roi_start_h = roi[2] * spatial_scale;
+  const float roi_end_w = roi[3] * spatial_scale;
+  const float roi_end_h = roi[4] * spatial_scale;
+  const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.f);
+  const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.f);
+  const float bin_size_h = roi_height / (float)PH;
+  const float bin_size_w = roi_width / (float)PW;
+  const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)PH);
+  const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)PW);
+  const float count = (float)(grid_h * grid_w);
+
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float output_val = 0.f;
+    for (int iy = 0; iy < grid_h; ++iy) {
+      const float y0 = roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)grid_h;
+      for (int ix = 0; ix < grid_w; ++ix) {
+        const float x0 = roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)grid_w;
+        float y = y0, x = x0;
+        if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;  // contributes 0
+        if (y <= 0.f) y = 0.f;
+        if (x <= 0.f) x = 0.f;
+        int y_low = (int)y, x_low = (int)x, y_high, x_high;
+        if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+        if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+        const float ly = y - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
+        float v1, v2, v3, v4;
+        if (in_nhwc) {
+          const T* base = feat + (size_t)b * H * W * C + c;
+          v1 = Elem<T>::ld(base + ((size_t)y_low * W + x_low) * C);
+          v2 = Elem<T>::ld(base + ((size_t)y_low * W + x_high) * C);
+          v3 = Elem<T>::ld(base + ((size_t)y_high * W + x_low) * C);
+          v4 = Elem<T>::ld(base + ((size_t)y_high * W + x_high) * C);
+        } else {
+          const T* base = feat + ((size_t)b * C + c) * H * W;
+          v1 = Elem<T>::ld(base + y_low * W + x_low);
+          v2 = Elem<T>::ld(base + y_low * W + x_high);
+          v3 = Elem<T>::ld(base + y_high * W + x_low);
+          v4 = Elem<T>::ld(base + y_high * W + x_high);
+        }
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        output_val += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+      }
+    }
+    output_val /= count;
+    if (out_nhwc)
+      Elem<OT>::st(out + ((size_t)k * PH * PW + ph * PW + pw) * C + c, output_val);
+    else
+      Elem<OT>::st(out + (((size_t)k * C + c) * PH + ph) * PW + pw, output_val);
+  }
+}
+
+}  // namespace
+
+extern "C" int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, const float* scale, const float* bias,
+                                      void* out, int N, int H, int W, int out_dtype, void* stream) {
+  if (!in || !w_tap64 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  dim3 grid(cdiv(Wo, ST_T), cdiv(Ho, ST_T), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == MEGA_BF16)
+    hipLaunchKernelGGL((stem_conv_kernel<bf16_t>), grid, dim3(256), 0, st, in, w_tap64, scale, bias, (bf16_t*)out, N, H,
+                       W, Ho, Wo);
+  else if (out_dtype == MEGA_F32)
+    hipLaunchKernelGGL((stem_conv_kernel<float>), grid, dim3(256), 0, st, in, w_tap64, scale, bias, (float*)out, N, H, W,
+                       Ho, Wo);
+  else
+    return MEGA_ERR_ARG;
+  return mega_check_launch();
+}
+
+extern "C" int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream) {
+  if (!in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MEGA_ERR_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MEGA_BF16) {
+    if (C % 8) return MEGA_ERR_ARG;
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL((maxpool_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, N, H,
+                       W, C, Ho, Wo);
+  } else if (dtype == MEGA_F32) {
+    if (C % 4) return MEGA_ERR_ARG;
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL((maxpool_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, N, H, W,
+                       C, Ho, Wo);
+  } else {
+    return MEGA_ERR_ARG;
+  }
+  return mega_check_launch();
+}
+
+extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out, int K, int C, int H, int W,
+                                  float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, int in_nhwc,
+                                  int out_nhwc, int dtype, int out_dtype, void* stream) {
+  if (K == 0) return MEGA_OK;
+  if (!feat || !rois || !out || K < 0 || C <= 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0)
+    return MEGA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)(K * pooled_h * pooled_w));
+  const int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+  if (dtype == MEGA_BF16 && out_dtype == MEGA_BF16)
+    hipLaunchKernelGGL((roi_align_kernel<bf16_t, bf16_t>), grid, dim3(threads), 0, st, (const bf16_t*)feat, rois,
+                       (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio, in_nhwc, out_nhwc);
+  else if (dtype == MEGA_F32 && out_dtype == MEGA_F32)
+    hipLaunchKernelGGL((roi_align_kernel<float, float>), grid, dim3(threads), 0, st, (const float*)feat, rois,
+                       (float*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio, in_nhwc, out_nhwc);
+  else
+    return MEGA_ERR_ARG;
+  return mega_check_launch();
+}

@@ -1,0 +1,230 @@
+"""Tensor-level wrappers over the C ABI (include/mega_hip.h).
+
+torch is used here only for device memory and the current HIP stream; every computation is a
+hand-written gfx950 kernel in libmega_hip.so.  All wrappers raise if the library is missing, a
+tensor is not on a HIP device, or a kernel call returns non-zero -- there is no CPU fallback.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mega.pytorch_amd ops need HIP device tensors (no CPU path)")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ conv / linear
+def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,
+                out=None):
+    """x [N,H,W,Cin] (contiguous), w [Cout,R,S,Cin] -> [N,Ho,Wo,Cout].  y = conv*scale + bias (+res) (relu)."""
+    _gpu(x, w, scale, bias, residual)
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    Cout, R, S, Cin2 = w.shape
+    assert Cin == Cin2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    odt = x.dtype if out_dtype is None else out_dtype
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=odt, device=x.device)
+    else:
+        assert out.dtype == odt and out.shape == (N, Ho, Wo, Cout) and out.is_contiguous()
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == x.dtype and residual.is_contiguous()
+    for v in (scale, bias):
+        assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
+    rc = lib.mega_conv2d_nhwc(_ptr(x), _ptr(w), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin,
+                              Cout, R, S, stride, pad, dil, int(relu), Cout, Cout, _dt(x), _DT[odt], _stream())
+    _lib.check(rc, "mega_conv2d_nhwc")
+    return out
+
+
+def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None):
+    """x [M,K], w [Nout,K] (nn.Linear layout) -> [M,Nout]."""
+    M, K = x.shape
+    y = conv2d_nhwc(x.view(M, 1, 1, K), w.view(w.shape[0], 1, 1, K), scale=scale, bias=bias,
+                    residual=None if residual is None else residual.view(M, 1, 1, -1), relu=relu,
+                    out_dtype=out_dtype)
+    return y.view(M, w.shape[0])
+
+
+def stem(x_nchw, w_tap64, scale, bias, out_dtype):
+    """x [N,3,H,W] f32 -> conv7x7 s2 + BN + ReLU -> NHWC [N,Ho,Wo,64]."""
+    _gpu(x_nchw, w_tap64, scale, bias)
+    lib = _lib.load()
+    N, C, H, W = x_nchw.shape
+    assert C == 3 and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, Ho, Wo, 64), dtype=out_dtype, device=x_nchw.device)
+    rc = lib.mega_stem_conv_bn_relu(_ptr(x_nchw), _ptr(w_tap64), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
+                                    _DT[out_dtype], _stream())
+    _lib.check(rc, "mega_stem_conv_bn_relu")
+    return out
+
+
+def maxpool3x3s2(x):
+    _gpu(x)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    assert x.is_contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    rc = lib.mega_maxpool3x3s2_nhwc(_ptr(x), _ptr(out), N, H, W, C, _dt(x), _stream())
+    _lib.check(rc, "mega_maxpool3x3s2_nhwc")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ ROIAlign
+def roi_align(feat, rois, spatial_scale, pooled, sampling_ratio, in_nhwc=True, out_nhwc=True):
+    """feat NHWC [B,H,W,C] (or NCHW when in_nhwc=False); rois [K,5] f32 -> [K,ph*pw,C] (or [K,C,ph,pw])."""
+    _gpu(feat, rois)
+    lib = _lib.load()
+    if in_nhwc:
+        B, H, W, C = feat.shape
+    else:
+        B, C, H, W = feat.shape
+    ph, pw = pooled
+    K = rois.shape[0]
+    assert feat.is_contiguous() and rois.dtype == torch.float32 and rois.is_contiguous() and rois.shape[1] == 5
+    shape = (K, ph * pw, C) if out_nhwc else (K, C, ph, pw)
+    out = torch.empty(shape, dtype=feat.dtype, device=feat.device)
+    rc = lib.mega_roi_align_fwd(_ptr(feat), _ptr(rois), _ptr(out), K, C, H, W, float(spatial_scale), ph, pw,
+                                int(sampling_ratio), int(in_nhwc), int(out_nhwc), _dt(feat), _dt(feat), _stream())
+    _lib.check(rc, "mega_roi_align_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ NMS
+def nms(dets, scores, thr, strict_gt=True):
+    """Kept ORIGINAL indices ascending (int64), reference mega_core._C.nms semantics.  One host sync (size)."""
+    _gpu(dets, scores)
+    lib = _lib.load()
+    n = dets.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dets.device)
+    dets = dets.contiguous().float()
+    scores = scores.contiguous().float()
+    keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    nb = lib.mega_nms_full_workspace_bytes(n)
+    ws = _ws(nb, dets.device)
+    rc = lib.mega_nms(_ptr(dets), _ptr(scores), n, float(thr), int(strict_gt), _ptr(keep), _ptr(cnt), _ptr(ws), nb,
+                      _stream())
+    _lib.check(rc, "mega_nms")
+    return keep[: int(cnt.item())]
+
+
+def rpn_select(rpn_out, cell_anchors, Hf, Wf, anchor_stride, pre_nms, post_nms, nms_thresh, min_size, im_w, im_h,
+               strict_gt=True):
+    """rpn_out [B,Hf*Wf,5A] f32 -> proposals [B,post_nms,4], scores [B,post_nms], counts [B] (all on device)."""
+    _gpu(rpn_out, cell_anchors)
+    lib = _lib.load()
+    B = rpn_out.shape[0]
+    A = cell_anchors.shape[0]
+    ldc = rpn_out.shape[-1]
+    assert rpn_out.dtype == torch.float32 and rpn_out.is_contiguous() and rpn_out.numel() == B * Hf * Wf * ldc
+    k = min(pre_nms, Hf * Wf * A)
+    props = torch.empty((B, post_nms, 4), dtype=torch.float32, device=rpn_out.device)
+    scores = torch.empty((B, post_nms), dtype=torch.float32, device=rpn_out.device)
+    cnt = torch.empty((B,), dtype=torch.int32, device=rpn_out.device)
+    nb = lib.mega_rpn_select_workspace_bytes(B, k)
+    ws = _ws(nb, rpn_out.device)
+    rc = lib.mega_rpn_select(_ptr(rpn_out), _ptr(cell_anchors), B, Hf, Wf, A, ldc, anchor_stride, pre_nms, post_nms,
+                             float(nms_thresh), int(strict_gt), float(min_size), float(im_w), float(im_h),
+                             _ptr(props), _ptr(scores), _ptr(cnt), _ptr(ws), nb, _stream())
+    _lib.check(rc, "mega_rpn_select")
+    return props, scores, cnt
+
+
+def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh, nms_thresh, max_det,
+                strict_gt=True, want_probs=False):
+    """One image: returns (boxes [cap,4], scores [cap], labels [cap] i64, count [1] i32 device[, probs])."""
+    _gpu(logits, deltas, props)
+    lib = _lib.load()
+    R, NC = logits.shape
+    cap = (NC - 1) * R
+    dev = logits.device
+    ob = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+    os_ = torch.empty((cap,), dtype=torch.float32, device=dev)
+    ol = torch.empty((cap,), dtype=torch.int64, device=dev)
+    oc = torch.zeros((1,), dtype=torch.int32, device=dev)
+    probs = torch.empty((R, NC), dtype=torch.float32, device=dev) if want_probs else None
+    nb = lib.mega_postprocess_workspace_bytes(R, NC)
+    ws = _ws(nb, dev)
+    assert logits.dtype == torch.float32 and deltas.dtype == torch.float32 and props.dtype == torch.float32
+    assert logits.is_contiguous() and deltas.is_contiguous() and props.is_contiguous()
+    wx, wy, ww, wh = weights
+    rc = lib.mega_postprocess(_ptr(logits), _ptr(deltas), _ptr(props), _ptr(nprop), R, NC, wx, wy, ww, wh,
+                              float(im_w), float(im_h), float(score_thresh), float(nms_thresh), int(strict_gt),
+                              int(max_det), _ptr(ob), _ptr(os_), _ptr(ol), _ptr(oc), _ptr(probs), _ptr(ws), nb,
+                              _stream())
+    _lib.check(rc, "mega_postprocess")
+    return (ob, os_, ol, oc, probs) if want_probs else (ob, os_, ol, oc)
+
+
+# ------------------------------------------------------------------------------------------------ relation module
+def position_logits(rois_q, rois_k, wg_t, bg, dim_mat):
+    """-> [16, Nq, ldp] f32 with ldp = roundup(Nk, 32)."""
+    _gpu(rois_q, rois_k, wg_t, bg, dim_mat)
+    lib = _lib.load()
+    Nq, Nk = rois_q.shape[0], rois_k.shape[0]
+    ldp = (Nk + 31) // 32 * 32
+    out = torch.empty((16, Nq, ldp), dtype=torch.float32, device=rois_q.device)
+    rc = lib.mega_position_logits(_ptr(rois_q.contiguous()), _ptr(rois_k.contiguous()), _ptr(wg_t), _ptr(bg),
+                                  _ptr(dim_mat), _ptr(out), Nq, Nk, ldp, _stream())
+    _lib.check(rc, "mega_position_logits")
+    return out
+
+
+def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=16):
+    """q [Nq,G*64] (u folded in), k [Nk,G*64], vt [G*64, ldv] key-contiguous projected V -> [Nq, G*64]."""
+    _gpu(q, k, vt, pos, resid, bias_v)
+    lib = _lib.load()
+    Nq = q.shape[0]
+    assert q.dtype == k.dtype == vt.dtype and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    out = torch.empty((Nq, groups * 64), dtype=q.dtype, device=q.device)
+    rc = lib.mega_relation_attention(_ptr(q), q.shape[1], _ptr(k), k.shape[1], _ptr(vt), vt.shape[1], _ptr(pos),
+                                     0 if pos is None else pos.shape[2], _ptr(resid),
+                                     0 if resid is None else resid.shape[1], _ptr(bias_v), _ptr(out), groups * 64,
+                                     Nq, Nk, groups, 1.0 / math.sqrt(64.0), _dt(q), _stream())
+    _lib.check(rc, "mega_relation_attention")
+    return out
+
+
+def preprocess_frames(frames_u8, mean, to_bgr=True):
+    """uint8 [N,H,W,3] RGB -> f32 [N,3,H,W] (BGR*255 - mean)."""
+    _gpu(frames_u8)
+    lib = _lib.load()
+    N, H, W, C = frames_u8.shape
+    assert C == 3 and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+    out = torch.empty((N, 3, H, W), dtype=torch.float32, device=frames_u8.device)
+    rc = lib.mega_preprocess_frames(_ptr(frames_u8), _ptr(out), N, H, W, float(mean[0]), float(mean[1]),
+                                    float(mean[2]), int(to_bgr), _stream())
+    _lib.check(rc, "mega_preprocess_frames")
+    return out
