@@ -111,14 +111,16 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ ma
     const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
     const u64 mine = blk < 64 ? remv0 : remv1;
     const int src = blk & 63;
-    u64 cur = ((u64)__builtin_amdgcn_readlane((unsigned)(mine >> 32), src) << 32) |
-              (u64)__builtin_amdgcn_readlane((unsigned)mine, src);
+    // NB: the builtin returns a signed int -- go through unsigned or bit 31 sign-extends into the high word
+    u64 cur = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), src) << 32) |
+              (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, src);
     cur |= ~okmask;
     u64 kept = 0;
     for (int t = 0; t < 64; ++t) {
       if (!((cur >> t) & 1ULL)) {
         kept |= 1ULL << t;
-        cur |= ((u64)__builtin_amdgcn_readlane(dhi, t) << 32) | (u64)__builtin_amdgcn_readlane(dlo, t);
+        cur |= ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, t) << 32) |
+               (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, t);
       }
     }
     // record kept boxes (ascending position)

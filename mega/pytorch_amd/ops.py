@@ -228,3 +228,19 @@ def preprocess_frames(frames_u8, mean, to_bgr=True):
                                     float(mean[2]), int(to_bgr), _stream())
     _lib.check(rc, "mega_preprocess_frames")
     return out
+
+
+def linear_transposed(w, x, ld):
+    """Returns (x @ w^T)^T laid out [Nout, ld] with ld >= M and the pad columns zero:
+    out[n][m] = sum_k w[n][k] * x[m][k].  The weight matrix plays the GEMM 'A rows' role, so the
+    projected values of one output feature are contiguous over rows m (keys)."""
+    _gpu(w, x)
+    lib = _lib.load()
+    Nout, K = w.shape
+    M = x.shape[0]
+    assert x.shape[1] == K and ld >= M and w.dtype == x.dtype and w.is_contiguous() and x.is_contiguous()
+    out = torch.zeros((Nout, ld), dtype=x.dtype, device=x.device)
+    rc = lib.mega_conv2d_nhwc(_ptr(w), _ptr(x), None, None, None, _ptr(out), Nout, 1, 1, K, M, 1, 1, 1, 0, 1, 0, ld,
+                              ld, _dt(x), _dt(x), _stream())
+    _lib.check(rc, "mega_conv2d_nhwc(transposed)")
+    return out

@@ -1,0 +1,275 @@
+"""-m gpu: every HIP kernel, called through the C ABI (mega/pytorch_amd/ops.py -> libmega_hip.so),
+against the CPU oracle (oracle/) or a plain torch-CPU fp32 reference of the same op, on seeded inputs.
+
+Tolerances: integer / index outputs bit-exact; f32 kernels 1e-4 relative to the tensor scale (MFMA f32
+is an exact fmaf chain, only the summation order differs from MKL); bf16 kernels 2e-2 of tensor scale.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from mega.pytorch_amd import ops
+    return ops
+
+
+def _relerr(a, b):
+    a = a.double(); b = b.double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, R, stride, pad, dil, relu, use_res
+    (1, 19, 23, 64, 64, 1, 1, 0, 1, True, False),
+    (2, 19, 23, 64, 256, 1, 1, 0, 1, False, True),
+    (1, 21, 17, 256, 128, 1, 2, 0, 1, True, False),      # stride-2 1x1 (STRIDE_IN_1X1)
+    (1, 19, 23, 64, 64, 3, 1, 1, 1, True, False),
+    (1, 13, 15, 128, 192, 3, 1, 2, 2, True, False),      # dilated res5-style
+    (1, 38, 63, 256, 60, 1, 1, 0, 1, False, False),      # RPN-style narrow output, N tail
+    (300, 1, 1, 1024, 155, 1, 1, 0, 1, False, False),    # linear, M and N tails
+    (1, 38, 63, 128, 512, 3, 1, 1, 1, True, True),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_nhwc(dev, case, dtype):
+    ops = _ops()
+    N, H, W, Cin, Cout, R, stride, pad, dil, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, R, R), generator=g) / math.sqrt(Cin * R * R)
+    scale = torch.rand((Cout,), generator=g) + 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    xq, wq = x.to(dtype).float(), w.to(dtype).float()
+    ref = F.conv2d(xq, wq, stride=stride, padding=pad, dilation=dil)
+    ref = ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g).to(dtype)
+        ref = ref + res.float()
+    if relu:
+        ref = F.relu(ref)
+    out = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev),
+                          w.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev), scale.to(dev), bias.to(dev),
+                          None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev),
+                          stride=stride, pad=pad, dil=dil, relu=relu)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    err = _relerr(got, ref)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert err < tol, "conv %s %s relerr %.3g" % (case, dtype, err)
+
+
+def test_conv_bf16_in_f32_out(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((700, 1024), generator=g).to(torch.bfloat16)
+    w = (torch.randn((60, 1024), generator=g) / 32).to(torch.bfloat16)
+    b = torch.randn((60,), generator=g)
+    ref = F.linear(x.float(), w.float(), b)
+    out = ops.linear(x.to(dev), w.to(dev), b.to(dev), out_dtype=torch.float32)
+    assert out.dtype == torch.float32
+    assert _relerr(out.cpu(), ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_and_maxpool(dev, dtype):
+    ops = _ops()
+    from oracle import mega_oracle as mo
+    from mega.pytorch_amd import synth
+    sd = synth.make_state_dict(blocks=(1, 1, 1), seed=2)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((2, 3, 75, 101), generator=g) * 60
+    p = "backbone.body.stem."
+    conv = F.conv2d(x, sd[p + "conv1.weight"], stride=2, padding=3)
+    ref_c = F.relu(mo.frozen_bn(conv, sd, p + "bn1."))
+    ref_p = F.max_pool2d(ref_c, 3, 2, 1)
+    scale = sd[p + "bn1.weight"] * sd[p + "bn1.running_var"].rsqrt()
+    bias = sd[p + "bn1.bias"] - sd[p + "bn1.running_mean"] * scale
+    w_tap = sd[p + "conv1.weight"].permute(1, 2, 3, 0).reshape(147, 64).contiguous()
+    y = ops.stem(x.to(dev), w_tap.to(dev), scale.to(dev), bias.to(dev), dtype)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert _relerr(y.float().cpu().permute(0, 3, 1, 2), ref_c) < tol
+    z = ops.maxpool3x3s2(y)
+    ref_p2 = F.max_pool2d(y.float().cpu().permute(0, 3, 1, 2), 3, 2, 1)
+    assert torch.equal(z.float().cpu().permute(0, 3, 1, 2), ref_p2)
+    assert _relerr(z.float().cpu().permute(0, 3, 1, 2), ref_p) < tol
+
+
+def _random_rois(g, K, B, W, H):
+    x1 = torch.rand((K,), generator=g) * W * 0.8
+    y1 = torch.rand((K,), generator=g) * H * 0.8
+    w = torch.rand((K,), generator=g) * W * 0.6 + 1
+    h = torch.rand((K,), generator=g) * H * 0.6 + 1
+    b = torch.randint(0, B, (K,), generator=g).float()
+    rois = torch.stack([b, x1, y1, (x1 + w).clamp(max=W - 1), (y1 + h).clamp(max=H - 1)], dim=1)
+    rois[0] = torch.tensor([0, 0, 0, W - 1, H - 1])          # whole image (largest sampling grid)
+    rois[1] = torch.tensor([0, 5.3, 7.1, 5.9, 7.4])          # tiny: forced to 1x1
+    return rois
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layouts", [(True, True), (False, False), (True, False)])
+def test_roi_align(dev, dtype, layouts):
+    ops = _ops()
+    from oracle import native
+    in_nhwc, out_nhwc = layouts
+    g = torch.Generator().manual_seed(7)
+    B, C, H, W = 2, 96, 38, 63
+    feat = torch.randn((B, C, H, W), generator=g).to(dtype)
+    rois = _random_rois(g, 40, B, W * 16, H * 16)
+    ref = torch.from_numpy(native.roi_align(feat.float().numpy(), rois.numpy(), 1 / 16., 7, 7, 0))
+    f_in = feat.permute(0, 2, 3, 1).contiguous() if in_nhwc else feat
+    out = ops.roi_align(f_in.to(dev), rois.to(dev), 1 / 16., (7, 7), 0, in_nhwc=in_nhwc, out_nhwc=out_nhwc).float().cpu()
+    if out_nhwc:
+        out = out.view(-1, 7, 7, C).permute(0, 3, 1, 2)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert _relerr(out, ref) < tol
+
+
+def test_nms_golden_and_random(dev):
+    ops = _ops()
+    from oracle import native
+    inputs = np.array([10, 10, 50, 60, 0.5, 11, 12, 48, 60, 0.7, 8, 9, 40, 50, 0.6, 100, 100, 150, 140, 0.9,
+                       99, 110, 155, 139, 0.8], dtype=np.float32).reshape(-1, 5)
+    gt = [[1, 3], [1, 3], [1, 3], [1, 2, 3, 4], [0, 1, 2, 3, 4]]
+    b = torch.from_numpy(inputs[:, :4].copy()).to(dev)
+    s = torch.from_numpy(inputs[:, 4].copy()).to(dev)
+    for thr, want in zip([0.1, 0.3, 0.5, 0.8, 0.9], gt):     # reference tests/test_nms.py:16-58
+        for strict in (False, True):
+            keep = ops.nms(b, s, thr, strict_gt=strict).cpu().tolist()
+            assert keep == want, (thr, strict, keep)
+    rng = np.random.RandomState(0)
+    for n, thr in [(1, 0.5), (63, 0.5), (64, 0.3), (65, 0.7), (300, 0.5), (1000, 0.7), (6000, 0.7)]:
+        ctr = rng.rand(n, 2) * 500
+        wh = rng.rand(n, 2) * 120 + 4
+        boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], axis=1).astype(np.float32)
+        scores = rng.rand(n).astype(np.float32)
+        if n >= 300:
+            scores[::7] = scores[3]                                  # ties
+        for strict in (True, False):
+            want = native.nms(boxes, scores, thr, strict)
+            got = ops.nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), thr, strict).cpu().numpy()
+            assert np.array_equal(got, want), "n=%d thr=%g strict=%s: %d vs %d kept" % (n, thr, strict, len(got), len(want))
+    assert ops.nms(torch.zeros((0, 4), device=dev), torch.zeros((0,), device=dev), 0.5).numel() == 0
+
+
+def _rpn_inputs(g, B, A, Hf, Wf):
+    obj = torch.randn((B, A, Hf, Wf), generator=g) * 2
+    reg = torch.randn((B, 4 * A, Hf, Wf), generator=g) * 0.5
+    obj[:, :, 0, :5] = obj[0, 0, 1, 1]                              # exact ties in the logits
+    return obj, reg
+
+
+@pytest.mark.parametrize("shape", [(2, 38, 63, 6000, 300), (1, 10, 16, 6000, 75), (3, 20, 30, 1000, 300)])
+def test_rpn_select(dev, shape):
+    ops = _ops()
+    from oracle import mega_oracle as mo
+    B, Hf, Wf, pre, post = shape
+    g = torch.Generator().manual_seed(11)
+    cell = mo.generate_anchors(16)
+    A = cell.shape[0]
+    obj, reg = _rpn_inputs(g, B, A, Hf, Wf)
+    im_w, im_h = Wf * 16 - 8, Hf * 16 - 8
+    anchors = mo.grid_anchors(cell, Hf, Wf, 16)
+    rpn_out = torch.cat([obj, reg], dim=1).permute(0, 2, 3, 1).reshape(B, Hf * Wf, 5 * A).contiguous()
+    props, scores, cnt = ops.rpn_select(rpn_out.to(dev), cell.to(dev), Hf, Wf, 16, pre, post, 0.7, 0, im_w, im_h, True)
+    props, scores, cnt = props.cpu(), scores.cpu(), cnt.cpu()
+    for b in range(B):
+        wb, ws = mo.rpn_select(obj[b], reg[b], anchors, im_w, im_h, pre, post, 0.7, 0, True)
+        n = int(cnt[b])
+        assert n == wb.shape[0], "frame %d: kept %d vs oracle %d" % (b, n, wb.shape[0])
+        assert (props[b, :n] - wb).abs().max() < 1e-3, (props[b, :n] - wb).abs().max()
+        assert (scores[b, :n] - ws).abs().max() < 1e-6
+        assert props[b, n:].abs().max() == 0 if n < post else True
+
+
+@pytest.mark.parametrize("R", [300, 77])
+def test_postprocess(dev, R):
+    ops = _ops()
+    from oracle import mega_oracle as mo
+    g = torch.Generator().manual_seed(R)
+    NC = 31
+    logits = torch.randn((R, NC), generator=g) * 1.5
+    deltas = torch.randn((R, NC * 4), generator=g) * 0.5
+    ctr = torch.rand((R, 2), generator=g) * torch.tensor([900., 500.])
+    wh = torch.rand((R, 2), generator=g) * 200 + 10
+    props = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=1).clamp(min=0)
+    props[:, 2].clamp_(max=999); props[:, 3].clamp_(max=599)
+    cfg = mo.OracleCfg()
+    wb, ws, wl = mo.postprocess(logits, deltas, props, 1000, 600, cfg)
+    ob, os_, ol, oc = ops.postprocess(logits.to(dev), deltas.to(dev), props.to(dev), None, cfg.bbox_reg_weights, 1000,
+                                      600, cfg.score_thresh, cfg.nms, cfg.detections_per_img, True)
+    n = int(oc.item())
+    assert n == wb.shape[0], "dets %d vs oracle %d" % (n, wb.shape[0])
+    assert torch.equal(ol[:n].cpu(), wl)
+    assert (ob[:n].cpu() - wb).abs().max() < 1e-3
+    assert (os_[:n].cpu() - ws).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(300, 750, True), (675, 1111, True), (70, 33, False), (129, 64, True)])
+def test_relation_attention(dev, dtype, shape):
+    """position logits + attention core + the projections (ops.linear) vs the literal reference formula
+    (oracle.attention_module_multi_head = roi_box_feature_extractors.py:567-646)."""
+    ops = _ops()
+    from oracle import mega_oracle as mo
+    from mega.pytorch_amd import synth
+    from mega.pytorch_amd.relation import RelationWeights, relation_attention_forward
+    Nq, Nk, use_pos = shape
+    sd = synth.make_state_dict(blocks=(1, 1, 1), seed=4)
+    g = torch.Generator().manual_seed(Nq)
+    x = torch.randn((Nq, 1024), generator=g).to(dtype)
+    r = torch.randn((Nk, 1024), generator=g).to(dtype)
+
+    def boxes(n):
+        c = torch.rand((n, 2), generator=g) * torch.tensor([900., 500.])
+        wh = torch.rand((n, 2), generator=g) * 250 + 2
+        return torch.cat([c - wh / 2, c + wh / 2], dim=1)
+    bq, bk = boxes(Nq), boxes(Nk)
+    ver = "local" if use_pos else "global"
+    pe = mo.cal_position_embedding(bq, bk) if use_pos else None
+    ref = x.float() + mo.attention_module_multi_head(sd, mo.FE, ver, 0, x.float(), r.float(), pe)
+    wts = RelationWeights(sd, mo.FE, "l_" if use_pos else "g_", 0, dtype, dev, with_pos=use_pos)
+    out = relation_attention_forward(wts, x.to(dev), r.to(dev), bq.to(dev) if use_pos else None,
+                                     bk.to(dev) if use_pos else None, residual=True)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    err = _relerr(out.float().cpu(), ref)
+    assert err < tol, "attention %s %s relerr %.3g" % (shape, dtype, err)
+
+
+def test_position_logits(dev):
+    ops = _ops()
+    from oracle import mega_oracle as mo
+    from mega.pytorch_amd import synth
+    sd = synth.make_state_dict(blocks=(1, 1, 1), seed=4)
+    g = torch.Generator().manual_seed(3)
+    c = torch.rand((90, 2), generator=g) * torch.tensor([900., 500.])
+    wh = torch.rand((90, 2), generator=g) * 250 + 2
+    b = torch.cat([c - wh / 2, c + wh / 2], dim=1)
+    bq, bk = b[:37], b[20:]
+    pe = mo.cal_position_embedding(bq, bk)
+    w, bias = sd[mo.FE + "l_Wgs.0.weight"], sd[mo.FE + "l_Wgs.0.bias"]
+    ref = (F.relu(F.conv2d(pe, w, bias)) + 1e-6).log()[0]           # [16, Nq, Nk]
+    got = ops.position_logits(bq.to(dev), bk.to(dev), w.view(16, 64).t().contiguous().to(dev), bias.to(dev),
+                              mo.dim_mat_values().to(dev)).cpu()[:, :, :bk.shape[0]]
+    # log() near relu's zero amplifies 1-ulp differences of the pre-activation: compare exp (the softmax weight)
+    assert (got.exp() - ref.exp()).abs().max() < 2e-5
+    big = ref > -8
+    assert (got[big] - ref[big]).abs().max() < 5e-2
+
+
+def test_preprocess(dev):
+    ops = _ops()
+    from mega.pytorch_amd import synth
+    fr = synth.make_clip(2, 40, 64, seed=1)
+    ref = synth.preprocess_cpu(fr)
+    got = ops.preprocess_frames(fr.to(dev), synth.PIXEL_MEAN).cpu()
+    assert (got - ref).abs().max() < 1e-4
