@@ -124,6 +124,9 @@ int mega_relation_attention(const void* q, int ldq, const void* k, int ldk, cons
 int mega_preprocess_frames(const unsigned char* in, float* out, int N, int H, int W, float mean0, float mean1,
                            float mean2, int to_bgr, void* stream);
 
+/* hipGetErrorString of the last launch failure any entry point of this library reported (MEGA_ERR_LAUNCH). */
+const char* mega_last_error_string(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,7 @@ SIGNATURES = {
                                         c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                         c_int, c_void_p]),
     "mega_preprocess_frames": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
+    "mega_last_error_string": (ctypes.c_char_p, []),
 }
 
 _lib = None
@@ -48,6 +49,10 @@ def load():
         raise RuntimeError(
             "libmega_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the MEGA hot path)" % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; ours must resolve to THAT copy (one HIP runtime per process:
+    # streams / device pointers are shared with torch).  Loading this library before torch would bind
+    # /opt/rocm's copy instead and every launch would fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
@@ -59,4 +64,7 @@ def load():
 
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError("%s failed: %s (code %d)" % (what, _ERR.get(rc, "unknown"), rc))
+        detail = ""
+        if rc == 2 and _lib is not None:
+            detail = ": " + _lib.mega_last_error_string().decode()
+        raise RuntimeError("%s failed: %s (code %d)%s" % (what, _ERR.get(rc, "unknown"), rc, detail))

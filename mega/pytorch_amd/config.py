@@ -1,0 +1,78 @@
+"""The config keys MEGA's inference path reads, as an attribute tree with the SAME key
+names as the reference's yacs config (mega_core/config/defaults.py + configs/BASE_RCNN_1gpu.yaml +
+configs/MEGA/vid_R_{50,101}_C4_MEGA_1x.yaml).  Any object with these attributes (e.g. the reference's
+own frozen yacs cfg) can be passed to the builders instead.
+"""
+import copy
+
+
+class CfgNode(dict):
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def merge_from_list(self, lst):
+        assert len(lst) % 2 == 0
+        for key, v in zip(lst[0::2], lst[1::2]):
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                node = node[p]
+            if parts[-1] not in node:
+                raise KeyError("unknown config key " + key)
+            node[parts[-1]] = v
+        return self
+
+
+def get_cfg(arch="R-101"):
+    """MEGA test-time defaults.  arch: 'R-101' (configs/MEGA/vid_R_101_C4_MEGA_1x.yaml) or
+    'R-50' (configs/MEGA/vid_R_50_C4_MEGA_1x.yaml)."""
+    r50 = arch in ("R-50", "R-50-C4")
+    return CfgNode({
+        "DTYPE": "float32",                      # defaults.py:541; "bfloat16" selects the bf16 MFMA path
+        "INPUT": {"MIN_SIZE_TEST": 600, "MAX_SIZE_TEST": 1000,
+                  "PIXEL_MEAN": [102.9801, 115.9465, 122.7717], "PIXEL_STD": [1.0, 1.0, 1.0], "TO_BGR255": True},
+        "MODEL": {
+            "DEVICE": "cuda",
+            "META_ARCHITECTURE": "GeneralizedRCNNMEGA",
+            "BACKBONE": {"CONV_BODY": "R-50-C4" if r50 else "R-101-C4"},
+            "RESNETS": {"NUM_GROUPS": 1, "WIDTH_PER_GROUP": 64, "STRIDE_IN_1X1": True,
+                        "TRANS_FUNC": "BottleneckWithFixedBatchNorm", "STEM_FUNC": "StemWithFixedBatchNorm",
+                        "RES5_DILATION": 2, "BACKBONE_OUT_CHANNELS": 256 * 4, "RES2_OUT_CHANNELS": 256,
+                        "STEM_OUT_CHANNELS": 64},
+            "RPN": {"RPN_HEAD": "SingleConvRPNHead", "ANCHOR_SIZES": (64, 128, 256, 512), "ANCHOR_STRIDE": (16,),
+                    "ASPECT_RATIOS": (0.5, 1.0, 2.0), "STRADDLE_THRESH": 0, "PRE_NMS_TOP_N_TEST": 6000,
+                    "POST_NMS_TOP_N_TEST": 300, "NMS_THRESH": 0.7, "MIN_SIZE": 0},
+            "ROI_HEADS": {"SCORE_THRESH": 0.001, "NMS": 0.5, "DETECTIONS_PER_IMG": 300,
+                          "BBOX_REG_WEIGHTS": (10.0, 10.0, 5.0, 5.0)},
+            "ROI_BOX_HEAD": {"FEATURE_EXTRACTOR": "MEGAFeatureExtractor", "PREDICTOR": "FPNPredictor",
+                             "POOLER_RESOLUTION": 7, "POOLER_SAMPLING_RATIO": 0, "POOLER_SCALES": (1.0 / 16,),
+                             "NUM_CLASSES": 31, "MLP_HEAD_DIM": 1024},
+            "VID": {
+                "ENABLE": True, "METHOD": "mega",
+                "RPN": {"REF_PRE_NMS_TOP_N": 6000, "REF_POST_NMS_TOP_N": 75},
+                "ROI_BOX_HEAD": {"REDUCE_CHANNEL": bool(r50),
+                                 "ATTENTION": {"ENABLE": True, "STAGE": 3, "GROUP": 16, "EMBED_DIM": 64}},
+                "MEGA": {"MIN_OFFSET": -12, "MAX_OFFSET": 12, "ALL_FRAME_INTERVAL": 25, "KEY_FRAME_LOCATION": 12,
+                         "RATIO": 0.2,
+                         "MEMORY": {"ENABLE": True, "SIZE": 25},
+                         "GLOBAL": {"ENABLE": True, "SIZE": 10, "RES_STAGE": 0 if r50 else 1, "SHUFFLE": True}},
+            },
+        },
+        # kernel-side switch: True = IoU > thr (the CUDA path the reference runs on GPU, csrc/cuda/nms.cu:60),
+        # False = IoU >= thr (its CPU path, csrc/cpu/nms_cpu.cpp:60)
+        "NMS_STRICT_GT": True,
+    })

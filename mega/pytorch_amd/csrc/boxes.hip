@@ -585,6 +585,7 @@ extern "C" size_t mega_nms_workspace_bytes(int P, int nmax) {
 extern "C" int mega_nms_sorted(const float* boxes, const int* counts, const unsigned char* valid, const int* order,
                                int P, int nmax, float thr, int strict_gt, int max_keep, int* keep_pos, int* keep_cnt,
                                unsigned char* flags, void* ws, size_t ws_bytes, void* stream) {
+  mega_clear_error();
   if (P == 0 || nmax == 0) return MEGA_OK;
   if (!boxes || !counts || !keep_pos || !keep_cnt || !ws || P < 0 || nmax < 0 || max_keep <= 0) return MEGA_ERR_ARG;
   if (nmax > SCAN_MAXCB * 64) return MEGA_ERR_ARG;
@@ -609,6 +610,7 @@ extern "C" size_t mega_nms_full_workspace_bytes(int n) {
 
 extern "C" int mega_nms(const float* dets, const float* scores, int n, float thr, int strict_gt, long long* keep_out,
                         int* keep_cnt, void* ws, size_t ws_bytes, void* stream) {
+  mega_clear_error();
   if (n == 0) return MEGA_OK;
   if (!dets || !scores || !keep_out || !keep_cnt || !ws || n < 0) return MEGA_ERR_ARG;
   if (n > SORT_MAX) return MEGA_ERR_ARG;
@@ -645,6 +647,7 @@ extern "C" int mega_rpn_select(const float* rpn_out, const float* cell_anchors, 
                                int anchor_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh,
                                int strict_gt, float min_size, float im_w, float im_h, float* proposals,
                                float* prop_scores, int* prop_cnt, void* ws, size_t ws_bytes, void* stream) {
+  mega_clear_error();
   if (!rpn_out || !cell_anchors || !proposals || !prop_scores || !prop_cnt || !ws || B <= 0 || Hf <= 0 || Wf <= 0 ||
       A <= 0 || ldc < 5 * A || pre_nms_top_n <= 0 || post_nms_top_n <= 0)
     return MEGA_ERR_ARG;
@@ -696,6 +699,7 @@ extern "C" int mega_postprocess(const float* logits, const float* deltas, const 
                                 float score_thresh, float nms_thresh, int strict_gt, int max_det, float* out_boxes,
                                 float* out_scores, long long* out_labels, int* out_cnt, float* probs_out, void* ws,
                                 size_t ws_bytes, void* stream) {
+  mega_clear_error();
   if (!logits || !deltas || !props || !out_boxes || !out_scores || !out_labels || !out_cnt || !ws || R <= 0 || NC < 2)
     return MEGA_ERR_ARG;
   if (R > 1024) return MEGA_ERR_ARG;

@@ -39,8 +39,16 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// hipGetLastError() is sticky per thread and also reports BENIGN codes left behind by other users of the runtime in
+// this process (e.g. hipErrorNotReady from an event query of torch's caching allocator): every entry point
+// clears it first, so the check after the launches only sees this call's own errors.
+static inline void mega_clear_error() { (void)hipGetLastError(); }
+
+extern int g_mega_last_hip_error;  // defined in frames.hip; read back through mega_last_error_string()
+
 static inline int mega_check_launch() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) g_mega_last_hip_error = (int)e;
   return e == hipSuccess ? MEGA_OK : MEGA_ERR_LAUNCH;
 }
 

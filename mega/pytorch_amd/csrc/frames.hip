@@ -25,8 +25,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __
 }
 }  // namespace
 
+int g_mega_last_hip_error = 0;
+
+extern "C" const char* mega_last_error_string() {
+  return hipGetErrorString((hipError_t)g_mega_last_hip_error);
+}
+
 extern "C" int mega_preprocess_frames(const unsigned char* in, float* out, int N, int H, int W, float mean0,
                                       float mean1, float mean2, int to_bgr, void* stream) {
+  mega_clear_error();
   if (!in || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
   const size_t total = (size_t)N * H * W;
   const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);

@@ -249,6 +249,7 @@ extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scal
                                 const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
                                 int R, int S, int stride, int pad, int dil, int relu, int ldo, int ldr,
                                 int in_dtype, int out_dtype, void* stream) {
+  mega_clear_error();
   if (!in || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
       dil <= 0 || pad < 0)
     return MEGA_ERR_ARG;

@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 // w[h][q][k] = log(relu(Wg_h . pe(q,k) + bg_h) + 1e-6);  out [16][Nq][ldp] f32, ldp >= Nk
 extern "C" int mega_position_logits(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
                                     const float* dim_mat, float* out, int Nq, int Nk, int ldp, void* stream) {
+  mega_clear_error();
   if (Nq == 0 || Nk == 0) return MEGA_OK;
   if (!rois_q || !rois_k || !wg_t || !bg || !dim_mat || !out || Nq < 0 || Nk < 0 || ldp < Nk) return MEGA_ERR_ARG;
   hipLaunchKernelGGL(pos_logits_kernel, dim3(cdiv(Nk, 256), Nq), dim3(256), 0, (hipStream_t)stream,
@@ -340,6 +341,7 @@ extern "C" int mega_relation_attention(const void* q, int ldq, const void* k, in
                                        const float* pos, int ldp, const void* resid, int ldr, const float* bias_v,
                                        void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype,
                                        void* stream) {
+  mega_clear_error();
   if (Nq == 0) return MEGA_OK;
   if (!q || !k || !vt || !out || Nq < 0 || Nk <= 0 || groups <= 0) return MEGA_ERR_ARG;
   const int ve = dtype == MEGA_BF16 ? 8 : 4;

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fe
 
 extern "C" int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, const float* scale, const float* bias,
                                       void* out, int N, int H, int W, int out_dtype, void* stream) {
+  mega_clear_error();
   if (!in || !w_tap64 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   dim3 grid(cdiv(Wo, ST_T), cdiv(Ho, ST_T), N);
@@ -190,6 +191,7 @@ extern "C" int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, con
 }
 
 extern "C" int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream) {
+  mega_clear_error();
   if (!in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MEGA_ERR_ARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   hipStream_t st = (hipStream_t)stream;
@@ -214,6 +216,7 @@ extern "C" int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, i
 extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out, int K, int C, int H, int W,
                                   float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, int in_nhwc,
                                   int out_nhwc, int dtype, int out_dtype, void* stream) {
+  mega_clear_error();
   if (K == 0) return MEGA_OK;
   if (!feat || !rois || !out || K < 0 || C <= 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0)
     return MEGA_ERR_ARG;

@@ -1,0 +1,783 @@
+"""Host-side mirror of the reference's mega_core.modeling modules for the MEGA inference path, running on
+the HIP kernels of libmega_hip.so.  Same class names, registry names, constructor signatures
+``(cfg, in_channels)``, call signatures at the seams and ``state_dict`` keys as the reference
+(SURVEY.md 8b), so a reference checkpoint loads with ``load_state_dict`` and the detector drops into
+``tools/test_net.py`` / ``demo/predictor.py``.
+
+Reference files mirrored:
+  detector/generalized_rcnn_mega.py:21-225     GeneralizedRCNNMEGA
+  backbone/resnet.py:81-366, backbone.py:12-20 ResNet C4 body / stem / bottleneck, build_backbone
+  rpn/rpn.py:73-125,:200-260, rpn/inference.py RPNHead, RPNWithRefModule, RPNPostProcessor
+  roi_heads/box_head/roi_box_feature_extractors.py:457-933   MEGAFeatureExtractor (test path)
+  roi_heads/box_head/{box_head.py:65-124, roi_box_predictors.py:35-57, inference.py:12-149}, roi_heads.py:9-76
+
+Layout contract at the seams: feature maps are logical NCHW tensors in channels-last memory
+(``x.permute(0,2,3,1)`` is contiguous), dtype = the compute dtype (cfg.DTYPE: float32 | bfloat16).
+There is no CPU path: modules raise if the kernels are unavailable.
+"""
+from collections import OrderedDict, deque
+
+import torch
+from torch import nn
+
+from . import ops
+from .relation import RelationWeights, relation_attention_forward
+from .structures import BoxList, cat_boxlist, to_image_list
+from .synth import _cell_anchors
+
+_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float": torch.float32, "bf16": torch.bfloat16}
+
+
+def compute_dtype(cfg):
+    return _DTYPES[str(getattr(cfg, "DTYPE", "float32"))]
+
+
+def _nhwc(x):
+    """logical NCHW / channels-last memory -> contiguous NHWC view (no copy when the contract holds)."""
+    y = x.permute(0, 2, 3, 1)
+    return y if y.is_contiguous() else y.contiguous()
+
+
+def _nchw_view(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+class Registry(dict):
+    """mega_core/utils/registry.py:9-45."""
+
+    def register(self, name, module=None):
+        if module is not None:
+            assert name not in self
+            self[name] = module
+            return module
+
+        def deco(fn):
+            assert name not in self
+            self[name] = fn
+            return fn
+        return deco
+
+
+BACKBONES = Registry()
+RPN_HEADS = Registry()
+ROI_BOX_FEATURE_EXTRACTORS = Registry()
+ROI_BOX_PREDICTOR = Registry()
+DETECTION_META_ARCHITECTURES = Registry()
+
+
+# ================================================================================================= backbone
+class FrozenBatchNorm2d(nn.Module):
+    """layers/batch_norm.py:7-31 (buffers only; applied as the conv kernel's scale/bias epilogue)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def folded(self):
+        scale = self.weight.float() * self.running_var.float().rsqrt()
+        bias = self.bias.float() - self.running_mean.float() * scale
+        return scale.contiguous(), bias.contiguous()
+
+
+def _pack_conv(conv, dtype):
+    """OIHW parameter -> OHWI kernel operand in the compute dtype."""
+    return conv.weight.detach().permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+class _Packed(nn.Module):
+    """Modules that cache kernel-ready operands; invalidated on load_state_dict / dtype change."""
+
+    def __init__(self):
+        super().__init__()
+        self._pk = None
+        self._pk_key = None
+
+    def _packed(self, dtype, device):
+        key = (dtype, str(device))
+        if self._pk is None or self._pk_key != key:
+            with torch.no_grad():
+                self._pk = self._pack(dtype, device)
+            self._pk_key = key
+        return self._pk
+
+    def invalidate(self):
+        self._pk = None
+        for m in self.children():
+            if hasattr(m, "invalidate"):
+                m.invalidate()
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pk = None
+        return super()._load_from_state_dict(*a, **k)
+
+
+class Bottleneck(_Packed):
+    """backbone/resnet.py:239-344 with FrozenBN, stride_in_1x1=True: three fused conv+BN(+ReLU) launches,
+    the residual add + final ReLU live in conv3's epilogue."""
+
+    def __init__(self, in_channels, bottleneck_channels, out_channels, stride, dilation=1):
+        super().__init__()
+        self.downsample = None
+        if in_channels != out_channels:
+            self.down_stride = stride if dilation == 1 else 1
+            self.downsample = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, bias=False),
+                                            FrozenBatchNorm2d(out_channels))
+        if dilation > 1:
+            stride = 1
+        self.stride, self.dilation = stride, dilation
+        self.conv1 = nn.Conv2d(in_channels, bottleneck_channels, 1, bias=False)
+        self.bn1 = FrozenBatchNorm2d(bottleneck_channels)
+        self.conv2 = nn.Conv2d(bottleneck_channels, bottleneck_channels, 3, bias=False)
+        self.bn2 = FrozenBatchNorm2d(bottleneck_channels)
+        self.conv3 = nn.Conv2d(bottleneck_channels, out_channels, 1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(out_channels)
+
+    def _pack(self, dtype, device):
+        pk = {}
+        for i in (1, 2, 3):
+            s, b = getattr(self, "bn%d" % i).folded()
+            pk["w%d" % i] = _pack_conv(getattr(self, "conv%d" % i), dtype).to(device)
+            pk["s%d" % i], pk["b%d" % i] = s.to(device), b.to(device)
+        if self.downsample is not None:
+            s, b = self.downsample[1].folded()
+            pk["wd"] = _pack_conv(self.downsample[0], dtype).to(device)
+            pk["sd"], pk["bd"] = s.to(device), b.to(device)
+        return pk
+
+    def run(self, x):
+        pk = self._packed(x.dtype, x.device)
+        identity = x
+        if self.downsample is not None:
+            identity = ops.conv2d_nhwc(x, pk["wd"], pk["sd"], pk["bd"], stride=self.down_stride)
+        out = ops.conv2d_nhwc(x, pk["w1"], pk["s1"], pk["b1"], stride=self.stride, relu=True)
+        out = ops.conv2d_nhwc(out, pk["w2"], pk["s2"], pk["b2"], pad=self.dilation, dil=self.dilation, relu=True)
+        return ops.conv2d_nhwc(out, pk["w3"], pk["s3"], pk["b3"], residual=identity, relu=True)
+
+
+def _make_stage(in_channels, bottleneck_channels, out_channels, block_count, first_stride, dilation=1):
+    blocks, stride = [], first_stride
+    for _ in range(block_count):
+        blocks.append(Bottleneck(in_channels, bottleneck_channels, out_channels, stride, dilation))
+        stride, in_channels = 1, out_channels
+    return nn.Sequential(*blocks)
+
+
+class BaseStem(_Packed):
+    """backbone/resnet.py:347-366: 7x7/2 conv + FrozenBN + ReLU (one direct-conv kernel), 3x3/2 max-pool."""
+
+    def __init__(self, out_channels=64):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, out_channels, 7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(out_channels)
+
+    def _pack(self, dtype, device):
+        s, b = self.bn1.folded()
+        w = self.conv1.weight.detach().float().permute(1, 2, 3, 0).reshape(147, 64).contiguous()
+        return {"w": w.to(device), "s": s.to(device), "b": b.to(device)}
+
+    def run(self, img_nchw_f32, dtype):
+        pk = self._packed(dtype, img_nchw_f32.device)
+        y = ops.stem(img_nchw_f32, pk["w"], pk["s"], pk["b"], dtype)
+        return ops.maxpool3x3s2(y)
+
+
+_STAGE_BLOCKS = {"R-50-C4": (3, 4, 6), "R-101-C4": (3, 4, 23)}
+
+
+class ResNet(nn.Module):
+    """backbone/resnet.py:81-152 for the *-C4 bodies."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.dtype = compute_dtype(cfg)
+        blocks = _STAGE_BLOCKS[cfg.MODEL.BACKBONE.CONV_BODY]
+        self.stem = BaseStem(cfg.MODEL.RESNETS.STEM_OUT_CHANNELS)
+        in_ch = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+        self.stages = []
+        for i, n in enumerate(blocks):
+            mid, out = 64 * 2 ** i, cfg.MODEL.RESNETS.RES2_OUT_CHANNELS * 2 ** i
+            name = "layer%d" % (i + 1)
+            self.add_module(name, _make_stage(in_ch, mid, out, n, first_stride=int(i > 0) + 1))
+            self.stages.append(name)
+            in_ch = out
+
+    def forward(self, x):
+        """x [N,3,H,W] f32 image batch -> [C4] (logical NCHW, channels-last memory, compute dtype)."""
+        y = self.stem.run(x.float().contiguous(), self.dtype)
+        for name in self.stages:
+            for blk in getattr(self, name):
+                y = blk.run(y)
+        return [_nchw_view(y)]
+
+
+@BACKBONES.register("R-50-C4")
+@BACKBONES.register("R-101-C4")
+def build_resnet_backbone(cfg):
+    """backbone/backbone.py:12-20."""
+    model = nn.Sequential(OrderedDict([("body", ResNet(cfg))]))
+    model.out_channels = cfg.MODEL.RESNETS.BACKBONE_OUT_CHANNELS
+    return model
+
+
+def build_backbone(cfg):
+    return BACKBONES[cfg.MODEL.BACKBONE.CONV_BODY](cfg)
+
+
+class ResNetHead(nn.Module):
+    """backbone/resnet.py:155-204 as built by roi_box_feature_extractors.py:462-472: res5, stride_init=1,
+    dilation=RES5_DILATION, run on the whole C4 map."""
+
+    def __init__(self, dilation=2):
+        super().__init__()
+        self.layer4 = _make_stage(1024, 512, 2048, 3, first_stride=1, dilation=dilation)
+        self.out_channels = 2048
+
+    def run(self, x):
+        for blk in self.layer4:
+            x = blk.run(x)
+        return x
+
+
+# ================================================================================================= RPN
+class BufferList(nn.Module):
+    """rpn/anchor_generator.py:11-31."""
+
+    def __init__(self, buffers=None):
+        super().__init__()
+        for i, b in enumerate(buffers or []):
+            self.register_buffer(str(i), b)
+
+    def __len__(self):
+        return len(self._buffers)
+
+    def __iter__(self):
+        return iter(self._buffers.values())
+
+
+class AnchorGenerator(nn.Module):
+    """rpn/anchor_generator.py:34-125.  Only the cell anchors are state; the [H*W*A,4] grid is generated on the
+    fly inside the proposal kernel from (cell anchor, x*stride, y*stride)."""
+
+    def __init__(self, sizes, aspect_ratios, anchor_strides, straddle_thresh=0):
+        super().__init__()
+        assert len(anchor_strides) == 1, "C4 path: single feature level"
+        self.strides = anchor_strides
+        self.cell_anchors = BufferList([_cell_anchors(anchor_strides[0], sizes, aspect_ratios)])
+        self.straddle_thresh = straddle_thresh
+
+    def num_anchors_per_location(self):
+        return [len(c) for c in self.cell_anchors]
+
+
+@RPN_HEADS.register("SingleConvRPNHead")
+class RPNHead(_Packed):
+    """rpn/rpn.py:73-106.  The two 1x1 convs are merged into one 5A-wide GEMM with f32 output."""
+
+    def __init__(self, cfg, in_channels, num_anchors):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, padding=1)
+        self.cls_logits = nn.Conv2d(in_channels, num_anchors, 1)
+        self.bbox_pred = nn.Conv2d(in_channels, num_anchors * 4, 1)
+        for l in (self.conv, self.cls_logits, self.bbox_pred):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+
+    def _pack(self, dtype, device):
+        w2 = torch.cat([self.cls_logits.weight.detach(), self.bbox_pred.weight.detach()], dim=0)
+        b2 = torch.cat([self.cls_logits.bias.detach(), self.bbox_pred.bias.detach()], dim=0)
+        return {"w1": _pack_conv(self.conv, dtype).to(device), "b1": self.conv.bias.detach().float().to(device).contiguous(),
+                "w2": w2.permute(0, 2, 3, 1).contiguous().to(dtype).to(device), "b2": b2.float().to(device).contiguous()}
+
+    def run(self, feat_nhwc):
+        """-> [B, H*W, 5A] f32 (channel a = objectness of anchor a, A + 4a + j = delta j)."""
+        pk = self._packed(feat_nhwc.dtype, feat_nhwc.device)
+        t = ops.conv2d_nhwc(feat_nhwc, pk["w1"], None, pk["b1"], pad=1, relu=True)
+        o = ops.conv2d_nhwc(t, pk["w2"], None, pk["b2"], out_dtype=torch.float32)
+        B, H, W, C = o.shape
+        return o.view(B, H * W, C)
+
+    def forward(self, x):
+        """reference signature: list of features -> (logits list [N,A,H,W], bbox_reg list [N,4A,H,W])."""
+        logits, reg = [], []
+        for f in x:
+            o = self.run(_nhwc(f))
+            B, _, H, W = f.shape
+            A = self.cls_logits.weight.shape[0]
+            o = o.view(B, H, W, 5 * A).permute(0, 3, 1, 2)
+            logits.append(o[:, :A])
+            reg.append(o[:, A:])
+        return logits, reg
+
+
+class RPNWithRefModule(nn.Module):
+    """rpn/rpn.py:200-243 (+ RPNModule :110-197, RPNPostProcessor rpn/inference.py:13-149), test path only."""
+
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        c = cfg.MODEL.RPN
+        self.anchor_generator = AnchorGenerator(c.ANCHOR_SIZES, c.ASPECT_RATIOS, c.ANCHOR_STRIDE, c.STRADDLE_THRESH)
+        self.head = RPN_HEADS[c.RPN_HEAD](cfg, in_channels, self.anchor_generator.num_anchors_per_location()[0])
+        self.pre_nms_top_n = {"key": c.PRE_NMS_TOP_N_TEST, "ref": cfg.MODEL.VID.RPN.REF_PRE_NMS_TOP_N}
+        self.post_nms_top_n = {"key": c.POST_NMS_TOP_N_TEST, "ref": cfg.MODEL.VID.RPN.REF_POST_NMS_TOP_N}
+        self.nms_thresh, self.min_size = c.NMS_THRESH, c.MIN_SIZE
+        self.strict_gt = bool(getattr(cfg, "NMS_STRICT_GT", True))
+
+    def propose(self, feat_nhwc, im_w, im_h, version="key"):
+        """Batched, sync-free: -> (proposals [B,post,4], objectness [B,post], counts [B] i32) on device."""
+        rpn_out = self.head.run(feat_nhwc)
+        B, H, W, _ = feat_nhwc.shape
+        cell = next(iter(self.anchor_generator.cell_anchors)).to(feat_nhwc.device).float().contiguous()
+        return ops.rpn_select(rpn_out, cell, H, W, self.anchor_generator.strides[0], self.pre_nms_top_n[version],
+                              self.post_nms_top_n[version], self.nms_thresh, self.min_size, im_w, im_h, self.strict_gt)
+
+    def forward(self, images, features, targets=None, version="key"):
+        if self.training:
+            raise NotImplementedError("inference path only (training is out of scope, SURVEY.md section 2)")
+        images = to_image_list(images)
+        im_h, im_w = images.image_sizes[0]
+        props, scores, cnt = self.propose(_nhwc(features[0]), im_w, im_h, version)
+        boxes = []
+        for b, n in enumerate(cnt.tolist()):
+            bl = BoxList(props[b, :n], (im_w, im_h), "xyxy")
+            bl.add_field("objectness", scores[b, :n])
+            boxes.append(bl)
+        return (boxes, {}) if version == "key" else boxes
+
+
+def build_rpn(cfg, in_channels):
+    """rpn/rpn.py:246-262: METHOD 'mega' -> RPNWithRefModule."""
+    assert cfg.MODEL.VID.METHOD == "mega"
+    return RPNWithRefModule(cfg, in_channels)
+
+
+# ================================================================================================= box head
+def convert_to_roi_format(boxes):
+    """modeling/poolers.py:78-89."""
+    rows = []
+    for i, b in enumerate(boxes):
+        bb = b.bbox if isinstance(b, BoxList) else b
+        ids = torch.full((bb.shape[0], 1), float(i), dtype=torch.float32, device=bb.device)
+        rows.append(torch.cat([ids, bb.float()], dim=1))
+    return torch.cat(rows, dim=0).contiguous()
+
+
+def _linear(mod):
+    return nn.Linear(mod[0], mod[1])
+
+
+@ROI_BOX_FEATURE_EXTRACTORS.register("MEGAFeatureExtractor")
+class MEGAFeatureExtractor(_Packed):
+    """roi_box_feature_extractors.py:457-933, test-time path (_forward_ref :885, _forward_test :898,
+    generate_feats_test :754, update_memory :678, update_global :674, update_lm :690)."""
+
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        rb = cfg.MODEL.ROI_BOX_HEAD
+        vid = cfg.MODEL.VID
+        self.head = ResNetHead(cfg.MODEL.RESNETS.RES5_DILATION)
+        pooled_c = 2048
+        self.conv = None
+        if vid.ROI_BOX_HEAD.REDUCE_CHANNEL:
+            self.conv = nn.Conv2d(2048, 256, 1)
+            pooled_c = 256
+        self.resolution = rb.POOLER_RESOLUTION
+        self.scale = rb.POOLER_SCALES[0]
+        self.sampling_ratio = rb.POOLER_SAMPLING_RATIO
+        rep = rb.MLP_HEAD_DIM
+        self.all_frame_interval = vid.MEGA.ALL_FRAME_INTERVAL
+        att = vid.ROI_BOX_HEAD.ATTENTION
+        assert att.ENABLE and att.GROUP == 16 and att.EMBED_DIM == 64 and rep == 1024, "kernels are built for 16x64 heads"
+        self.embed_dim, self.groups, self.feat_dim, self.stage = att.EMBED_DIM, att.GROUP, rep, att.STAGE
+        self.base_num = vid.RPN.REF_POST_NMS_TOP_N
+        self.advanced_num = int(self.base_num * vid.MEGA.RATIO)
+        in0 = pooled_c * self.resolution ** 2
+        self.pooled_c = pooled_c
+        self.l_fcs = nn.ModuleList([nn.Linear(in0 if i == 0 else rep, rep) for i in range(self.stage)])
+        self.l_Wgs = nn.ModuleList([nn.Conv2d(self.embed_dim, self.groups, 1) for _ in range(self.stage)])
+        self.l_Wqs = nn.ModuleList([nn.Linear(rep, rep) for _ in range(self.stage)])
+        self.l_Wks = nn.ModuleList([nn.Linear(rep, rep) for _ in range(self.stage)])
+        self.l_Wvs = nn.ModuleList([nn.Conv2d(rep * self.groups, rep, 1, groups=self.groups) for _ in range(self.stage)])
+        self.l_us = nn.ParameterList([nn.Parameter(torch.randn(self.groups, 1, self.embed_dim) * 0.01)
+                                      for _ in range(self.stage)])
+        self.memory_enable = vid.MEGA.MEMORY.ENABLE
+        self.global_enable = vid.MEGA.GLOBAL.ENABLE
+        if self.global_enable:
+            self.global_size = vid.MEGA.GLOBAL.SIZE
+            self.global_res_stage = vid.MEGA.GLOBAL.RES_STAGE
+            n = self.global_res_stage + 1
+            self.g_Wqs = nn.ModuleList([nn.Linear(rep, rep) for _ in range(n)])
+            self.g_Wks = nn.ModuleList([nn.Linear(rep, rep) for _ in range(n)])
+            self.g_Wvs = nn.ModuleList([nn.Conv2d(rep * self.groups, rep, 1, groups=self.groups) for _ in range(n)])
+            self.g_us = nn.ParameterList([nn.Parameter(torch.randn(self.groups, 1, self.embed_dim) * 0.01)
+                                          for _ in range(n)])
+        else:
+            self.global_res_stage = 0
+        self.out_channels = rep
+        self.mem = None
+        self.global_cache = None
+
+    # ---- kernel operands
+    def _pack(self, dtype, device):
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        pk = {"local": [RelationWeights(sd, "", "l_", i, dtype, device, with_pos=True) for i in range(self.stage)],
+              "global": [RelationWeights(sd, "", "g_", i, dtype, device, with_pos=False)
+                         for i in range(self.global_res_stage + 1)] if self.global_enable else []}
+        # fc0 consumes the bin-major [K, 49, C] ROIAlign output: permute its columns from (c, ph, pw) to (ph, pw, c)
+        w0 = self.l_fcs[0].weight.detach()
+        r2 = self.resolution ** 2
+        w0 = w0.view(w0.shape[0], self.pooled_c, r2).permute(0, 2, 1).reshape(w0.shape[0], -1)
+        pk["fc_w"] = [w0.contiguous().to(dtype).to(device)] + [self.l_fcs[i].weight.detach().to(dtype).to(device).contiguous()
+                                                                for i in range(1, self.stage)]
+        pk["fc_b"] = [self.l_fcs[i].bias.detach().float().to(device).contiguous() for i in range(self.stage)]
+        if self.conv is not None:
+            pk["rc_w"] = _pack_conv(self.conv, dtype).to(device)
+            pk["rc_b"] = self.conv.bias.detach().float().to(device).contiguous()
+        return pk
+
+    # ---- per-frame stage (independent per frame; the multi-GPU sharding unit)
+    def box_features(self, feat_nhwc, rois5):
+        """res5 (+1x1 reduce) on the full C4 maps -> ROIAlign -> fc0 + ReLU.  feat [B,H,W,1024], rois5 [K,5]
+        -> [K,1024].  (:885-896 and :898-907)"""
+        pk = self._packed(feat_nhwc.dtype, feat_nhwc.device)
+        x = self.head.run(feat_nhwc)
+        if self.conv is not None:
+            x = ops.conv2d_nhwc(x, pk["rc_w"], None, pk["rc_b"], relu=True)
+        pooled = ops.roi_align(x, rois5, self.scale, (self.resolution, self.resolution), self.sampling_ratio)
+        return ops.linear(pooled.view(pooled.shape[0], -1), pk["fc_w"][0], pk["fc_b"][0], relu=True)
+
+    # ---- test-time state (:657-688)
+    def init_memory(self):
+        self.mem_queue_list = [{"rois": deque(maxlen=self.all_frame_interval),
+                                "feats": deque(maxlen=self.all_frame_interval)} for _ in range(self.stage)]
+        self.mem = [dict() for _ in range(self.stage)]
+
+    def init_global(self):
+        self.global_queue_list = [{"feats": deque(maxlen=self.global_size)}]
+        self.global_cache = [dict()]
+
+    def update_global(self, feats):
+        self.global_queue_list[0]["feats"].append(feats)
+        self.global_cache[0]["feats"] = torch.cat(list(self.global_queue_list[0]["feats"]), dim=0)
+
+    def update_memory(self, i, cache):
+        n = self.base_num if i == 0 else self.advanced_num
+        self.mem_queue_list[i]["rois"].append(cache["rois_ref"][:n])
+        self.mem_queue_list[i]["feats"].append(cache["feats_ref"][:n])
+        self.mem[i] = {"rois": torch.cat(list(self.mem_queue_list[i]["rois"]), dim=0),
+                       "feats": torch.cat(list(self.mem_queue_list[i]["feats"]), dim=0)}
+
+    def update_lm(self, feats, i=0):
+        pk = self._packed(feats.dtype, feats.device)
+        return relation_attention_forward(pk["global"][i], feats, self.global_cache[-1]["feats"], residual=True)
+
+    # ---- aggregation for one key frame (:898-933 after the fc0 line)
+    def aggregate(self, x, rois_key, rois, rois_dis, x_ref, dis_index=None, x_ref_dis=None):
+        """x [nk,1024] key-frame fc0 features, rois_key [nk,4]; rois [Nl,4] / x_ref [Nl,1024] the local window
+        (oldest frame first); rois_dis [Nd,4] with either dis_index [Nd] (rows of x_ref forming the 'dis' set;
+        update_lm is row-wise, so update_lm(x_ref_dis) == update_lm(x_ref)[dis_index]) or, in the reference's
+        call convention, the explicit x_ref_dis [Nd,1024] tensor."""
+        pk = self._packed(x.dtype, x.device)
+        nkey = x.shape[0]
+        nl = x_ref.shape[0]
+        if self.global_enable and self.global_cache and "feats" in self.global_cache[-1]:
+            # :757-760 -- ONE launch chain for all query sets (rows are independent)
+            parts = [x, x_ref] + ([x_ref_dis] if x_ref_dis is not None else [])
+            z = self.update_lm(torch.cat(parts, dim=0))
+            x, x_ref = z[:nkey], z[nkey:nkey + nl]
+            if x_ref_dis is not None:
+                x_ref_dis = z[nkey + nl:]
+        if x_ref_dis is None:
+            x_ref_dis = x_ref.index_select(0, dis_index)
+        rois_cur01 = torch.cat([rois_key, rois_dis], dim=0)
+        cache = [{"rois_cur": rois_cur01, "rois_ref": rois, "feats_cur": torch.cat([x, x_ref_dis], dim=0),
+                  "feats_ref": x_ref}]
+        for _ in range(self.stage - 2):
+            cache.append({"rois_cur": rois_cur01, "rois_ref": rois_dis})
+        cache.append({"rois_cur": rois_key, "rois_ref": rois_dis})
+        for i in range(self.stage):
+            memory = self.mem[i] if self.mem[i] else None                 # read BEFORE the push (:914-917)
+            if self.memory_enable:
+                self.update_memory(i, cache[i])
+            rois_cur, rois_ref = cache[i]["rois_cur"], cache[i]["rois_ref"]
+            feats_cur, feats_ref = cache[i]["feats_cur"], cache[i]["feats_ref"]
+            if memory is not None:
+                rois_ref = torch.cat([rois_ref, memory["rois"]], dim=0)
+                feats_ref = torch.cat([feats_ref, memory["feats"]], dim=0)
+            feats_cur = relation_attention_forward(pk["local"][i], feats_cur.contiguous(), feats_ref.contiguous(),
+                                                   rois_cur.contiguous(), rois_ref.contiguous(), residual=True)
+            if i != self.stage - 1:
+                feats_cur = ops.linear(feats_cur, pk["fc_w"][i + 1], pk["fc_b"][i + 1], relu=True)
+            if i == self.stage - 1:
+                x = feats_cur
+            elif i == self.stage - 2:
+                cache[i + 1]["feats_cur"] = feats_cur[:nkey]
+                cache[i + 1]["feats_ref"] = feats_cur[nkey:]
+            else:
+                cache[i + 1]["feats_cur"] = feats_cur
+                cache[i + 1]["feats_ref"] = feats_cur[nkey:]
+        for i in range(self.global_res_stage):
+            x = self.update_lm(x.contiguous(), i + 1)
+        return x
+
+    # ---- reference call signatures
+    def forward(self, x, proposals, pre_calculate=False, key_features=None):
+        if self.training:
+            raise NotImplementedError("inference path only")
+        if pre_calculate:                                                  # _forward_ref (:885-896)
+            return self.box_features(_nhwc(x), convert_to_roi_format(proposals))
+        props, proposals_ref, proposals_ref_dis, x_ref, x_ref_dis = proposals  # _forward_test (:898-933)
+        xk = key_features if key_features is not None else self.box_features(_nhwc(x), convert_to_roi_format(props))
+        return self.aggregate(xk, props[0].bbox, proposals_ref.bbox, proposals_ref_dis.bbox, x_ref,
+                              x_ref_dis=x_ref_dis)
+
+
+def make_roi_box_feature_extractor(cfg, in_channels):
+    return ROI_BOX_FEATURE_EXTRACTORS[cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR](cfg, in_channels)
+
+
+@ROI_BOX_PREDICTOR.register("FPNPredictor")
+class FPNPredictor(_Packed):
+    """roi_box_predictors.py:35-57; both Linears as one 5*NC-wide GEMM with f32 output."""
+
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        nc = cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES
+        self.num_classes = nc
+        self.cls_score = nn.Linear(in_channels, nc)
+        self.bbox_pred = nn.Linear(in_channels, nc * 4)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        for l in (self.cls_score, self.bbox_pred):
+            nn.init.constant_(l.bias, 0)
+
+    def _pack(self, dtype, device):
+        w = torch.cat([self.cls_score.weight.detach(), self.bbox_pred.weight.detach()], dim=0)
+        b = torch.cat([self.cls_score.bias.detach(), self.bbox_pred.bias.detach()], dim=0)
+        return {"w": w.to(dtype).to(device).contiguous(), "b": b.float().to(device).contiguous()}
+
+    def forward(self, x):
+        pk = self._packed(x.dtype, x.device)
+        o = ops.linear(x.contiguous(), pk["w"], pk["b"], out_dtype=torch.float32)
+        return o[:, :self.num_classes].contiguous(), o[:, self.num_classes:].contiguous()
+
+
+class PostProcessor(nn.Module):
+    """roi_heads/box_head/inference.py:12-149 on device: no per-class host loop, no CPU kthvalue."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        rh = cfg.MODEL.ROI_HEADS
+        self.score_thresh, self.nms, self.detections_per_img = rh.SCORE_THRESH, rh.NMS, rh.DETECTIONS_PER_IMG
+        self.weights = tuple(rh.BBOX_REG_WEIGHTS)
+        self.strict_gt = bool(getattr(cfg, "NMS_STRICT_GT", True))
+
+    def forward(self, x, boxes):
+        class_logits, box_regression = x
+        assert len(boxes) == 1, "MEGA test path: one key frame per call (data/collate_batch.py:22)"
+        bl = boxes[0]
+        im_w, im_h = bl.size
+        ob, os_, ol, oc = ops.postprocess(class_logits.float().contiguous(), box_regression.float().contiguous(),
+                                          bl.bbox.float().contiguous(), None, self.weights, im_w, im_h,
+                                          self.score_thresh, self.nms, self.detections_per_img, self.strict_gt)
+        n = int(oc.item())
+        res = BoxList(ob[:n], bl.size, "xyxy")
+        res.add_field("scores", os_[:n])
+        res.add_field("labels", ol[:n])
+        return [res]
+
+
+class ROIAttentionBoxHead(nn.Module):
+    """roi_heads/box_head/box_head.py:65-124."""
+
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        self.feature_extractor = make_roi_box_feature_extractor(cfg, in_channels)
+        self.predictor = ROI_BOX_PREDICTOR[cfg.MODEL.ROI_BOX_HEAD.PREDICTOR](cfg, self.feature_extractor.out_channels)
+        self.post_processor = PostProcessor(cfg)
+
+    def forward(self, features, proposals, targets=None, key_features=None):
+        if self.training:
+            raise NotImplementedError("inference path only")
+        x = self.feature_extractor(features, proposals, key_features=key_features)
+        class_logits, box_regression = self.predictor(x)
+        result = self.post_processor((class_logits, box_regression), proposals[0])
+        return x, result, {}
+
+
+class CombinedROIHeads(nn.ModuleDict):
+    """roi_heads/roi_heads.py:9-76 (box head only on this path)."""
+
+    def __init__(self, cfg, heads):
+        super().__init__(heads)
+        self.cfg = cfg.clone() if hasattr(cfg, "clone") else cfg
+
+    def forward(self, features, proposals, targets=None, **kw):
+        x, detections, loss_box = self.box(features, proposals, targets, **kw)
+        return x, detections, dict(loss_box)
+
+
+def build_roi_heads(cfg, in_channels):
+    return CombinedROIHeads(cfg, [("box", ROIAttentionBoxHead(cfg, in_channels))])
+
+
+# ================================================================================================= detector
+class GeneralizedRCNNMEGA(nn.Module):
+    """detector/generalized_rcnn_mega.py:21-225, inference.
+
+    Same per-video state machine (deques of maxlen ALL_FRAME_INTERVAL, key = slot KEY_FRAME_LOCATION,
+    frame-0 replication, end-of-video clamping), with two work-saving re-arrangements that do not change
+    results: a frame's RPN + res5 + ROIAlign + fc0 are computed ONCE when it enters the window, for the
+    300 'key' proposals (the 75 'ref' proposals are their first 75 rows: same NMS keep list cut earlier,
+    rpn/inference.py:116-121, boxlist_ops.py:27-29), instead of being recomputed when the frame becomes
+    the key frame (generalized_rcnn_mega.py:211, roi_box_feature_extractors.py:901-907).
+    """
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.backbone = build_backbone(cfg)
+        self.rpn = build_rpn(cfg, self.backbone.out_channels)
+        self.roi_heads = build_roi_heads(cfg, self.backbone.out_channels)
+        mega = cfg.MODEL.VID.MEGA
+        self.memory_enable = mega.MEMORY.ENABLE
+        self.global_enable = mega.GLOBAL.ENABLE
+        self.base_num = cfg.MODEL.VID.RPN.REF_POST_NMS_TOP_N
+        self.advanced_num = int(self.base_num * mega.RATIO)
+        self.all_frame_interval = mega.ALL_FRAME_INTERVAL
+        self.key_frame_location = mega.KEY_FRAME_LOCATION
+        self.key_num = cfg.MODEL.RPN.POST_NMS_TOP_N_TEST
+        assert cfg.MODEL.VID.RPN.REF_PRE_NMS_TOP_N == cfg.MODEL.RPN.PRE_NMS_TOP_N_TEST and self.base_num <= self.key_num, \
+            "ref proposals must be a prefix of the key proposals for the single-pass frame stage"
+        self.eval()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        for m in self.modules():
+            if isinstance(m, _Packed):
+                m._pk = None
+        return out
+
+    # ------------------------------------------------------------------ frame stage (batched, frame-independent)
+    @torch.no_grad()
+    def frame_stage(self, imgs, want):
+        """imgs [B,3,H,W] f32 preprocessed frames; want[b] = proposals needed from frame b (key_num for local
+        frames, base_num for global-pool frames).  Returns a list of records
+        {"boxes": [n,4] f32, "scores": [n], "feats": [n,1024]} (n <= want[b]).  One host sync (the counts)."""
+        fe = self.roi_heads.box.feature_extractor
+        B, _, H, W = imgs.shape
+        c4 = _nhwc(self.backbone(imgs)[0])
+        props, scores, cnt = self.rpn.propose(c4, W, H, "key")
+        counts = [min(int(n), int(w)) for n, w in zip(cnt.tolist(), want)]
+        rois5 = torch.cat([torch.cat([torch.full((n, 1), float(b), dtype=torch.float32, device=imgs.device),
+                                      props[b, :n]], dim=1) for b, n in enumerate(counts)], dim=0).contiguous()
+        feats = fe.box_features(c4, rois5)
+        out, o = [], 0
+        for b, n in enumerate(counts):
+            out.append({"boxes": props[b, :n], "scores": scores[b, :n], "feats": feats[o:o + n]})
+            o += n
+        return out
+
+    # ------------------------------------------------------------------ state machine
+    def _reset(self, seg_len):
+        n = self.all_frame_interval
+        self.seg_len = seg_len
+        self.end_id = 0
+        self.records = deque(maxlen=n)          # one record per window slot (key_num proposals each)
+        fe = self.roi_heads.box.feature_extractor
+        fe.init_memory()
+        if self.global_enable:
+            fe.init_global()
+
+    def _window(self):
+        """Concatenated local window (oldest first) in the reference's terms (:213-216)."""
+        bn, an = self.base_num, self.advanced_num
+        ns = tuple(min(bn, r["boxes"].shape[0]) for r in self.records)
+        rois = torch.cat([r["boxes"][:n] for r, n in zip(self.records, ns)], 0)
+        feats = torch.cat([r["feats"][:n] for r, n in zip(self.records, ns)], 0)
+        rois_dis = torch.cat([r["boxes"][:min(an, n)] for r, n in zip(self.records, ns)], 0)
+        cache = getattr(self, "_dis_cache", None)
+        if cache is None or cache[0] != ns or cache[1].device != feats.device:
+            rows, off = [], 0
+            for n in ns:
+                rows.append(torch.arange(off, off + min(an, n)))
+                off += n
+            cache = (ns, torch.cat(rows).to(feats.device))
+            self._dis_cache = cache
+        return rois, rois_dis, feats, cache[1]
+
+    @torch.no_grad()
+    def step(self, new_local=None, new_globals=(), im_size=None):
+        """Advance by one key frame given already-computed frame records: new_local enters the window (None at
+        the end-clamped tail is NOT allowed: the reference re-processes the last frame, so pass its record
+        again), new_globals go to the global pool.  Returns a BoxList on the device."""
+        fe = self.roi_heads.box.feature_extractor
+        if new_local is not None:
+            self.records.append(new_local)
+        for g in new_globals:
+            fe.update_global(g["feats"][:self.base_num])
+        key = self.records[self.key_frame_location]
+        rois, rois_dis, x_ref, dis_index = self._window()
+        x = fe.aggregate(key["feats"], key["boxes"], rois, rois_dis, x_ref, dis_index)
+        logits, deltas = self.roi_heads.box.predictor(x)
+        kb = BoxList(key["boxes"], im_size, "xyxy")
+        kb.add_field("objectness", key["scores"])
+        return self.roi_heads.box.post_processor((logits, deltas), [kb])[0]
+
+    def forward(self, images, targets=None):
+        """Reference call convention (generalized_rcnn_mega.py:48-78, data/datasets/vid_mega.py:95-142):
+        images = {"cur", "ref_l": [frame t+MAX_OFFSET], "ref_g": [...], "frame_category", "seg_len", "pattern",
+        "img_dir", "transforms"}.  Extension: "ref_l_init" may hold the preprocessed frames 1..12 needed at
+        frame_category 0, which replaces the PIL read inside forward (:185-191)."""
+        if targets is not None:
+            raise ValueError("In testing mode, targets should be None")
+        if self.training:
+            raise NotImplementedError("inference path only (training is out of scope)")
+        cur = to_image_list(images["cur"]).tensors.to(self.device)
+        H, W = cur.shape[-2:]
+        ref_g = [to_image_list(g).tensors.to(self.device) for g in images.get("ref_g", [])]
+        new_local = None
+        locals_batch = []
+        if images["frame_category"] == 0:
+            self._reset(images["seg_len"])
+            locals_batch.append(cur)
+            init = images.get("ref_l_init")          # init[j] = preprocessed frame j + 1
+            for _ in range(self.all_frame_interval - self.key_frame_location - 1):
+                self.end_id = min(self.end_id + 1, self.seg_len - 1)
+                if self.end_id == 0:
+                    t = cur
+                elif init is not None:
+                    t = to_image_list(init[self.end_id - 1]).tensors
+                else:
+                    from PIL import Image
+                    im = Image.open(images["img_dir"] % (images["pattern"] % self.end_id)).convert("RGB")
+                    t = images["transforms"](im)
+                    t = t[0] if isinstance(t, tuple) else t
+                    t = t.view(1, *t.shape)
+                locals_batch.append(t.to(self.device))
+        elif images["frame_category"] == 1:
+            self.end_id = min(self.end_id + 1, self.seg_len - 1)
+            locals_batch.append(to_image_list(images["ref_l"][0]).tensors.to(self.device))
+        batch = torch.cat(locals_batch + ref_g, dim=0)
+        want = [self.key_num] * len(locals_batch) + [self.base_num] * len(ref_g)
+        recs = self.frame_stage(batch, want)
+        loc, glob = recs[:len(locals_batch)], recs[len(locals_batch):]
+        if images["frame_category"] == 0:
+            for _ in range(self.key_frame_location + 1):
+                self.records.append(loc[0])
+            for r in loc[1:]:
+                self.records.append(r)
+        else:
+            new_local = loc[0]
+        return [self.step(new_local, glob, (W, H))]
+
+
+DETECTION_META_ARCHITECTURES.register("GeneralizedRCNNMEGA", GeneralizedRCNNMEGA)
+
+
+def build_detection_model(cfg):
+    """detector/detectors.py:9-18."""
+    return DETECTION_META_ARCHITECTURES[cfg.MODEL.META_ARCHITECTURE](cfg)

@@ -39,6 +39,54 @@ def _ws(nbytes, device):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
+class Profiler(object):
+    """Per-kernel-family GPU time from HIP event pairs recorded on the launch stream (torch's current stream,
+    the one every wrapper launches on), with the algorithmic FLOPs / bytes each launch stands for.  Used by
+    bench.py for the roofline line; never enabled in the timed region."""
+
+    def __init__(self):
+        self.items = []
+
+    def begin(self, family, flops=0.0, nbytes=0.0):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return [family, float(flops), float(nbytes), e0]
+
+    def end(self, tok):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        tok.append(e1)
+        self.items.append(tok)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, fl, nb, e0, e1 in self.items:
+            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+_PROF = None
+
+
+def set_profiler(p):
+    global _PROF
+    _PROF = p
+
+
+def _pb(family, flops=0.0, nbytes=0.0):
+    return None if _PROF is None else _PROF.begin(family, flops, nbytes)
+
+
+def _pe(tok):
+    if tok is not None:
+        _PROF.end(tok)
+
+
 # ------------------------------------------------------------------------------------------------ conv / linear
 def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,
                 out=None):
@@ -59,8 +107,10 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
         assert residual.shape == out.shape and residual.dtype == x.dtype and residual.is_contiguous()
     for v in (scale, bias):
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
+    _tok = _pb("igemm_" + ("bf16" if x.dtype == torch.bfloat16 else "f32"), 2.0 * N * Ho * Wo * Cout * R * S * Cin, x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size())
     rc = lib.mega_conv2d_nhwc(_ptr(x), _ptr(w), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin,
                               Cout, R, S, stride, pad, dil, int(relu), Cout, Cout, _dt(x), _DT[odt], _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_conv2d_nhwc")
     return out
 
@@ -82,8 +132,10 @@ def stem(x_nchw, w_tap64, scale, bias, out_dtype):
     assert C == 3 and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = torch.empty((N, Ho, Wo, 64), dtype=out_dtype, device=x_nchw.device)
+    _tok = _pb("stem", 2.0 * N * Ho * Wo * 64 * 147, x_nchw.numel() * 4 + out.numel() * out.element_size())
     rc = lib.mega_stem_conv_bn_relu(_ptr(x_nchw), _ptr(w_tap64), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
                                     _DT[out_dtype], _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_stem_conv_bn_relu")
     return out
 
@@ -95,7 +147,9 @@ def maxpool3x3s2(x):
     assert x.is_contiguous()
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    _tok = _pb("maxpool", 0.0, (x.numel() + out.numel()) * x.element_size())
     rc = lib.mega_maxpool3x3s2_nhwc(_ptr(x), _ptr(out), N, H, W, C, _dt(x), _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_maxpool3x3s2_nhwc")
     return out
 
@@ -114,8 +168,10 @@ def roi_align(feat, rois, spatial_scale, pooled, sampling_ratio, in_nhwc=True, o
     assert feat.is_contiguous() and rois.dtype == torch.float32 and rois.is_contiguous() and rois.shape[1] == 5
     shape = (K, ph * pw, C) if out_nhwc else (K, C, ph, pw)
     out = torch.empty(shape, dtype=feat.dtype, device=feat.device)
+    _tok = _pb("roi_align", 0.0, out.numel() * out.element_size() + feat.numel() * feat.element_size())
     rc = lib.mega_roi_align_fwd(_ptr(feat), _ptr(rois), _ptr(out), K, C, H, W, float(spatial_scale), ph, pw,
                                 int(sampling_ratio), int(in_nhwc), int(out_nhwc), _dt(feat), _dt(feat), _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_roi_align_fwd")
     return out
 
@@ -155,9 +211,11 @@ def rpn_select(rpn_out, cell_anchors, Hf, Wf, anchor_stride, pre_nms, post_nms, 
     cnt = torch.empty((B,), dtype=torch.int32, device=rpn_out.device)
     nb = lib.mega_rpn_select_workspace_bytes(B, k)
     ws = _ws(nb, rpn_out.device)
+    _tok = _pb("rpn_select", 0.0, rpn_out.numel() * 4)
     rc = lib.mega_rpn_select(_ptr(rpn_out), _ptr(cell_anchors), B, Hf, Wf, A, ldc, anchor_stride, pre_nms, post_nms,
                              float(nms_thresh), int(strict_gt), float(min_size), float(im_w), float(im_h),
                              _ptr(props), _ptr(scores), _ptr(cnt), _ptr(ws), nb, _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_rpn_select")
     return props, scores, cnt
 
@@ -180,10 +238,12 @@ def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh,
     assert logits.dtype == torch.float32 and deltas.dtype == torch.float32 and props.dtype == torch.float32
     assert logits.is_contiguous() and deltas.is_contiguous() and props.is_contiguous()
     wx, wy, ww, wh = weights
+    _tok = _pb("postprocess", 0.0, (logits.numel() + deltas.numel()) * 4)
     rc = lib.mega_postprocess(_ptr(logits), _ptr(deltas), _ptr(props), _ptr(nprop), R, NC, wx, wy, ww, wh,
                               float(im_w), float(im_h), float(score_thresh), float(nms_thresh), int(strict_gt),
                               int(max_det), _ptr(ob), _ptr(os_), _ptr(ol), _ptr(oc), _ptr(probs), _ptr(ws), nb,
                               _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_postprocess")
     return (ob, os_, ol, oc, probs) if want_probs else (ob, os_, ol, oc)
 
@@ -196,8 +256,10 @@ def position_logits(rois_q, rois_k, wg_t, bg, dim_mat):
     Nq, Nk = rois_q.shape[0], rois_k.shape[0]
     ldp = (Nk + 31) // 32 * 32
     out = torch.empty((16, Nq, ldp), dtype=torch.float32, device=rois_q.device)
+    _tok = _pb("pos_logits", 2.0 * Nq * Nk * 1024, 16.0 * Nq * ldp * 4)
     rc = lib.mega_position_logits(_ptr(rois_q.contiguous()), _ptr(rois_k.contiguous()), _ptr(wg_t), _ptr(bg),
                                   _ptr(dim_mat), _ptr(out), Nq, Nk, ldp, _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_position_logits")
     return out
 
@@ -209,10 +271,12 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     Nq = q.shape[0]
     assert q.dtype == k.dtype == vt.dtype and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
     out = torch.empty((Nq, groups * 64), dtype=q.dtype, device=q.device)
+    _tok = _pb("attention_" + ("bf16" if q.dtype == torch.bfloat16 else "f32"), 4.0 * Nq * Nk * 64 * groups, (q.numel() + k.numel() + vt.numel() + out.numel()) * q.element_size() + (0 if pos is None else pos.numel() * 4))
     rc = lib.mega_relation_attention(_ptr(q), q.shape[1], _ptr(k), k.shape[1], _ptr(vt), vt.shape[1], _ptr(pos),
                                      0 if pos is None else pos.shape[2], _ptr(resid),
                                      0 if resid is None else resid.shape[1], _ptr(bias_v), _ptr(out), groups * 64,
                                      Nq, Nk, groups, 1.0 / math.sqrt(64.0), _dt(q), _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_relation_attention")
     return out
 
@@ -224,8 +288,10 @@ def preprocess_frames(frames_u8, mean, to_bgr=True):
     N, H, W, C = frames_u8.shape
     assert C == 3 and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
     out = torch.empty((N, 3, H, W), dtype=torch.float32, device=frames_u8.device)
+    _tok = _pb("preprocess", 0.0, frames_u8.numel() * 5)
     rc = lib.mega_preprocess_frames(_ptr(frames_u8), _ptr(out), N, H, W, float(mean[0]), float(mean[1]),
                                     float(mean[2]), int(to_bgr), _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_preprocess_frames")
     return out
 
@@ -240,7 +306,9 @@ def linear_transposed(w, x, ld):
     M = x.shape[0]
     assert x.shape[1] == K and ld >= M and w.dtype == x.dtype and w.is_contiguous() and x.is_contiguous()
     out = torch.zeros((Nout, ld), dtype=x.dtype, device=x.device)
+    _tok = _pb("igemm_" + ("bf16" if x.dtype == torch.bfloat16 else "f32"), 2.0 * Nout * M * K, (w.numel() + x.numel() + out.numel()) * x.element_size())
     rc = lib.mega_conv2d_nhwc(_ptr(w), _ptr(x), None, None, None, _ptr(out), Nout, 1, 1, K, M, 1, 1, 1, 0, 1, 0, ld,
                               ld, _dt(x), _dt(x), _stream())
+    _pe(_tok)
     _lib.check(rc, "mega_conv2d_nhwc(transposed)")
     return out

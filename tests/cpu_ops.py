@@ -1,0 +1,138 @@
+"""TEST-ONLY stand-in for mega.pytorch_amd.ops built from the CPU oracle, so that the HOST logic of the
+product (weight packing / permutations, the per-video state machine, pool assembly, sharding) can be
+exercised by the `-m "not gpu"` suite on a box without a GPU.  It is injected by monkeypatching inside
+tests only; the product package never imports it and has no CPU path of its own.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import mega_oracle as mo
+from oracle import native
+
+
+def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,
+                out=None):
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=stride, padding=pad, dilation=dil)
+    if scale is not None:
+        y = y * scale.view(1, -1, 1, 1)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    y = y.permute(0, 2, 3, 1)
+    if residual is not None:
+        y = y + residual.float()
+    if relu:
+        y = F.relu(y)
+    return y.contiguous().to(out_dtype or x.dtype)
+
+
+def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None):
+    M, K = x.shape
+    y = conv2d_nhwc(x.view(M, 1, 1, K), w.view(w.shape[0], 1, 1, K), scale=scale, bias=bias,
+                    residual=None if residual is None else residual.view(M, 1, 1, -1), relu=relu, out_dtype=out_dtype)
+    return y.view(M, w.shape[0])
+
+
+def linear_transposed(w, x, ld):
+    out = torch.zeros((w.shape[0], ld), dtype=x.dtype)
+    out[:, :x.shape[0]] = (x.float() @ w.float().t()).t().to(x.dtype)
+    return out
+
+
+def stem(x_nchw, w_tap64, scale, bias, out_dtype):
+    w = w_tap64.view(3, 7, 7, 64).permute(3, 0, 1, 2)
+    y = F.conv2d(x_nchw, w, stride=2, padding=3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    return F.relu(y).permute(0, 2, 3, 1).contiguous().to(out_dtype)
+
+
+def maxpool3x3s2(x):
+    return F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+
+def roi_align(feat, rois, spatial_scale, pooled, sampling_ratio, in_nhwc=True, out_nhwc=True):
+    f = feat.float().permute(0, 3, 1, 2).contiguous() if in_nhwc else feat.float()
+    out = torch.from_numpy(native.roi_align(f.numpy(), rois.numpy(), spatial_scale, pooled[0], pooled[1], sampling_ratio))
+    if out_nhwc:
+        K, C = out.shape[:2]
+        out = out.permute(0, 2, 3, 1).reshape(K, pooled[0] * pooled[1], C)
+    return out.contiguous().to(feat.dtype)
+
+
+def nms(dets, scores, thr, strict_gt=True):
+    return torch.from_numpy(native.nms(dets.numpy(), scores.numpy(), thr, strict_gt))
+
+
+def rpn_select(rpn_out, cell_anchors, Hf, Wf, anchor_stride, pre_nms, post_nms, nms_thresh, min_size, im_w, im_h,
+               strict_gt=True):
+    B = rpn_out.shape[0]
+    A = cell_anchors.shape[0]
+    anchors = mo.grid_anchors(cell_anchors, Hf, Wf, anchor_stride)
+    props = torch.zeros((B, post_nms, 4))
+    scores = torch.zeros((B, post_nms))
+    cnt = torch.zeros((B,), dtype=torch.int32)
+    for b in range(B):
+        o = rpn_out[b].view(Hf, Wf, 5 * A).permute(2, 0, 1)
+        pb, ps = mo.rpn_select(o[:A], o[A:], anchors, im_w, im_h, pre_nms, post_nms, nms_thresh, min_size, strict_gt)
+        n = pb.shape[0]
+        props[b, :n], scores[b, :n], cnt[b] = pb, ps, n
+    return props, scores, cnt
+
+
+def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh, nms_thresh, max_det,
+                strict_gt=True, want_probs=False):
+    cfg = mo.OracleCfg(score_thresh=score_thresh, nms=nms_thresh, detections_per_img=max_det,
+                       bbox_reg_weights=tuple(weights), nms_strict_gt=strict_gt, num_classes=logits.shape[1])
+    b, s, l = mo.postprocess(logits, deltas, props, im_w, im_h, cfg)
+    cap = (logits.shape[1] - 1) * logits.shape[0]
+    ob, os_, ol = torch.zeros((cap, 4)), torch.zeros((cap,)), torch.zeros((cap,), dtype=torch.int64)
+    n = b.shape[0]
+    ob[:n], os_[:n], ol[:n] = b, s, l
+    return ob, os_, ol, torch.tensor([n], dtype=torch.int32)
+
+
+def position_logits(rois_q, rois_k, wg_t, bg, dim_mat):
+    pe = mo.cal_position_embedding(rois_q, rois_k)
+    w = wg_t.t().contiguous().view(16, 64, 1, 1)
+    out = (F.relu(F.conv2d(pe, w, bg)) + 1e-6).log()[0]
+    ldp = (rois_k.shape[0] + 31) // 32 * 32
+    full = torch.zeros((16, rois_q.shape[0], ldp))
+    full[:, :, :rois_k.shape[0]] = out
+    return full
+
+
+def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=16):
+    Nq = q.shape[0]
+    qh = q.float().view(Nq, groups, 64).permute(1, 0, 2)
+    kh = k.float().view(Nk, groups, 64).permute(1, 0, 2)
+    s = torch.bmm(qh, kh.transpose(1, 2)) / math.sqrt(64.0)
+    if pos is not None:
+        s = s + pos[:, :, :Nk]
+    p = F.softmax(s, dim=2)
+    v = vt.float()[:, :Nk].view(groups, 64, Nk)
+    o = torch.bmm(p, v.transpose(1, 2)).permute(1, 0, 2).reshape(Nq, groups * 64)
+    if bias_v is not None:
+        o = o + bias_v
+    if resid is not None:
+        o = o + resid.float()
+    return o.to(q.dtype)
+
+
+def preprocess_frames(frames_u8, mean, to_bgr=True):
+    x = frames_u8.permute(0, 3, 1, 2).float() / 255.0
+    if to_bgr:
+        x = x[:, [2, 1, 0]] * 255.0
+    return x - torch.tensor(mean).view(1, 3, 1, 1)
+
+
+ALL = ["conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+       "postprocess", "position_logits", "relation_attention", "preprocess_frames"]
+
+
+def install(monkeypatch):
+    """Replace every kernel wrapper of mega.pytorch_amd.ops with its oracle-backed CPU twin."""
+    from mega.pytorch_amd import ops
+    g = globals()
+    for name in ALL:
+        monkeypatch.setattr(ops, name, g[name])

@@ -1,0 +1,232 @@
+"""Generates tests/golden/*.npz FROM THE REFERENCE ITSELF (run in the build container, where
+/root/reference exists; the fixtures are committed because the reference cannot travel to the GPU box).
+
+  python tests/golden/make_golden.py
+
+1. ref_tests_nms.npz / ref_tests_box_coder.npz -- the known-answer vectors held by the reference's own tests
+   (tests/test_nms.py:11-217, tests/test_box_coder.py:11-105).  They are extracted by EXECUTING those test
+   modules under oracle/ref_shim.py with the op under test and numpy's assert functions wrapped by recorders, so
+   no literal is transcribed by hand; the reference's ops must pass their own asserts while recording.
+2. ref_ops.npz  -- seeded inputs/outputs of the reference's native ops (mega_core._C.nms / roi_align_forward,
+   i.e. csrc/cpu/*.cpp compiled by oracle/build_ref.py) and python pieces (anchors, BoxCoder.decode,
+   position embedding, attention_module_multi_head, RPNPostProcessor, PostProcessor).
+3. ref_e2e_r50.npz -- GeneralizedRCNNMEGA (R-50 MEGA config, calibrated synthetic weights from
+   mega.pytorch_amd.synth, seeded synthetic 160x256 clip) run for a few key frames on CPU: final detections and
+   the intermediates named in SURVEY.md 8a.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_shim  # noqa: E402
+from mega.pytorch_amd import synth  # noqa: E402
+
+E2E = dict(H=160, W=256, T=30, nkey=4, seed_w=1, seed_clip=3, global_seed=0)
+
+
+def _load_ref_test(name):
+    spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(ref_shim.REF_ROOT, "tests", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def golden_from_reference_tests():
+    ref_shim.install()
+    # ---- tests/test_nms.py
+    mod = _load_ref_test("test_nms")
+    calls, expects = [], []
+    real_nms = mod.box_nms
+
+    def rec_nms(boxes, scores, thresh):
+        keep = real_nms(boxes, scores, thresh)
+        calls.append((boxes.numpy().copy(), scores.numpy().copy(), float(thresh)))
+        return keep
+    mod.box_nms = rec_nms
+    real_assert = np.testing.assert_array_equal
+
+    def rec_assert(a, b, *args, **kw):
+        real_assert(a, b, *args, **kw)          # the reference op must satisfy the reference's own assert
+        expects.append(np.asarray(b).copy())
+    np.testing.assert_array_equal = rec_assert
+    try:
+        t = mod.TestNMS()
+        t.test_nms_cpu()
+        t.test_nms1_cpu()
+    finally:
+        np.testing.assert_array_equal = real_assert
+    assert len(calls) == len(expects) == 6
+    out = {}
+    for i, ((b, s, thr), e) in enumerate(zip(calls, expects)):
+        out["boxes%d" % i], out["scores%d" % i], out["thr%d" % i], out["keep%d" % i] = b, s, np.float32(thr), np.sort(e)
+    out["n"] = np.int64(len(calls))
+    np.savez(os.path.join(HERE, "ref_tests_nms.npz"), **out)
+    # ---- tests/test_box_coder.py
+    mod = _load_ref_test("test_box_coder")
+    rec = {}
+    real_decode = mod.BoxCoder.decode
+
+    def rec_decode(self, rel_codes, boxes):
+        r = real_decode(self, rel_codes, boxes)
+        rec.update(weights=np.array(self.weights, dtype=np.float32), rel_codes=rel_codes.numpy().copy(),
+                   boxes=boxes.numpy().copy(), out=r.numpy().copy())
+        return r
+    mod.BoxCoder.decode = rec_decode
+    real_allclose = np.testing.assert_allclose
+
+    def rec_allclose(a, b, *args, **kw):
+        real_allclose(a, b, *args, **kw)
+        rec["expected"] = np.asarray(b).copy()
+        rec["atol"] = np.float32(kw.get("atol", 0))
+    np.testing.assert_allclose = rec_allclose
+    try:
+        mod.TestBoxCoder().test_box_decoder()
+    finally:
+        np.testing.assert_allclose = real_allclose
+        mod.BoxCoder.decode = real_decode
+    np.savez(os.path.join(HERE, "ref_tests_box_coder.npz"), **rec)
+    print("reference test vectors: %d nms cases, box_coder %s" % (len(calls), rec["out"].shape))
+
+
+def golden_ops():
+    ref_shim.install()
+    from mega_core import _C
+    from mega_core.modeling.box_coder import BoxCoder
+    from mega_core.modeling.rpn.anchor_generator import generate_anchors, AnchorGenerator
+    from mega_core.modeling.rpn.inference import RPNPostProcessor
+    from mega_core.modeling.roi_heads.box_head.inference import PostProcessor
+    from mega_core.modeling.roi_heads.box_head.roi_box_feature_extractors import AttentionExtractor
+    from mega_core.structures.bounding_box import BoxList
+    from mega_core.structures.image_list import ImageList
+    g = torch.Generator().manual_seed(123)
+    out = {}
+    # native ops
+    n = 400
+    ctr = torch.rand((n, 2), generator=g) * 300
+    wh = torch.rand((n, 2), generator=g) * 90 + 4
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=1)
+    scores = torch.rand((n,), generator=g)
+    out["nms_boxes"], out["nms_scores"] = boxes.numpy(), scores.numpy()
+    for thr in (0.3, 0.5, 0.7):
+        out["nms_keep_%d" % int(thr * 10)] = _C.nms(boxes, scores, thr).numpy()
+    feat = torch.randn((2, 24, 20, 30), generator=g)
+    rois = torch.tensor([[0, 0, 0, 479, 319], [1, 35.2, 17.9, 200.4, 180.1], [0, 100, 50, 104, 53], [1, 300, 200, 470, 310],
+                         [0, -20, -30, 50, 60], [1, 450, 300, 520, 400]], dtype=torch.float32)
+    out["ra_feat"], out["ra_rois"] = feat.numpy(), rois.numpy()
+    out["ra_out_sr0"] = _C.roi_align_forward(feat, rois, 1 / 16., 7, 7, 0).numpy()
+    out["ra_out_sr2"] = _C.roi_align_forward(feat, rois, 1 / 16., 7, 7, 2).numpy()
+    # anchors
+    out["cell_anchors"] = generate_anchors(16, (64, 128, 256, 512), (0.5, 1.0, 2.0)).float().numpy()
+    ag = AnchorGenerator((64, 128, 256, 512), (0.5, 1.0, 2.0), (16,), 0)
+    out["grid_anchors_5x7"] = ag.grid_anchors([(5, 7)])[0].numpy()
+    # box coder
+    rel = torch.randn((50, 8), generator=g)
+    rel[0, 2] = 9.0
+    bx = boxes[:50]
+    out["bc_rel"], out["bc_boxes"] = rel.numpy(), bx.numpy()
+    out["bc_out_1111"] = BoxCoder((1., 1., 1., 1.)).decode(rel, bx).numpy()
+    out["bc_out_10_5"] = BoxCoder((10., 10., 5., 5.)).decode(rel, bx).numpy()
+    # position embedding + attention
+    sd = synth.make_state_dict(blocks=(1, 1, 1), seed=4)
+    bq, bk = boxes[:23], boxes[30:71]
+    pe = AttentionExtractor.extract_position_embedding(AttentionExtractor.extract_position_matrix(bq, bk), 64)
+    out["pe_bq"], out["pe_bk"], out["pe_out"] = bq.numpy(), bk.numpy(), pe.numpy()
+    cfg = ref_shim.make_cfg("configs/MEGA/vid_R_101_C4_MEGA_1x.yaml")
+    model = ref_shim.build_model(cfg)
+    fe = model.roi_heads.box.feature_extractor
+    fe_sd = {k[len(synth.FE):]: v for k, v in synth.make_state_dict(seed=4).items() if k.startswith(synth.FE)}
+    fe.load_state_dict(fe_sd)
+    x = torch.randn((23, 1024), generator=g)
+    r = torch.randn((41, 1024), generator=g)
+    with torch.no_grad():
+        pe4 = fe.cal_position_embedding(bq, bk)
+        out["att_x"], out["att_ref"] = x.numpy(), r.numpy()
+        out["att_local1"] = fe.attention_module_multi_head(x, r, pe4, index=1, ver="local").numpy()
+        out["att_global0"] = fe.attention_module_multi_head(x, r, None, index=0, ver="global").numpy()
+    out["att_seed"] = np.int64(4)
+    # RPN post-processor
+    A, Hf, Wf = 12, 9, 13
+    obj = torch.randn((1, A, Hf, Wf), generator=g) * 2
+    reg = torch.randn((1, 4 * A, Hf, Wf), generator=g) * 0.5
+    im_w, im_h = Wf * 16 - 8, Hf * 16 - 8
+    anchors = [[BoxList(ag.grid_anchors([(Hf, Wf)])[0], (im_w, im_h), mode="xyxy")]]
+    pp = RPNPostProcessor(pre_nms_top_n=600, post_nms_top_n=50, nms_thresh=0.7, min_size=0)
+    pp.eval()
+    res = pp(anchors, [obj], [reg])[0]
+    out["rpn_obj"], out["rpn_reg"], out["rpn_imwh"] = obj.numpy(), reg.numpy(), np.array([im_w, im_h])
+    out["rpn_boxes"], out["rpn_scores"] = res.bbox.numpy(), res.get_field("objectness").numpy()
+    # box-head post-processor
+    R = 60
+    logits = torch.randn((R, 31), generator=g) * 1.5
+    deltas = torch.randn((R, 124), generator=g) * 0.5
+    props = BoxList(boxes[:R].clamp(min=0, max=250), (300, 260), mode="xyxy")
+    post = PostProcessor(0.001, 0.5, 300, BoxCoder((10., 10., 5., 5.)))
+    det = post((logits, deltas), [props])[0]
+    out["post_logits"], out["post_deltas"], out["post_props"] = logits.numpy(), deltas.numpy(), props.bbox.numpy()
+    out["post_boxes"], out["post_scores"] = det.bbox.numpy(), det.get_field("scores").numpy()
+    out["post_labels"] = det.get_field("labels").numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_ops.npz"), **out)
+    print("reference op fixtures written: %d arrays" % len(out))
+
+
+def golden_e2e():
+    c = E2E
+    cfg = ref_shim.make_cfg("configs/MEGA/vid_R_50_C4_MEGA_1x.yaml")
+    model = ref_shim.build_model(cfg)
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, stage=3, global_res_stage=0, seed=c["seed_w"])
+    model.load_state_dict(sd, strict=True)
+    frames = synth.preprocess_cpu(synth.make_clip(c["T"], c["H"], c["W"], seed=c["seed_clip"]))
+    rng = np.random.RandomState(c["global_seed"])
+    shuffled = np.arange(c["T"]); rng.shuffle(shuffled)
+    gs = cfg.MODEL.VID.MEGA.GLOBAL.SIZE
+
+    import mega_core.modeling.detector.generalized_rcnn_mega as gm
+
+    class _FakeImg(object):
+        def __init__(self, i): self.i = i
+        def convert(self, m): return self
+
+    class _FakeImage(object):
+        @staticmethod
+        def open(path): return _FakeImg(int(path))
+    gm.Image = _FakeImage
+    # record intermediates with forward hooks
+    trace = {}
+    fe = model.roi_heads.box.feature_extractor
+    pred = model.roi_heads.box.predictor
+    pred.register_forward_hook(lambda m, i, o: trace.update(x=i[0].detach().clone(), logits=o[0].detach().clone(),
+                                                            deltas=o[1].detach().clone()))
+    out = {}
+    for idx in range(c["nkey"]):
+        gl = [int(shuffled[(idx + gs - i - 1) % c["T"]]) for i in range(gs if idx == 0 else 1)]
+        images = {"cur": frames[idx], "ref_l": [frames[min(c["T"] - 1, idx + 12)]], "ref_g": [frames[g] for g in gl],
+                  "frame_category": 0 if idx == 0 else 1, "seg_len": c["T"], "pattern": "%d", "img_dir": "%s",
+                  "transforms": lambda im: frames[im.i]}
+        with torch.no_grad():
+            det = model(images)[0]
+        out["boxes%d" % idx] = det.bbox.numpy()
+        out["scores%d" % idx] = det.get_field("scores").numpy()
+        out["labels%d" % idx] = det.get_field("labels").numpy()
+        out["x%d" % idx] = trace["x"].numpy()[:48]          # first rows only: keeps the fixture small
+        out["logits%d" % idx] = trace["logits"].numpy()
+        out["deltas%d" % idx] = trace["deltas"].numpy()
+        print("frame", idx, "dets", det.bbox.shape[0])
+    for k, v in c.items():
+        out["cfg_" + k] = np.int64(v)
+    np.savez_compressed(os.path.join(HERE, "ref_e2e_r50.npz"), **out)
+
+
+if __name__ == "__main__":
+    if not ref_shim.available():
+        sys.exit("needs /root/reference")
+    torch.set_num_threads(8)
+    golden_from_reference_tests()
+    golden_ops()
+    golden_e2e()

@@ -1,0 +1,127 @@
+"""CPU: host-side logic of the product (value types, config, checkpoint-key compatibility, weight packing,
+the per-video MEGA state machine) with the kernel wrappers replaced by oracle-backed CPU twins
+(tests/cpu_ops.py) -- so a wrong permutation / pool order / memory update shows up here, before GPU time
+is spent.  The kernels themselves are checked by the -m gpu suite.
+"""
+import numpy as np
+import pytest
+import torch
+
+from mega.pytorch_amd import config, modeling, structures, synth
+from oracle import mega_oracle as mo
+import cpu_ops
+
+
+def test_boxlist_and_cat():
+    a = structures.BoxList(torch.tensor([[0., 0., 10., 10.], [5., 5., 300., 300.]]), (100, 80))
+    a.add_field("scores", torch.tensor([0.5, 0.7]))
+    a.clip_to_image(remove_empty=False)
+    assert a.bbox[1].tolist() == [5., 5., 99., 79.]
+    b = a[torch.tensor([1])]
+    assert len(b) == 1 and b.get_field("scores").item() == pytest.approx(0.7)
+    c = structures.cat_boxlist([a, b])
+    assert len(c) == 3 and c.fields() == ["scores"]
+    with pytest.raises(ValueError):
+        structures.BoxList(torch.zeros(3), (1, 1))
+    il = structures.to_image_list(torch.zeros(3, 8, 9))
+    assert il.tensors.shape == (1, 3, 8, 9) and tuple(il.image_sizes[0]) == (8, 9)
+
+
+def test_config_tree_and_registries():
+    c = config.get_cfg("R-101")
+    assert c.MODEL.VID.MEGA.ALL_FRAME_INTERVAL == 25 and c.MODEL.VID.MEGA.GLOBAL.RES_STAGE == 1
+    c50 = config.get_cfg("R-50")
+    assert c50.MODEL.VID.ROI_BOX_HEAD.REDUCE_CHANNEL and c50.MODEL.VID.MEGA.GLOBAL.RES_STAGE == 0
+    c.merge_from_list(["MODEL.VID.MEGA.GLOBAL.SIZE", 4])
+    assert c.MODEL.VID.MEGA.GLOBAL.SIZE == 4
+    with pytest.raises(KeyError):
+        c.merge_from_list(["MODEL.NOPE", 1])
+    for reg, name in [(modeling.BACKBONES, "R-101-C4"), (modeling.BACKBONES, "R-50-C4"),
+                      (modeling.RPN_HEADS, "SingleConvRPNHead"),
+                      (modeling.ROI_BOX_FEATURE_EXTRACTORS, "MEGAFeatureExtractor"),
+                      (modeling.ROI_BOX_PREDICTOR, "FPNPredictor"),
+                      (modeling.DETECTION_META_ARCHITECTURES, "GeneralizedRCNNMEGA")]:
+        assert name in reg
+
+
+@pytest.mark.parametrize("arch", ["R-50", "R-101"])
+def test_state_dict_keys_match_reference_layout(arch):
+    cfg = config.get_cfg(arch)
+    cfg.MODEL.DEVICE = "cpu"
+    m = modeling.build_detection_model(cfg)
+    r50 = arch == "R-50"
+    sd = synth.make_state_dict(blocks=(3, 4, 6) if r50 else (3, 4, 23), reduce_channel=r50,
+                               global_res_stage=0 if r50 else 1)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    if not r50:
+        assert len(sd) == 578 and sum(v.numel() for v in sd.values()) == 172877047   # SURVEY.md 8b probe
+
+
+def _small_cfg():
+    cfg = config.get_cfg("R-50")
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.NMS_STRICT_GT = True
+    return cfg
+
+
+def test_detector_state_machine_matches_oracle(monkeypatch):
+    """GeneralizedRCNNMEGA.forward (reference call convention + ref_l_init) == MegaOracle frame by frame:
+    cold start with 13x replication, sliding window, global pool, memory read-before-push."""
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    H, W, T, nkey = 96, 128, 16, 3
+    cfg = _small_cfg()
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    model = modeling.build_detection_model(cfg)
+    model.load_state_dict(sd)
+    frames = synth.preprocess_cpu(synth.make_clip(T, H, W, seed=2))
+    _, gfor = mo.global_frame_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
+    ocfg = mo.OracleCfg(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, nms_strict_gt=True)
+    orc = mo.MegaOracle(sd, ocfg)
+    for idx in range(nkey):
+        images = {"cur": frames[idx], "ref_l": [frames[min(T - 1, idx + 12)]], "ref_g": [frames[g] for g in gfor(idx)],
+                  "frame_category": 0 if idx == 0 else 1, "seg_len": T,
+                  "ref_l_init": [frames[i] for i in range(1, 13)]}
+        with torch.no_grad():
+            det = model(images)[0]
+            orc.trace = {}
+            wb, ws, wl = orc.forward_frame(frames[idx:idx + 1], 0 if idx == 0 else 1,
+                                           ref_l=frames[min(T - 1, idx + 12)][None],
+                                           ref_g=[frames[g][None] for g in gfor(idx)], seg_len=T,
+                                           frame_loader=lambda i: frames[i][None])
+        key = model.records[model.key_frame_location]
+        # (the CPU twins run the frame stage batched, the oracle frame by frame: MKL sums in a different order)
+        assert key["boxes"].shape == orc.trace["proposals"].shape
+        assert (key["boxes"] - orc.trace["proposals"]).abs().max() < 1e-3, "key proposals differ at frame %d" % idx
+        assert len(det) == wb.shape[0]
+        assert torch.equal(det.get_field("labels"), wl)
+        assert (det.bbox - wb).abs().max() < 5e-3
+        assert (det.get_field("scores") - ws).abs().max() < 1e-5
+    # memory / global pools have the sizes the reference would have
+    fe = model.roi_heads.box.feature_extractor
+    assert len(fe.mem_queue_list[0]["feats"]) == nkey and fe.mem[1]["feats"].shape[0] == nkey * 15
+    assert fe.global_cache[0]["feats"].shape[0] == 10 * 75
+
+
+def test_reference_call_convention_of_submodules(monkeypatch):
+    """backbone / rpn / feature_extractor / roi_heads keep the reference's call signatures at the seams."""
+    cpu_ops.install(monkeypatch)
+    cfg = _small_cfg()
+    model = modeling.build_detection_model(cfg)
+    model.load_state_dict(synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5))
+    img = synth.preprocess_cpu(synth.make_clip(1, 96, 128, seed=1))
+    with torch.no_grad():
+        feats = model.backbone(img)[0]
+        assert feats.shape == (1, 1024, 6, 8)
+        il = structures.to_image_list(img)
+        ref = model.rpn(il, (feats,), version="ref")
+        key, losses = model.rpn(il, (feats,), None)
+        assert isinstance(ref, list) and isinstance(ref[0], structures.BoxList) and losses == {}
+        assert len(ref[0]) <= 75 and len(key[0]) <= 300
+        n = len(ref[0])
+        assert torch.equal(key[0].bbox[:n], ref[0].bbox), "ref proposals are the first rows of the key proposals"
+        x = model.roi_heads.box.feature_extractor(feats, ref, pre_calculate=True)
+        assert x.shape == (n, 1024)
+    with pytest.raises(ValueError):
+        model({"cur": img[0], "ref_l": [], "ref_g": [], "frame_category": 0, "seg_len": 1}, targets=[1])
