@@ -211,7 +211,8 @@ def main():
                                    "300 key / 75 ref proposals, 3 attention stages (BASELINE configs[2]%s)"
                                    % (args.arch, args.width, args.height, "" if world == 1 else " sharded = configs[3]"),
                        "steps_per_batch": args.steps_per_batch, "parallelism": "frame-sharded x%d" % world,
-                       "avg_detections": round(ndet, 1)},
+                       "avg_detections": round(ndet, 1),
+                       "key_proposals_last_frame": int(model.records[model.key_frame_location]["boxes"].shape[0])},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_families": fam,
         }
         print(json.dumps(line))

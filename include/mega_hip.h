@@ -105,9 +105,10 @@ int mega_postprocess(const float* logits, const float* deltas, const float* prop
  * Replaces extract_position_matrix + extract_position_embedding + the Wgs 1x1 conv + relu + log
  * (roi_box_feature_extractors.py:147-176,:126-144,:593-597,:630) without materialising the
  * [64][Nq][Nk] embedding.  wg_t [64][16] (Wg transposed), bg [16], dim_mat [8] = 1000^(i/8);
- * out [16][Nq][ldp] f32, ldp >= Nk (attention wants ldp % 32 == 0). */
+ * out [16][Nq][ldp] f32, ldp >= Nk (attention wants ldp % 32 == 0).  precise != 0: libm-accurate sincosf
+ * (f32 parity mode); 0: two-constant range reduction + hardware sin/cos (abs error ~1e-6). */
 int mega_position_logits(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
-                         const float* dim_mat, float* out, int Nq, int Nk, int ldp, void* stream);
+                         const float* dim_mat, float* out, int Nq, int Nk, int ldp, int precise, void* stream);
 
 /* Relation-attention core (roi_box_feature_extractors.py:599-646): per head h (64-wide)
  *   out[q][h*64+j] = resid[q][h*64+j] + bias_v[h*64+j]
@@ -116,7 +117,13 @@ int mega_position_logits(const float* rois_q, const float* rois_k, const float* 
  * key-contiguous ([groups*64][ldv], pad columns zero).  pos / resid / bias_v may be NULL. */
 int mega_relation_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
                             const float* pos, int ldp, const void* resid, int ldr, const float* bias_v, void* out,
-                            int ldo, int Nq, int Nk, int groups, float scale, int dtype, void* stream);
+                            int ldo, int Nq, int Nk, int groups, float scale, int dtype, void* ws, size_t ws_bytes,
+                            void* stream);
+/* The key range of one call is split over mega_relation_attention_splits() block groups (flash-decoding style:
+ * partial max / sum / output per split, merged by a second kernel) when ws holds at least
+ * mega_relation_attention_workspace_bytes(); with ws == NULL the call runs unsplit. */
+int mega_relation_attention_splits(int Nq, int Nk, int groups);
+size_t mega_relation_attention_workspace_bytes(int Nq, int Nk, int groups);
 
 /* Test-time frame transform on device: uint8 HWC RGB [N][H][W][3] -> f32 CHW [N][3][H][W],
  * ToTensor -> (BGR*255 if to_bgr) -> minus mean, std 1.  Replaces the CPU chain

@@ -35,6 +35,7 @@ struct ConvParams {
   int M, K;
   int ldo, ldr;
   int relu;
+  unsigned in_bytes, w_bytes;
 };
 
 template <typename T> struct Mma;
@@ -57,7 +58,7 @@ template <> struct Mma<float> {
 };
 
 template <typename T, typename OT, int BM, int BN>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(ConvParams p) {
   constexpr int KE = KTB / (int)sizeof(T);   // K elements per tile
   constexpr int VE = 16 / (int)sizeof(T);    // elements per 16-B vector
   constexpr int AV = BM / 32;                // A vectors per thread per tile
@@ -85,14 +86,17 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(ConvParams p) {
   const int tile_m = lid / ntn, tile_n = lid - tile_m * ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const T* __restrict__ in = (const T*)p.in;
-  const T* __restrict__ wt = (const T*)p.w;
+  // Buffer descriptors: loads are branch-free `buffer_load_dwordx4 ... offen`; a lane that must read zero
+  // (conv padding, M / Cout tails) gets the offset 0xFFFFFFFF, which the hardware range check turns into 0.
+  // No exec-mask branches around the loads => the compiler keeps COUNTED vmcnt waits and two K-tiles stay in flight.
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
   // ---- per-thread load descriptors
   const int vec = tid & 7;
   const int lrow = tid >> 3;  // 0..31
   int a_hi0[AV], a_wi0[AV];
-  size_t a_base[AV];
+  unsigned a_base[AV];
   bool a_ok[AV];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -106,38 +110,36 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(ConvParams p) {
     const int wo = rem - ho * p.Wo;
     a_hi0[i] = ho * p.stride - p.pad;
     a_wi0[i] = wo * p.stride - p.pad;
-    a_base[i] = (size_t)nimg * p.H * p.W;
+    a_base[i] = (unsigned)nimg * (unsigned)(p.H * p.W);
   }
-  size_t b_off[BV];
+  unsigned b_off[BV];
   bool b_ok[BV];
 #pragma unroll
   for (int j = 0; j < BV; ++j) {
     const int n = n0 + lrow + 32 * j;
     b_ok[j] = n < p.Cout;
-    b_off[j] = (size_t)(b_ok[j] ? n : 0) * p.K + vec * VE;
+    b_off[j] = b_ok[j] ? ((unsigned)n * (unsigned)p.K + vec * VE) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
   }
 
-  uint4 areg[AV], breg[BV];
   int kr = 0, ks = 0, kc = 0;  // (r, s, c0) of the tile about to be loaded
   int kk = 0;                  // k offset of that tile
 
-  auto load_tile = [&]() {
+  auto load_tile = [&](uint4 (&areg)[AV], uint4 (&breg)[BV]) {
     const int dh = kr * p.dil, dw = ks * p.dil;
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
       const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      if (ok) {
-        const size_t off = (a_base[i] + (size_t)hi * p.W + wi) * p.Cin + kc + vec * VE;
-        areg[i] = *reinterpret_cast<const uint4*>(in + off);
-      } else {
-        areg[i] = make_uint4(0u, 0u, 0u, 0u);
-      }
+      const unsigned off = ((a_base[i] + (unsigned)(hi * p.W + wi)) * (unsigned)p.Cin + (unsigned)(kc + vec * VE)) *
+                           (unsigned)sizeof(T);
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : 0xFFFFFFFFu, 0, 0);
+      areg[i] = make_uint4(v.x, v.y, v.z, v.w);
     }
 #pragma unroll
     for (int j = 0; j < BV; ++j) {
-      if (b_ok[j]) breg[j] = *reinterpret_cast<const uint4*>(wt + b_off[j] + kk);
-      else breg[j] = make_uint4(0u, 0u, 0u, 0u);
+      const unsigned off = b_ok[j] ? b_off[j] + (unsigned)kk * (unsigned)sizeof(T) : 0xFFFFFFFFu;
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+      breg[j] = make_uint4(v.x, v.y, v.z, v.w);
     }
     // advance (r, s, c0)
     kk += KE;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(ConvParams p) {
       if (++ks == p.S) { ks = 0; ++kr; }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const uint4 (&areg)[AV], const uint4 (&breg)[BV]) {
     unsigned char* a = As + buf * BM * LDS_STRIDE;
     unsigned char* b = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
@@ -166,16 +168,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nkt = p.K / KE;
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-
   const int frag_off = (lane & 31) * LDS_STRIDE + (lane >> 5) * 16;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    const bool more = (kt + 1) < nkt;
-    if (more) load_tile();
+  auto compute = [&](int cur) {
     const unsigned char* a = As + cur * BM * LDS_STRIDE + (wm * WTM) * LDS_STRIDE + frag_off;
     const unsigned char* b = Bs + cur * BN * LDS_STRIDE + (wn * WTN) * LDS_STRIDE + frag_off;
 #pragma unroll
@@ -190,31 +184,86 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
     }
-    if (more) store_tile(cur ^ 1);
+  };
+
+  // ---- main loop: global loads run TWO K-tiles ahead of the MFMAs (two register sets, two LDS buffers,
+  //      one barrier per K-tile); the store of tile t+1 waits only for the older register set.
+  const int nkt = p.K / KE;
+  uint4 ra[AV], rb[BV], sa[AV], sb[BV];
+  //      The steady-state body has NO conditionals (hipcc merges wait counts conservatively at control-flow
+  //      joins: one conditional load collapses the counted vmcnt into vmcnt(0)).  Tiles past the end of K are
+  //      still "loaded" -- the buffer range check makes that harmless -- and never fed to an MFMA.
+  load_tile(ra, rb);                // tile 0
+  store_tile(0, ra, rb);
+  load_tile(ra, rb);                // tile 1 in flight
+  __syncthreads();
+  for (int it = 0; it < (nkt >> 1); ++it) {   // invariant: LDS buffer 0 holds tile 2*it, ra/rb hold tile 2*it+1
+    load_tile(sa, sb);              // tile 2*it+2
+    compute(0);                     // tile 2*it
+    store_tile(1, ra, rb);          // tile 2*it+1
+    __syncthreads();
+    load_tile(ra, rb);              // tile 2*it+3
+    compute(1);                     // tile 2*it+1
+    store_tile(0, sa, sb);          // tile 2*it+2
     __syncthreads();
   }
+  if (nkt & 1) {                    // odd tile count: the last tile sits in buffer 0
+    compute(0);
+    __syncthreads();                // the epilogue below re-uses the LDS buffers other waves may still read
+  }
 
-  // ---- epilogue: lane owns column n = (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-  OT* __restrict__ out = (OT*)p.out;
-  const T* __restrict__ res = (const T*)p.res;
+  // ---- epilogue.  Accumulators (lane owns column n = lane&31, rows (r&3)+8*(r>>2)+4*(lane>>5)) are scaled /
+  //      biased, staged through LDS as an f32 [BM][BN+4] tile, then written as whole 16-byte vectors along n:
+  //      coalesced row segments instead of 2-byte-per-lane stores; the residual is read the same way.
+  constexpr int CST = BN + 4;  // f32 row stride of the staged tile
+  float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-    if (n >= p.Cout) continue;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float bi = p.bias ? p.bias[n] : 0.f;
+    const int nl = wn * WTN + j * 32 + (lane & 31);
+    const int n = n0 + nl;
+    const float sc = (p.scale && n < p.Cout) ? p.scale[n] : 1.f;
+    const float bi = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+      const int mb = wm * WTM + i * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m < p.M) {
-          float v = acc[i][j][r] * sc + bi;
-          if (res) v += Elem<T>::ld(res + (size_t)m * p.ldr + n);
-          if (p.relu) v = fmaxf(v, 0.f);
-          Elem<OT>::st(out + (size_t)m * p.ldo + n, v);
-        }
+      for (int r = 0; r < 16; ++r) cs[(mb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][j][r] * sc + bi;
+    }
+  }
+  __syncthreads();
+  OT* __restrict__ out = (OT*)p.out;
+  const T* __restrict__ res = (const T*)p.res;
+  constexpr int OVE = 16 / (int)sizeof(OT);   // output elements per 16-byte vector
+  constexpr int VPR = BN / OVE;               // vectors per tile row
+  const bool vec_ok = (p.ldo % OVE == 0) && (!res || (sizeof(T) == sizeof(OT) && p.ldr % OVE == 0));
+  for (int e = tid; e < BM * VPR; e += NTHREADS) {
+    const int row = e / VPR, cv = e - row * VPR;
+    const int m = m0 + row, n = n0 + cv * OVE;
+    if (m >= p.M || n >= p.Cout) continue;
+    float v[OVE];
+#pragma unroll
+    for (int t = 0; t < OVE; t += 4) {
+      const float4 f = *reinterpret_cast<const float4*>(cs + row * CST + cv * OVE + t);
+      v[t] = f.x; v[t + 1] = f.y; v[t + 2] = f.z; v[t + 3] = f.w;
+    }
+    if (vec_ok && n + OVE <= p.Cout) {
+      if (res) {
+        const uint4 rr = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
+        const T* re = reinterpret_cast<const T*>(&rr);
+#pragma unroll
+        for (int t = 0; t < OVE; ++t) v[t] += Elem<T>::ld(re + t);
+      }
+      uint4 o;
+      OT* oe = reinterpret_cast<OT*>(&o);
+#pragma unroll
+      for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, p.relu ? fmaxf(v[t], 0.f) : v[t]);
+      *reinterpret_cast<uint4*>(out + (size_t)m * p.ldo + n) = o;
+    } else {
+      for (int t = 0; t < OVE && n + t < p.Cout; ++t) {
+        float x = v[t];
+        if (res) x += Elem<T>::ld(res + (size_t)m * p.ldr + n + t);
+        if (p.relu) x = fmaxf(x, 0.f);
+        Elem<OT>::st(out + (size_t)m * p.ldo + n + t, x);
       }
     }
   }
@@ -265,6 +314,13 @@ extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scal
   p.ldo = ldo > 0 ? ldo : Cout;
   p.ldr = ldr > 0 ? ldr : Cout;
   p.relu = relu;
+  {
+    const size_t esz = in_dtype == MEGA_BF16 ? 2 : 4;
+    const size_t ib = (size_t)N * H * W * Cin * esz, wb = (size_t)Cout * p.K * esz;
+    if (ib >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return MEGA_ERR_ARG;  // 32-bit buffer offsets
+    p.in_bytes = (unsigned)ib;
+    p.w_bytes = (unsigned)wb;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == MEGA_BF16) {
     if (Cin % 64 != 0) return MEGA_ERR_ARG;

@@ -13,24 +13,46 @@
 //
 // Kernels:
 //   pos_logits_kernel : boxes -> w[h][q][k] (f32), one thread per (q,k) pair, 64-d sin/cos embedding and the
-//                       16x64 Wg contraction in registers (Wg read through the scalar cache).
+//                       16x64 Wg contraction in registers (Wg staged in LDS, broadcast reads).
 //   attn_kernel<T>    : flash-style streaming softmax.  One wave owns 32 query rows of one head; per 32-key tile
 //                       S^T = K Q^T on MFMA (so a lane holds 16 keys of ONE query: row max / sum are register
 //                       reductions + one cross-half shuffle), P feeds the PV MFMA straight from registers,
 //                       V is consumed from a key-contiguous (transposed) LDS image.  bf16 -> mfma_32x32x16_bf16,
-//                       f32 -> mfma_32x32x2_f32 (exact f32, parity mode).
+//                       f32 -> mfma_32x32x2_f32 (exact f32, parity mode).  The key range can be split over
+//                       blockIdx.z (a call has only Nq/128 * 16 blocks for 256 CUs); partial (m, l, O) are then
+//                       merged by attn_combine_kernel.
 #include "common.h"
 
 namespace {
 
 // ----------------------------------------------------------------------------------------------- position logits
+// sin/cos of a = 100 * log-ratio / 1000^(i/8), |a| up to a few hundred rad: two-constant Cody-Waite reduction to
+// [-pi, pi] (exact to ~1e-7 rad for |n| < 2^12), then the hardware sin/cos (argument in revolutions).
+__device__ __forceinline__ void sincos_reduced(float a, float* sn, float* cs) {
+  const float INV2PI = 0.15915494309189535f;
+  const float TWO_PI_HI = 6.28318548202514648f;      // float(2*pi)
+  const float TWO_PI_LO = -1.7484555e-7f;            // 2*pi - float(2*pi)
+  const float n = rintf(a * INV2PI);
+  float r = fmaf(-n, TWO_PI_HI, a);
+  r = fmaf(-n, TWO_PI_LO, r);
+  const float rev = r * INV2PI;
+  *sn = __builtin_amdgcn_sinf(rev);
+  *cs = __builtin_amdgcn_cosf(rev);
+}
+
 // rois_q [Nq][4], rois_k [Nk][4], wgt [64][16] (Wg transposed), bg [16], dim_mat [8]
 // out [16][Nq][ldp] f32
+template <bool PRECISE>
 __global__ __launch_bounds__(256) void pos_logits_kernel(const float4* __restrict__ rois_q,
                                                          const float4* __restrict__ rois_k,
                                                          const float* __restrict__ wgt, const float* __restrict__ bg,
                                                          const float* __restrict__ dim_mat, float* __restrict__ out,
                                                          int Nq, int Nk, int ldp) {
+  __shared__ __attribute__((aligned(16))) float sw[64 * 16];
+  __shared__ float sdim[8];
+  for (int e = threadIdx.x; e < 1024; e += 256) sw[e] = wgt[e];
+  if (threadIdx.x < 8) sdim[threadIdx.x] = dim_mat[threadIdx.x];
+  __syncthreads();
   const int q = blockIdx.y;
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= Nk) return;
@@ -52,16 +74,26 @@ __global__ __launch_bounds__(256) void pos_logits_kernel(const float4* __restric
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const float pv = pm[d] * 100.0f;
+#pragma unroll 2
     for (int i = 0; i < 8; ++i) {
-      const float a = pv / dim_mat[i];
+      const float a = pv / sdim[i];
       float sn, cs;
-      sincosf(a, &sn, &cs);
-      const float* ws = wgt + (d * 16 + i) * 16;      // embedding index d*16 + i     (sin block)
-      const float* wc = wgt + (d * 16 + 8 + i) * 16;  // embedding index d*16 + 8 + i (cos block)
+      if (PRECISE) sincosf(a, &sn, &cs);
+      else sincos_reduced(a, &sn, &cs);
+      const float4* ws = reinterpret_cast<const float4*>(sw + (d * 16 + i) * 16);      // sin block: index d*16 + i
+      const float4* wc = reinterpret_cast<const float4*>(sw + (d * 16 + 8 + i) * 16);  // cos block: d*16 + 8 + i
 #pragma unroll
-      for (int h = 0; h < 16; ++h) acc[h] = fmaf(sn, ws[h], acc[h]);
-#pragma unroll
-      for (int h = 0; h < 16; ++h) acc[h] = fmaf(cs, wc[h], acc[h]);
+      for (int h4 = 0; h4 < 4; ++h4) {
+        const float4 a4 = ws[h4], c4 = wc[h4];
+        acc[4 * h4 + 0] = fmaf(sn, a4.x, acc[4 * h4 + 0]);
+        acc[4 * h4 + 1] = fmaf(sn, a4.y, acc[4 * h4 + 1]);
+        acc[4 * h4 + 2] = fmaf(sn, a4.z, acc[4 * h4 + 2]);
+        acc[4 * h4 + 3] = fmaf(sn, a4.w, acc[4 * h4 + 3]);
+        acc[4 * h4 + 0] = fmaf(cs, c4.x, acc[4 * h4 + 0]);
+        acc[4 * h4 + 1] = fmaf(cs, c4.y, acc[4 * h4 + 1]);
+        acc[4 * h4 + 2] = fmaf(cs, c4.z, acc[4 * h4 + 2]);
+        acc[4 * h4 + 3] = fmaf(cs, c4.w, acc[4 * h4 + 3]);
+      }
     }
   }
 #pragma unroll
@@ -76,7 +108,7 @@ template <> struct AttnCfg<bf16_t> {
   static constexpr int VROW = 72;    // Vs row stride (32 bf16 = 64 B + 8)
   static constexpr int NQF = 4;      // 16-B vectors per lane for a 64-wide head slice
   static constexpr int NPV = 2;      // P A-vectors per 32-key tile
-  static constexpr int NLD = 1;      // 16-B loads per thread per tile (K and V each)
+  static constexpr int NLD = 1;      // 16-B loads per thread per tile (K and V each), 256 threads
 };
 template <> struct AttnCfg<float> {
   static constexpr int KROW = 272;   // 256 B + 16
@@ -114,8 +146,11 @@ struct AttnParams {
   const void* resid; int ldr; // [Nq][ldr] residual (feats_cur) or null
   const float* bias_v;        // [G*64] or null
   void* out; int ldo;         // [Nq][ldo]
-  int Nq, Nk;
+  int Nq, Nk, G;
   float scale;
+  int nsplit, tiles_per_split;
+  float* part_o;              // [nsplit][Nq][G*64] un-normalised partial outputs (nsplit > 1)
+  float* part_ml;             // [nsplit][2][G][Nq]   running max / sum of each partial
 };
 
 template <typename T>
@@ -124,6 +159,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   constexpr int VE = 16 / (int)sizeof(T);
   constexpr int KV_PER_ROW = 64 * (int)sizeof(T) / 16;  // 16-B vectors per K row
   constexpr int VV_PER_ROW = 32 * (int)sizeof(T) / 16;  // 16-B vectors per V^T row (32 keys)
+  constexpr int NLD = C::NLD;
   __shared__ __attribute__((aligned(16))) unsigned char Ks[2][32 * C::KROW];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[2][64 * C::VROW];
   __shared__ __attribute__((aligned(16))) float sRow[4][32];
@@ -131,10 +167,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = lane >> 5, l31 = lane & 31;
   const int head = blockIdx.y;
+  const int split = blockIdx.z;
   const int qw0 = blockIdx.x * 128 + wave * 32;  // first query row of this wave
   const T* __restrict__ Qp = (const T*)p.Q;
-  const T* __restrict__ Kp = (const T*)p.K;
-  const T* __restrict__ Vp = (const T*)p.Vt;
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.K), 0, (int)((unsigned)p.Nk * (unsigned)p.ldk * (unsigned)sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.Vt), 0, (int)((unsigned)(p.G * 64) * (unsigned)p.ldv * (unsigned)sizeof(T)), 0x00020000);
 
   // ---- Q fragments (B operand of S^T = K Q^T): row q = qw0 + l31, vector v at bytes v*32 + h2*16
   const int q_ld = min(qw0 + l31, p.Nq - 1);
@@ -145,38 +184,35 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     for (int v = 0; v < C::NQF; ++v) qf[v] = *reinterpret_cast<const uint4*>(qrow + v * 32 + h2 * 16);
   }
 
-  // ---- cooperative tile loads
-  uint4 kreg[C::NLD], vreg[C::NLD];
-  auto load_tiles = [&](int k0) {
+  // ---- cooperative tile loads (global -> registers), two register sets = two tiles in flight
+  auto load_tiles = [&](int k0, uint4 (&kreg)[NLD], uint4 (&vreg)[NLD]) {
 #pragma unroll
-    for (int i = 0; i < C::NLD; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
+      // branch-free buffer loads: lanes past Nk use offset 0xFFFFFFFF, which the range check turns into zeros
       {  // K tile: 32 keys x 64 d
         const int row = idx / KV_PER_ROW, vec = idx - row * KV_PER_ROW;
         const int key = k0 + row;
-        if (key < p.Nk) kreg[i] = *reinterpret_cast<const uint4*>(Kp + (size_t)key * p.ldk + head * 64 + vec * VE);
-        else kreg[i] = make_uint4(0u, 0u, 0u, 0u);
+        const unsigned off = ((unsigned)key * (unsigned)p.ldk + (unsigned)(head * 64 + vec * VE)) * (unsigned)sizeof(T);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_k, key < p.Nk ? off : 0xFFFFFFFFu, 0, 0);
+        kreg[i] = make_uint4(v.x, v.y, v.z, v.w);
       }
       {  // V^T tile: 64 dv x 32 keys
         const int row = idx / VV_PER_ROW, vec = idx - row * VV_PER_ROW;
         const int key = k0 + vec * VE;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (key < p.Nk) {
-          v = *reinterpret_cast<const uint4*>(Vp + (size_t)(head * 64 + row) * p.ldv + key);
-          if (key + VE > p.Nk) {  // zero the tail keys (pad columns of Vt are not guaranteed finite)
-            T* e = reinterpret_cast<T*>(&v);
+        const unsigned off = ((unsigned)(head * 64 + row) * (unsigned)p.ldv + (unsigned)key) * (unsigned)sizeof(T);
+        const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs_v, key < p.Nk ? off : 0xFFFFFFFFu, 0, 0);
+        uint4 v = make_uint4(r.x, r.y, r.z, r.w);
+        T* e = reinterpret_cast<T*>(&v);   // zero the tail keys (pad columns of Vt are not guaranteed finite)
 #pragma unroll
-            for (int t = 0; t < VE; ++t)
-              if (key + t >= p.Nk) e[t] = (T)0;
-          }
-        }
+        for (int t = 0; t < VE; ++t) e[t] = (key + t < p.Nk) ? e[t] : (T)0;
         vreg[i] = v;
       }
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const uint4 (&kreg)[NLD], const uint4 (&vreg)[NLD]) {
 #pragma unroll
-    for (int i = 0; i < C::NLD; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
       {
         const int row = idx / KV_PER_ROW, vec = idx - row * KV_PER_ROW;
@@ -199,19 +235,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
-
   const float* pos_row = p.pos ? p.pos + ((size_t)head * p.Nq + q_ld) * p.ldp : nullptr;
-  const int ntiles = (p.Nk + 31) / 32;
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
 
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
-    const int k0 = kt * 32;
-    const bool more = (kt + 1) < ntiles;
-    if (more) load_tiles(k0 + 32);
-
+  auto compute = [&](int cur, int k0) {
     // ---- S^T[key][q] = sum_d K[key][d] * Q[q][d]
     f32x16_t st;
 #pragma unroll
@@ -265,43 +291,80 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     __builtin_amdgcn_wave_barrier();
 
     // ---- O[q][dv] += sum_key P[q][key] * V[key][dv]
-    {
-      const unsigned char* vb0 = &Vs[cur][l31 * C::VROW];
-      const unsigned char* vb1 = &Vs[cur][(32 + l31) * C::VROW];
+    const unsigned char* vb0 = &Vs[cur][l31 * C::VROW];
+    const unsigned char* vb1 = &Vs[cur][(32 + l31) * C::VROW];
 #pragma unroll
-      for (int u = 0; u < C::NPV; ++u) {
-        uint4 pa, v0, v1;
-        if (sizeof(T) == 2) {
-          pa.x = pack_bf16x2(s[8 * u + 0], s[8 * u + 1]);
-          pa.y = pack_bf16x2(s[8 * u + 2], s[8 * u + 3]);
-          pa.z = pack_bf16x2(s[8 * u + 4], s[8 * u + 5]);
-          pa.w = pack_bf16x2(s[8 * u + 6], s[8 * u + 7]);
-          const int off = (16 * u + 4 * h2) * 2;
-          const uint2 a0 = *reinterpret_cast<const uint2*>(vb0 + off);
-          const uint2 a1 = *reinterpret_cast<const uint2*>(vb0 + off + 16);
-          const uint2 b0 = *reinterpret_cast<const uint2*>(vb1 + off);
-          const uint2 b1 = *reinterpret_cast<const uint2*>(vb1 + off + 16);
-          v0 = make_uint4(a0.x, a0.y, a1.x, a1.y);
-          v1 = make_uint4(b0.x, b0.y, b1.x, b1.y);
-        } else {
-          pa.x = __float_as_uint(s[4 * u + 0]);
-          pa.y = __float_as_uint(s[4 * u + 1]);
-          pa.z = __float_as_uint(s[4 * u + 2]);
-          pa.w = __float_as_uint(s[4 * u + 3]);
-          const int off = (8 * u + 4 * h2) * 4;
-          v0 = *reinterpret_cast<const uint4*>(vb0 + off);
-          v1 = *reinterpret_cast<const uint4*>(vb1 + off);
-        }
-        Mma32<T>::run(o0, pa, v0);
-        Mma32<T>::run(o1, pa, v1);
+    for (int u = 0; u < C::NPV; ++u) {
+      uint4 pa, v0, v1;
+      if (sizeof(T) == 2) {
+        pa.x = pack_bf16x2(s[8 * u + 0], s[8 * u + 1]);
+        pa.y = pack_bf16x2(s[8 * u + 2], s[8 * u + 3]);
+        pa.z = pack_bf16x2(s[8 * u + 4], s[8 * u + 5]);
+        pa.w = pack_bf16x2(s[8 * u + 6], s[8 * u + 7]);
+        const int off = (16 * u + 4 * h2) * 2;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(vb0 + off);
+        const uint2 a1 = *reinterpret_cast<const uint2*>(vb0 + off + 16);
+        const uint2 b0 = *reinterpret_cast<const uint2*>(vb1 + off);
+        const uint2 b1 = *reinterpret_cast<const uint2*>(vb1 + off + 16);
+        v0 = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        v1 = make_uint4(b0.x, b0.y, b1.x, b1.y);
+      } else {
+        pa.x = __float_as_uint(s[4 * u + 0]);
+        pa.y = __float_as_uint(s[4 * u + 1]);
+        pa.z = __float_as_uint(s[4 * u + 2]);
+        pa.w = __float_as_uint(s[4 * u + 3]);
+        const int off = (8 * u + 4 * h2) * 4;
+        v0 = *reinterpret_cast<const uint4*>(vb0 + off);
+        v1 = *reinterpret_cast<const uint4*>(vb1 + off);
       }
+      Mma32<T>::run(o0, pa, v0);
+      Mma32<T>::run(o1, pa, v1);
     }
-    if (more) store_tiles(cur ^ 1);
+  };
+
+  // ---- this block's key-tile range; loads run two tiles ahead of the MFMAs
+  const int ntiles = (p.Nk + 31) / 32;
+  const int t0 = split * p.tiles_per_split;
+  const int n = min(ntiles, t0 + p.tiles_per_split) - t0;
+  uint4 ka[NLD], va[NLD], kb2[NLD], vb2[NLD];
+  // (unconditional steady-state body, see igemm.hip: tiles past this split's range are loaded but never used)
+  load_tiles(t0 * 32, ka, va);
+  store_tiles(0, ka, va);
+  load_tiles((t0 + 1) * 32, ka, va);
+  __syncthreads();
+  for (int i = 0; i + 1 < n; i += 2) {   // invariant: LDS buffer 0 holds tile t0+i, ka/va hold tile t0+i+1
+    load_tiles((t0 + i + 2) * 32, kb2, vb2);
+    compute(0, (t0 + i) * 32);
+    store_tiles(1, ka, va);
+    __syncthreads();
+    load_tiles((t0 + i + 3) * 32, ka, va);
+    compute(1, (t0 + i + 1) * 32);
+    store_tiles(0, kb2, vb2);
     __syncthreads();
   }
+  if (n & 1) compute(0, (t0 + n - 1) * 32);
 
-  // ---- normalise and write: out[q'][head*64 + dv] = resid + O/l + bias_v
   const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (p.nsplit > 1) {
+    // ---- partial result: un-normalised O, running max and sum (merged by attn_combine_kernel)
+    if (h2 == 0 && qw0 + l31 < p.Nq) {
+      float* ml = p.part_ml + (size_t)split * 2 * p.G * p.Nq;
+      ml[(size_t)head * p.Nq + qw0 + l31] = m_run;
+      ml[(size_t)(p.G + head) * p.Nq + qw0 + l31] = l_tot;
+    }
+    float* po = p.part_o + (size_t)split * p.Nq * p.G * 64;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int col = head * 64 + jj * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qw0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        if (q < p.Nq) po[(size_t)q * p.G * 64 + col] = (jj == 0 ? o0[r] : o1[r]);
+      }
+    }
+    return;
+  }
+  // ---- normalise and write: out[q'][head*64 + dv] = resid + O/l + bias_v
   if (h2 == 0) sRow[wave][l31] = 1.f / l_tot;
   __builtin_amdgcn_wave_barrier();
   const T* __restrict__ resid = (const T*)p.resid;
@@ -323,24 +386,74 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   }
 }
 
+// out[q][c] = resid + bias + (sum_s e^{m_s - M} O_s[q][c]) / (sum_s e^{m_s - M} l_s),  M = max_s m_s  (head = c / 64)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
+  const int D = p.G * 64;
+  const size_t total = (size_t)p.Nq * D;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(idx / D), c = (int)(idx - (size_t)q * D), head = c >> 6;
+    float M = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s)
+      M = fmaxf(M, p.part_ml[((size_t)s * 2 * p.G + head) * p.Nq + q]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+      const float* ml = p.part_ml + (size_t)s * 2 * p.G * p.Nq;
+      const float w = expf(ml[(size_t)head * p.Nq + q] - M);
+      den += w * ml[(size_t)(p.G + head) * p.Nq + q];
+      num += w * p.part_o[((size_t)s * p.Nq + q) * D + c];
+    }
+    float v = num / den + (p.bias_v ? p.bias_v[c] : 0.f);
+    if (p.resid) v += Elem<T>::ld((const T*)p.resid + (size_t)q * p.ldr + c);
+    Elem<T>::st((T*)p.out + (size_t)q * p.ldo + c, v);
+  }
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
 }  // namespace
 
 // w[h][q][k] = log(relu(Wg_h . pe(q,k) + bg_h) + 1e-6);  out [16][Nq][ldp] f32, ldp >= Nk
+// precise != 0: libm-accurate sincosf (parity mode); 0: Cody-Waite reduction + hardware sin/cos (~1e-6 abs).
 extern "C" int mega_position_logits(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
-                                    const float* dim_mat, float* out, int Nq, int Nk, int ldp, void* stream) {
+                                    const float* dim_mat, float* out, int Nq, int Nk, int ldp, int precise,
+                                    void* stream) {
   mega_clear_error();
   if (Nq == 0 || Nk == 0) return MEGA_OK;
   if (!rois_q || !rois_k || !wg_t || !bg || !dim_mat || !out || Nq < 0 || Nk < 0 || ldp < Nk) return MEGA_ERR_ARG;
-  hipLaunchKernelGGL(pos_logits_kernel, dim3(cdiv(Nk, 256), Nq), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)rois_q, (const float4*)rois_k, wg_t, bg, dim_mat, out, Nq, Nk, ldp);
+  dim3 grid(cdiv(Nk, 256), Nq);
+  if (precise)
+    hipLaunchKernelGGL((pos_logits_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
+                       (const float4*)rois_k, wg_t, bg, dim_mat, out, Nq, Nk, ldp);
+  else
+    hipLaunchKernelGGL((pos_logits_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
+                       (const float4*)rois_k, wg_t, bg, dim_mat, out, Nq, Nk, ldp);
   return mega_check_launch();
 }
 
-// Multi-head relation attention core (16 heads x 64).  See header comment for the formula.
+// Number of key-range splits the attention core uses for (Nq, Nk): enough blocks for ~3 per CU, >= 4 key tiles each.
+extern "C" int mega_relation_attention_splits(int Nq, int Nk, int groups) {
+  if (Nq <= 0 || Nk <= 0 || groups <= 0) return 1;
+  const int blocks = cdiv(Nq, 128) * groups;
+  const int ntiles = cdiv(Nk, 32);
+  int s = cdiv(768, blocks);
+  if (s > ntiles / 4) s = ntiles / 4;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" size_t mega_relation_attention_workspace_bytes(int Nq, int Nk, int groups) {
+  const int s = mega_relation_attention_splits(Nq, Nk, groups);
+  if (s <= 1) return 0;
+  return align_up((size_t)s * Nq * groups * 64 * sizeof(float), 256) +
+         align_up((size_t)s * 2 * groups * Nq * sizeof(float), 256);
+}
+
+// Multi-head relation attention core (groups heads x 64).  See header comment for the formula.
 extern "C" int mega_relation_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
                                        const float* pos, int ldp, const void* resid, int ldr, const float* bias_v,
                                        void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype,
-                                       void* stream) {
+                                       void* ws, size_t ws_bytes, void* stream) {
   mega_clear_error();
   if (Nq == 0) return MEGA_OK;
   if (!q || !k || !vt || !out || Nq < 0 || Nk <= 0 || groups <= 0) return MEGA_ERR_ARG;
@@ -349,13 +462,28 @@ extern "C" int mega_relation_attention(const void* q, int ldq, const void* k, in
   if (ldv < ((Nk + ve - 1) / ve) * ve) return MEGA_ERR_ARG;
   AttnParams p;
   p.Q = q; p.ldq = ldq; p.K = k; p.ldk = ldk; p.Vt = vt; p.ldv = ldv; p.pos = pos; p.ldp = ldp;
-  p.resid = resid; p.ldr = ldr; p.bias_v = bias_v; p.out = out; p.ldo = ldo; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
-  dim3 grid(cdiv(Nq, 128), groups);
-  if (dtype == MEGA_BF16)
-    hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else if (dtype == MEGA_F32)
-    hipLaunchKernelGGL((attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else
-    return MEGA_ERR_ARG;
+  p.resid = resid; p.ldr = ldr; p.bias_v = bias_v; p.out = out; p.ldo = ldo; p.Nq = Nq; p.Nk = Nk; p.G = groups;
+  p.scale = scale;
+  const int want = mega_relation_attention_splits(Nq, Nk, groups);
+  int nsplit = want;
+  if (nsplit > 1 && (!ws || ws_bytes < mega_relation_attention_workspace_bytes(Nq, Nk, groups))) nsplit = 1;
+  const int ntiles = cdiv(Nk, 32);
+  p.tiles_per_split = cdiv(ntiles, nsplit);
+  nsplit = cdiv(ntiles, p.tiles_per_split);   // no empty splits
+  p.nsplit = nsplit;
+  p.part_o = (float*)ws;
+  p.part_ml = nsplit > 1 ? (float*)((unsigned char*)ws + align_up((size_t)want * Nq * groups * 64 * sizeof(float), 256))
+                         : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(Nq, 128), groups, nsplit);
+  if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(256), 0, st, p);
+  else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_kernel<float>), grid, dim3(256), 0, st, p);
+  else return MEGA_ERR_ARG;
+  if (nsplit > 1) {
+    const size_t total = (size_t)Nq * groups * 64;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_combine_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_combine_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
+  }
   return mega_check_launch();
 }

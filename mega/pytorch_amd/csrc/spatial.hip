@@ -170,6 +170,76 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fe
   }
 }
 
+// Channel-vectorised NHWC -> bin-major variant (the hot-path layout): one work item = (bin, 16-byte channel
+// vector); a wave reads 64 consecutive 16-B vectors of one pixel = 1 KiB fully coalesced per neighbour.
+// Same arithmetic, same order of operations as roi_align_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __restrict__ feat,
+                                                                 const float* __restrict__ rois, T* __restrict__ out,
+                                                                 int K, int C, int H, int W, float spatial_scale,
+                                                                 int PH, int PW, int sampling_ratio) {
+  constexpr int VE = Elem<T>::VE;
+  const int CV = C / VE;
+  const long long total = (long long)K * PH * PW * CV;
+  for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+       item += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(item % CV);
+    const int bin = (int)(item / CV);
+    const int pw = bin % PW;
+    const int ph = (bin / PW) % PH;
+    const int k = bin / (PW * PH);
+    const float* roi = rois + (size_t)k * 5;
+    const int b = (int)roi[0];
+    const float roi_start_w = roi[1] * spatial_scale;
+    const float roi_start_h = roi[2] * spatial_scale;
+    const float roi_end_w = roi[3] * spatial_scale;
+    const float roi_end_h = roi[4] * spatial_scale;
+    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.f);
+    const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.f);
+    const float bin_size_h = roi_height / (float)PH;
+    const float bin_size_w = roi_width / (float)PW;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)PH);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)PW);
+    const float count = (float)(grid_h * grid_w);
+    const T* base = feat + (size_t)b * H * W * C + (size_t)cv * VE;
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    for (int iy = 0; iy < grid_h; ++iy) {
+      const float y0 = roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)grid_h;
+      for (int ix = 0; ix < grid_w; ++ix) {
+        const float x0 = roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)grid_w;
+        float y = y0, x = x0;
+        if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+        if (y <= 0.f) y = 0.f;
+        if (x <= 0.f) x = 0.f;
+        int y_low = (int)y, x_low = (int)x, y_high, x_high;
+        if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+        if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+        const float ly = y - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const uint4 r1 = *reinterpret_cast<const uint4*>(base + ((size_t)y_low * W + x_low) * C);
+        const uint4 r2 = *reinterpret_cast<const uint4*>(base + ((size_t)y_low * W + x_high) * C);
+        const uint4 r3 = *reinterpret_cast<const uint4*>(base + ((size_t)y_high * W + x_low) * C);
+        const uint4 r4 = *reinterpret_cast<const uint4*>(base + ((size_t)y_high * W + x_high) * C);
+        const T* e1 = reinterpret_cast<const T*>(&r1);
+        const T* e2 = reinterpret_cast<const T*>(&r2);
+        const T* e3 = reinterpret_cast<const T*>(&r3);
+        const T* e4 = reinterpret_cast<const T*>(&r4);
+#pragma unroll
+        for (int e = 0; e < VE; ++e)
+          acc[e] += (w1 * Elem<T>::ld(e1 + e) + w2 * Elem<T>::ld(e2 + e) + w3 * Elem<T>::ld(e3 + e) +
+                     w4 * Elem<T>::ld(e4 + e));
+      }
+    }
+    uint4 o;
+    T* oe = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] / count);
+    *reinterpret_cast<uint4*>(out + (size_t)bin * C + (size_t)cv * VE) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, const float* scale, const float* bias,
@@ -221,6 +291,20 @@ extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out
   if (!feat || !rois || !out || K < 0 || C <= 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0)
     return MEGA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (in_nhwc && out_nhwc && dtype == out_dtype && C % (dtype == MEGA_BF16 ? 8 : 4) == 0) {
+    const long long total = (long long)K * pooled_h * pooled_w * (C / (dtype == MEGA_BF16 ? 8 : 4));
+    const long long nb = (total + 255) / 256;
+    dim3 vgrid((unsigned)(nb > 1048576 ? 1048576 : nb));
+    if (dtype == MEGA_BF16)
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<bf16_t>), vgrid, dim3(256), 0, st, (const bf16_t*)feat, rois,
+                         (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+    else if (dtype == MEGA_F32)
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float>), vgrid, dim3(256), 0, st, (const float*)feat, rois,
+                         (float*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+    else
+      return MEGA_ERR_ARG;
+    return mega_check_launch();
+  }
   dim3 grid((unsigned)(K * pooled_h * pooled_w));
   const int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
   if (dtype == MEGA_BF16 && out_dtype == MEGA_BF16)

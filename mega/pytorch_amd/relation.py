@@ -49,5 +49,5 @@ def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=Tru
     vt = ops.linear_transposed(w.wv, ref, ldv)
     pos = None
     if w.with_pos:
-        pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat)
+        pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=(x.dtype == torch.float32))
     return ops.relation_attention(q, k, vt, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)

@@ -34,6 +34,9 @@ CONV_CASES = [
     (1, 38, 63, 256, 60, 1, 1, 0, 1, False, False),      # RPN-style narrow output, N tail
     (300, 1, 1, 1024, 155, 1, 1, 0, 1, False, False),    # linear, M and N tails
     (1, 38, 63, 128, 512, 3, 1, 1, 1, True, True),
+    (2, 150, 250, 64, 64, 1, 1, 0, 1, True, False),      # one K-tile (bf16), many blocks: LDS re-use races show up
+    (2, 150, 250, 64, 64, 3, 1, 1, 1, True, False),      # odd K-tile count (9)
+    (2, 75, 125, 64, 256, 1, 1, 0, 1, False, True),
 ]
 
 
@@ -264,6 +267,10 @@ def test_position_logits(dev):
     assert (got.exp() - ref.exp()).abs().max() < 2e-5
     big = ref > -8
     assert (got[big] - ref[big]).abs().max() < 5e-2
+    # fast mode (bf16 path): Cody-Waite reduction + hardware sin/cos
+    fast = ops.position_logits(bq.to(dev), bk.to(dev), w.view(16, 64).t().contiguous().to(dev), bias.to(dev),
+                               mo.dim_mat_values().to(dev), precise=False).cpu()[:, :, :bk.shape[0]]
+    assert (fast.exp() - ref.exp()).abs().max() < 1e-4
 
 
 def test_preprocess(dev):
