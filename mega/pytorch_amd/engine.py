@@ -122,6 +122,7 @@ class ClipEngine(object):
             flat = [j for js in per_step for j in js]
             recs = self.compute_records(clip, flat)
             o = 0
+            pending = []
             for i, js in zip(range(idx, hi), per_step):
                 r = recs[o:o + len(js)]
                 o += len(js)
@@ -133,9 +134,14 @@ class ClipEngine(object):
                         m.records.append(loc[0])
                     for x in loc[1:]:
                         m.records.append(x)
-                    det = m.step(None, glob, (W, H))
+                    pending.append((i, m.step(None, glob, (W, H), defer=True)))
                 else:
-                    det = m.step(loc[0], glob, (W, H))
+                    pending.append((i, m.step(loc[0], glob, (W, H), defer=True)))
+            # one host sync per batch of steps: read all detection counts, then cut the padded outputs
+            counts = torch.cat([pd[3] for _, pd in pending]).tolist()
+            pp = m.roi_heads.box.post_processor
+            for (i, pd), n in zip(pending, counts):
+                det = pp.materialize(pd, int(n), (W, H))
                 out.append(det)
                 if on_step is not None:
                     on_step(i, det)

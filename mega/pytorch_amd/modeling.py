@@ -574,19 +574,26 @@ class PostProcessor(nn.Module):
         self.weights = tuple(rh.BBOX_REG_WEIGHTS)
         self.strict_gt = bool(getattr(cfg, "NMS_STRICT_GT", True))
 
-    def forward(self, x, boxes):
+    def run(self, x, bl):
+        """Sync-free form: padded outputs + device-side count (ob [cap,4], os [cap], ol [cap] i64, oc [1] i32)."""
         class_logits, box_regression = x
-        assert len(boxes) == 1, "MEGA test path: one key frame per call (data/collate_batch.py:22)"
-        bl = boxes[0]
         im_w, im_h = bl.size
-        ob, os_, ol, oc = ops.postprocess(class_logits.float().contiguous(), box_regression.float().contiguous(),
-                                          bl.bbox.float().contiguous(), None, self.weights, im_w, im_h,
-                                          self.score_thresh, self.nms, self.detections_per_img, self.strict_gt)
-        n = int(oc.item())
-        res = BoxList(ob[:n], bl.size, "xyxy")
+        return ops.postprocess(class_logits.float().contiguous(), box_regression.float().contiguous(),
+                               bl.bbox.float().contiguous(), None, self.weights, im_w, im_h,
+                               self.score_thresh, self.nms, self.detections_per_img, self.strict_gt)
+
+    @staticmethod
+    def materialize(padded, n, size):
+        ob, os_, ol, _ = padded
+        res = BoxList(ob[:n], size, "xyxy")
         res.add_field("scores", os_[:n])
         res.add_field("labels", ol[:n])
-        return [res]
+        return res
+
+    def forward(self, x, boxes):
+        assert len(boxes) == 1, "MEGA test path: one key frame per call (data/collate_batch.py:22)"
+        padded = self.run(x, boxes[0])
+        return [self.materialize(padded, int(padded[3].item()), boxes[0].size)]   # the one host sync
 
 
 class ROIAttentionBoxHead(nn.Module):
@@ -710,10 +717,11 @@ class GeneralizedRCNNMEGA(nn.Module):
         return rois, rois_dis, feats, cache[1]
 
     @torch.no_grad()
-    def step(self, new_local=None, new_globals=(), im_size=None):
+    def step(self, new_local=None, new_globals=(), im_size=None, defer=False):
         """Advance by one key frame given already-computed frame records: new_local enters the window (None at
         the end-clamped tail is NOT allowed: the reference re-processes the last frame, so pass its record
-        again), new_globals go to the global pool.  Returns a BoxList on the device."""
+        again), new_globals go to the global pool.  Returns a BoxList on the device; with defer=True returns the
+        padded outputs + device-side count instead (no host sync; see PostProcessor.materialize)."""
         fe = self.roi_heads.box.feature_extractor
         if new_local is not None:
             self.records.append(new_local)
@@ -725,7 +733,10 @@ class GeneralizedRCNNMEGA(nn.Module):
         logits, deltas = self.roi_heads.box.predictor(x)
         kb = BoxList(key["boxes"], im_size, "xyxy")
         kb.add_field("objectness", key["scores"])
-        return self.roi_heads.box.post_processor((logits, deltas), [kb])[0]
+        pp = self.roi_heads.box.post_processor
+        if defer:
+            return pp.run((logits, deltas), kb)
+        return pp((logits, deltas), [kb])[0]
 
     def forward(self, images, targets=None):
         """Reference call convention (generalized_rcnn_mega.py:48-78, data/datasets/vid_mega.py:95-142):
