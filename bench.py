@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run frame stage and aggregation on one stream")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     return ap.parse_args()
 
@@ -144,7 +145,7 @@ def main():
     T = 1 + Wm + K + prof_steps + 13
     clip = make_clip(T, args.height, args.width, device)
     gfor = eng.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
-    runner = eng.ClipEngine(model, steps_per_batch=args.steps_per_batch, dist_group=group)
+    runner = eng.ClipEngine(model, steps_per_batch=args.steps_per_batch, dist_group=group, overlap=not args.no_overlap)
 
     def barrier():
         torch.cuda.synchronize()
@@ -176,6 +177,7 @@ def main():
     if prof_steps:
         p = ops.Profiler()
         ops.set_profiler(p)
+        runner.overlap = False     # per-kernel event pairs are only meaningful without cross-stream concurrency
         runner.run(clip, T, gfor, first=Wm + K, last=Wm + K + prof_steps)
         summ = p.summary()
         ops.set_profiler(None)

@@ -32,10 +32,11 @@ def global_schedule(seg_len, global_size, seed=0):
 
 
 class ClipEngine(object):
-    def __init__(self, model, steps_per_batch=8, dist_group=None):
+    def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True):
         """steps_per_batch: key-frame steps whose frame jobs are computed in one frame-stage batch
         (steady state: 2 frames per step).  dist_group: torch.distributed group to shard the frame stage over
-        (None = single process)."""
+        (None = single process).  overlap: run the frame stage of the next batch and the aggregation of the
+        current one on two HIP streams (see run())."""
         self.model = model
         self.steps_per_batch = steps_per_batch
         self.group = dist_group
@@ -47,6 +48,8 @@ class ClipEngine(object):
             self.dist, self.rank, self.world = None, 0, 1
         self.mean = tuple(model.cfg.INPUT.PIXEL_MEAN)
         self.to_bgr = bool(model.cfg.INPUT.TO_BGR255)
+        self.overlap = overlap
+        self._streams = None
 
     # ------------------------------------------------------------------ schedule
     def jobs_for_step(self, idx, T, gfor):
@@ -114,16 +117,47 @@ class ClipEngine(object):
             gfor = global_schedule(T, m.cfg.MODEL.VID.MEGA.GLOBAL.SIZE)
         last = T if last is None else last
         H, W = (clip.shape[1], clip.shape[2]) if clip.dtype == torch.uint8 else (clip.shape[2], clip.shape[3])
-        out = []
+        # ---- software pipeline over batches of steps, on two HIP streams:
+        #        frame stage of batch b+1 (big MFMA kernels)  ||  aggregation steps of batch b (many small kernels)
+        #      The aggregation of batch b only needs the frame records of batch b (an event on the frame stream);
+        #      its small kernels fill the CUs the frame-stage tails leave idle.  Host order per iteration: enqueue
+        #      aggregation(b) [async] -> enqueue frame stage(b+1) [blocks on the proposal counts] -> read the
+        #      detection counts of batch b.  Results are identical to the sequential order.
+        use_streams = clip.is_cuda and self.overlap
+        if use_streams:
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(device=clip.device), torch.cuda.Stream(device=clip.device))
+            sF, sB = self._streams
+            cur = torch.cuda.current_stream(clip.device)
+            sF.wait_stream(cur)
+            sB.wait_stream(cur)
+        batches = []
         idx = first
         while idx < last:
             hi = min(last, idx + (1 if idx == 0 else self.steps_per_batch))
-            per_step = [self.jobs_for_step(i, T, gfor) for i in range(idx, hi)]
+            batches.append((idx, hi))
+            idx = hi
+        out = []
+        pp = m.roi_heads.box.post_processor
+
+        def frame_stage(b):
+            per_step = [self.jobs_for_step(i, T, gfor) for i in range(b[0], b[1])]
             flat = [j for js in per_step for j in js]
-            recs = self.compute_records(clip, flat)
-            o = 0
-            pending = []
-            for i, js in zip(range(idx, hi), per_step):
+            if use_streams:
+                with torch.cuda.stream(sF):
+                    recs = self.compute_records(clip, flat)
+                    ev = torch.cuda.Event()
+                    ev.record(sF)
+                for r in recs:                       # produced on sF, consumed on sB
+                    for t in r.values():
+                        t.record_stream(sB)
+            else:
+                recs, ev = self.compute_records(clip, flat), None
+            return per_step, recs, ev
+
+        def aggregate(b, per_step, recs, ev):
+            pending, o = [], 0
+            for i, js in zip(range(b[0], b[1]), per_step):
                 r = recs[o:o + len(js)]
                 o += len(js)
                 loc = [x for x, j in zip(r, js) if j[2] == "l"]
@@ -137,13 +171,32 @@ class ClipEngine(object):
                     pending.append((i, m.step(None, glob, (W, H), defer=True)))
                 else:
                     pending.append((i, m.step(loc[0], glob, (W, H), defer=True)))
+            return pending
+
+        def finish(pending):
             # one host sync per batch of steps: read all detection counts, then cut the padded outputs
             counts = torch.cat([pd[3] for _, pd in pending]).tolist()
-            pp = m.roi_heads.box.post_processor
             for (i, pd), n in zip(pending, counts):
                 det = pp.materialize(pd, int(n), (W, H))
                 out.append(det)
                 if on_step is not None:
                     on_step(i, det)
-            idx = hi
+
+        staged = frame_stage(batches[0]) if batches else None
+        for bi, b in enumerate(batches):
+            per_step, recs, ev = staged
+            if use_streams:
+                with torch.cuda.stream(sB):
+                    sB.wait_event(ev)
+                    pending = aggregate(b, per_step, recs, ev)
+                staged = frame_stage(batches[bi + 1]) if bi + 1 < len(batches) else None
+                with torch.cuda.stream(sB):
+                    finish(pending)
+            else:
+                pending = aggregate(b, per_step, recs, ev)
+                staged = frame_stage(batches[bi + 1]) if bi + 1 < len(batches) else None
+                finish(pending)
+        if use_streams:
+            cur.wait_stream(sF)
+            cur.wait_stream(sB)
         return out
