@@ -11,12 +11,16 @@ Results are identical to calling ``model(images)`` frame by frame: every kernel 
 Frame schedule = the reference's test-time feed (mega_core/data/datasets/vid_mega.py:95-142):
 key frame 0 consumes local frames 0..12 and GLOBAL.SIZE shuffled global frames, key frame t > 0 consumes
 local frame min(T-1, t+12) and one more global frame.
+
+Pipeline (run()): two HIP streams.  The frame stage of batch b+1 (big MFMA kernels, enqueued with NO host
+sync) runs concurrently with the aggregation steps of batch b (many small kernels that fill the CUs the
+frame-stage tails leave idle).  The host only ever waits for work that was enqueued a full batch earlier
+(proposal counts of batch b, detection counts of batch b-1).
 """
 import numpy as np
 import torch
 
 from . import ops
-from .structures import BoxList
 
 
 def global_schedule(seg_len, global_size, seed=0):
@@ -31,12 +35,28 @@ def global_schedule(seg_len, global_size, seed=0):
     return for_frame
 
 
+class _On(object):
+    """`with _On(stream)`: run the block on that HIP stream; `_On(None)` is a no-op (CPU / single-stream mode)."""
+
+    def __init__(self, s):
+        self.s = s
+        self.c = None
+
+    def __enter__(self):
+        if self.s is not None:
+            self.c = torch.cuda.stream(self.s)
+            self.c.__enter__()
+
+    def __exit__(self, *a):
+        if self.c is not None:
+            self.c.__exit__(*a)
+
+
 class ClipEngine(object):
     def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True):
         """steps_per_batch: key-frame steps whose frame jobs are computed in one frame-stage batch
         (steady state: 2 frames per step).  dist_group: torch.distributed group to shard the frame stage over
-        (None = single process).  overlap: run the frame stage of the next batch and the aggregation of the
-        current one on two HIP streams (see run())."""
+        (None = single process).  overlap: use the two-stream pipeline (see module docstring)."""
         self.model = model
         self.steps_per_batch = steps_per_batch
         self.group = dist_group
@@ -77,34 +97,46 @@ class ClipEngine(object):
             return ops.preprocess_frames(sel.contiguous(), self.mean, self.to_bgr)
         return sel.contiguous()
 
-    def compute_records(self, clip, jobs):
-        """Run the frame stage for jobs [(frame_id, want, role)] -> list of records (same order)."""
+    def records_async(self, clip, jobs):
+        """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
+        records_resolve()."""
         m = self.model
         if self.world == 1:
-            return m.frame_stage(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs])
-        # ---- sharded: contiguous slices of the (padded) job list per rank, fixed-size records, one all-gather
+            return {"st": m.frame_stage_async(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs])}
+        # ---- sharded: contiguous slices of the (padded) job list per rank, fixed-size records, one all-gather each
         n = len(jobs)
         per = (n + self.world - 1) // self.world
         padded = jobs + [jobs[-1]] * (per * self.world - n)
         mine = padded[self.rank * per:(self.rank + 1) * per]
-        recs = m.frame_stage(self._frames(clip, [j[0] for j in mine]), [j[1] for j in mine])
+        st = m.frame_stage_async(self._frames(clip, [j[0] for j in mine]), [j[1] for j in mine])
         K, dev = m.key_num, clip.device
-        fdt = recs[0]["feats"].dtype
-        boxes = torch.zeros((per, K, 4), dtype=torch.float32, device=dev)
-        scores = torch.zeros((per, K), dtype=torch.float32, device=dev)
-        feats = torch.zeros((per, K, recs[0]["feats"].shape[1]), dtype=fdt, device=dev)
-        cnt = torch.zeros((per,), dtype=torch.int32, device=dev)
-        for i, r in enumerate(recs):
-            k = r["boxes"].shape[0]
-            boxes[i, :k], scores[i, :k], feats[i, :k], cnt[i] = r["boxes"], r["scores"], r["feats"], k
+        feats = torch.zeros((per, K, st["feats"].shape[1]), dtype=st["feats"].dtype, device=dev)
+        o = 0
+        for i, w in enumerate(st["want"]):
+            feats[i, :w] = st["feats"][o:o + w]
+            o += w
         g = {}
-        for name, t in (("boxes", boxes), ("scores", scores), ("feats", feats), ("cnt", cnt)):
+        for name, t in (("props", st["props"]), ("scores", st["scores"]), ("feats", feats), ("cnt", st["cnt"])):
             out = torch.empty((self.world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
             self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
             g[name] = out
+        g["want"] = [j[1] for j in jobs]
+        return {"gathered": g}
+
+    def records_resolve(self, h):
+        """handle -> list of frame records (one host read of the proposal counts)."""
+        if "st" in h:
+            return self.model.frame_stage_resolve(h["st"])
+        g = h["gathered"]
         counts = g["cnt"].tolist()
-        return [{"boxes": g["boxes"][i, :counts[i]], "scores": g["scores"][i, :counts[i]],
-                 "feats": g["feats"][i, :counts[i]]} for i in range(n)]
+        out = []
+        for i, w in enumerate(g["want"]):
+            n = min(int(counts[i]), w)
+            out.append({"boxes": g["props"][i, :n], "scores": g["scores"][i, :n], "feats": g["feats"][i, :n]})
+        return out
+
+    def compute_records(self, clip, jobs):
+        return self.records_resolve(self.records_async(clip, jobs))
 
     # ------------------------------------------------------------------ driver
     @torch.no_grad()
@@ -117,13 +149,8 @@ class ClipEngine(object):
             gfor = global_schedule(T, m.cfg.MODEL.VID.MEGA.GLOBAL.SIZE)
         last = T if last is None else last
         H, W = (clip.shape[1], clip.shape[2]) if clip.dtype == torch.uint8 else (clip.shape[2], clip.shape[3])
-        # ---- software pipeline over batches of steps, on two HIP streams:
-        #        frame stage of batch b+1 (big MFMA kernels)  ||  aggregation steps of batch b (many small kernels)
-        #      The aggregation of batch b only needs the frame records of batch b (an event on the frame stream);
-        #      its small kernels fill the CUs the frame-stage tails leave idle.  Host order per iteration: enqueue
-        #      aggregation(b) [async] -> enqueue frame stage(b+1) [blocks on the proposal counts] -> read the
-        #      detection counts of batch b.  Results are identical to the sequential order.
         use_streams = clip.is_cuda and self.overlap
+        sF = sB = cur = None
         if use_streams:
             if self._streams is None:
                 self._streams = (torch.cuda.Stream(device=clip.device), torch.cuda.Stream(device=clip.device))
@@ -143,39 +170,45 @@ class ClipEngine(object):
         def frame_stage(b):
             per_step = [self.jobs_for_step(i, T, gfor) for i in range(b[0], b[1])]
             flat = [j for js in per_step for j in js]
-            if use_streams:
-                with torch.cuda.stream(sF):
-                    recs = self.compute_records(clip, flat)
+            with _On(sF):
+                h = self.records_async(clip, flat)
+                ev = None
+                if use_streams:
                     ev = torch.cuda.Event()
                     ev.record(sF)
-                for r in recs:                       # produced on sF, consumed on sB
-                    for t in r.values():
-                        t.record_stream(sB)
-            else:
-                recs, ev = self.compute_records(clip, flat), None
-            return per_step, recs, ev
+            return per_step, h, ev
 
-        def aggregate(b, per_step, recs, ev):
-            pending, o = [], 0
-            for i, js in zip(range(b[0], b[1]), per_step):
-                r = recs[o:o + len(js)]
-                o += len(js)
-                loc = [x for x, j in zip(r, js) if j[2] == "l"]
-                glob = [x for x, j in zip(r, js) if j[2] == "g"]
-                if i == 0:
-                    m._reset(T)
-                    for _ in range(m.key_frame_location + 1):
-                        m.records.append(loc[0])
-                    for x in loc[1:]:
-                        m.records.append(x)
-                    pending.append((i, m.step(None, glob, (W, H), defer=True)))
-                else:
-                    pending.append((i, m.step(loc[0], glob, (W, H), defer=True)))
+        def aggregate(b, per_step, h, ev):
+            with _On(sB):
+                if use_streams:
+                    sB.wait_event(ev)
+                    ev.synchronize()                  # the proposal counts are read on the host right below
+                recs = self.records_resolve(h)        # counts of a batch that was enqueued one iteration ago
+                if use_streams:
+                    for r in recs:                    # produced on sF, consumed on sB
+                        for t in r.values():
+                            t.record_stream(sB)
+                pending, o = [], 0
+                for i, js in zip(range(b[0], b[1]), per_step):
+                    r = recs[o:o + len(js)]
+                    o += len(js)
+                    loc = [x for x, j in zip(r, js) if j[2] == "l"]
+                    glob = [x for x, j in zip(r, js) if j[2] == "g"]
+                    if i == 0:
+                        m._reset(T)
+                        for _ in range(m.key_frame_location + 1):
+                            m.records.append(loc[0])
+                        for x in loc[1:]:
+                            m.records.append(x)
+                        pending.append((i, m.step(None, glob, (W, H), defer=True)))
+                    else:
+                        pending.append((i, m.step(loc[0], glob, (W, H), defer=True)))
             return pending
 
         def finish(pending):
-            # one host sync per batch of steps: read all detection counts, then cut the padded outputs
-            counts = torch.cat([pd[3] for _, pd in pending]).tolist()
+            # one host read per batch of steps: all detection counts, then cut the padded outputs
+            with _On(sB):
+                counts = torch.cat([pd[3] for _, pd in pending]).tolist()
             for (i, pd), n in zip(pending, counts):
                 det = pp.materialize(pd, int(n), (W, H))
                 out.append(det)
@@ -183,19 +216,15 @@ class ClipEngine(object):
                     on_step(i, det)
 
         staged = frame_stage(batches[0]) if batches else None
+        prev_pending = None
         for bi, b in enumerate(batches):
-            per_step, recs, ev = staged
-            if use_streams:
-                with torch.cuda.stream(sB):
-                    sB.wait_event(ev)
-                    pending = aggregate(b, per_step, recs, ev)
-                staged = frame_stage(batches[bi + 1]) if bi + 1 < len(batches) else None
-                with torch.cuda.stream(sB):
-                    finish(pending)
-            else:
-                pending = aggregate(b, per_step, recs, ev)
-                staged = frame_stage(batches[bi + 1]) if bi + 1 < len(batches) else None
-                finish(pending)
+            nxt = frame_stage(batches[bi + 1]) if bi + 1 < len(batches) else None   # F(b+1): async, enqueued first
+            pending = aggregate(b, *staged)                                        # B(b): runs beside F(b+1)
+            if prev_pending is not None:
+                finish(prev_pending)                                               # results of B(b-1)
+            prev_pending, staged = pending, nxt
+        if prev_pending is not None:
+            finish(prev_pending)
         if use_streams:
             cur.wait_stream(sF)
             cur.wait_stream(sB)

@@ -670,23 +670,46 @@ class GeneralizedRCNNMEGA(nn.Module):
 
     # ------------------------------------------------------------------ frame stage (batched, frame-independent)
     @torch.no_grad()
-    def frame_stage(self, imgs, want):
-        """imgs [B,3,H,W] f32 preprocessed frames; want[b] = proposals needed from frame b (key_num for local
-        frames, base_num for global-pool frames).  Returns a list of records
-        {"boxes": [n,4] f32, "scores": [n], "feats": [n,1024]} (n <= want[b]).  One host sync (the counts)."""
+    def frame_stage_async(self, imgs, want):
+        """Enqueue the whole frame stage for imgs [B,3,H,W] (f32, preprocessed) WITHOUT any host sync.
+        want[b] = proposal rows computed for frame b (key_num for local frames, base_num for global-pool frames).
+        Shapes are static: frame b always gets want[b] ROI rows; rows past its (device-side) proposal count are
+        all-zero boxes whose features are simply never used.  Returns a handle for frame_stage_resolve()."""
         fe = self.roi_heads.box.feature_extractor
         B, _, H, W = imgs.shape
         c4 = _nhwc(self.backbone(imgs)[0])
-        props, scores, cnt = self.rpn.propose(c4, W, H, "key")
-        counts = [min(int(n), int(w)) for n, w in zip(cnt.tolist(), want)]
-        rois5 = torch.cat([torch.cat([torch.full((n, 1), float(b), dtype=torch.float32, device=imgs.device),
-                                      props[b, :n]], dim=1) for b, n in enumerate(counts)], dim=0).contiguous()
+        props, scores, cnt = self.rpn.propose(c4, W, H, "key")           # [B,K,4], [B,K], [B] (device)
+        want = tuple(int(w) for w in want)
+        key = (want, str(imgs.device))
+        cache = getattr(self, "_roi_index_cache", None)
+        if cache is None or cache[0] != key:
+            K = props.shape[1]
+            flat = torch.cat([b * K + torch.arange(w) for b, w in enumerate(want)])
+            ids = torch.cat([torch.full((w,), float(b)) for b, w in enumerate(want)]).view(-1, 1)
+            cache = (key, flat.to(imgs.device), ids.to(imgs.device))
+            self._roi_index_cache = cache
+        boxes = props.view(-1, 4).index_select(0, cache[1])
+        rois5 = torch.cat([cache[2], boxes], dim=1)
         feats = fe.box_features(c4, rois5)
+        return {"props": props, "scores": scores, "cnt": cnt, "feats": feats, "want": want}
+
+    @staticmethod
+    def frame_stage_resolve(st, counts=None):
+        """Handle -> list of records {"boxes": [n,4], "scores": [n], "feats": [n,1024]}, n = min(count, want).
+        counts: host list of the per-frame proposal counts (default: read st["cnt"], one host sync)."""
+        if counts is None:
+            counts = st["cnt"].tolist()
         out, o = [], 0
-        for b, n in enumerate(counts):
-            out.append({"boxes": props[b, :n], "scores": scores[b, :n], "feats": feats[o:o + n]})
-            o += n
+        for b, w in enumerate(st["want"]):
+            n = min(int(counts[b]), w)
+            out.append({"boxes": st["props"][b, :n], "scores": st["scores"][b, :n], "feats": st["feats"][o:o + n]})
+            o += w
         return out
+
+    @torch.no_grad()
+    def frame_stage(self, imgs, want):
+        """frame_stage_async + frame_stage_resolve (one host sync: the proposal counts)."""
+        return self.frame_stage_resolve(self.frame_stage_async(imgs, want))
 
     # ------------------------------------------------------------------ state machine
     def _reset(self, seg_len):
