@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run frame stage and aggregation on one stream")
+    ap.add_argument("--no-graphs", action="store_true", help="launch the frame stage kernel by kernel (no hipGraph)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     return ap.parse_args()
 
@@ -145,7 +146,8 @@ def main():
     T = 1 + Wm + K + prof_steps + 13
     clip = make_clip(T, args.height, args.width, device)
     gfor = eng.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
-    runner = eng.ClipEngine(model, steps_per_batch=args.steps_per_batch, dist_group=group, overlap=not args.no_overlap)
+    runner = eng.ClipEngine(model, steps_per_batch=args.steps_per_batch, dist_group=group, overlap=not args.no_overlap,
+                            graphs=not args.no_graphs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -161,6 +163,8 @@ def main():
     runner.run(clip, T, gfor, first=1, last=Wm)
     barrier()
     log("warm-up done; timing %d steps" % K)
+    for k in runner.host_times:
+        runner.host_times[k] = 0
     t0 = time.perf_counter()
     dets = runner.run(clip, T, gfor, first=Wm, last=Wm + K)
     barrier()
@@ -171,12 +175,16 @@ def main():
         elapsed = float(t.item())
     fps = K / elapsed
     log("timed region: %.3fs (%.2f frames/s)" % (elapsed, fps))
+    ht = dict(runner.host_times)
+    log("host ms/step: frame-stage enqueue %.3f, aggregation enqueue %.3f, waiting for results %.3f" % tuple(
+        1e3 * ht[k] / max(ht["steps"], 1) for k in ("frame_enqueue", "aggregate_enqueue", "finish_wait")))
 
     roofline = None
     fam = {}
     if prof_steps:
         p = ops.Profiler()
         ops.set_profiler(p)
+        runner.use_graphs = False
         runner.overlap = False     # per-kernel event pairs are only meaningful without cross-stream concurrency
         runner.run(clip, T, gfor, first=Wm + K, last=Wm + K + prof_steps)
         summ = p.summary()

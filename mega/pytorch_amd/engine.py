@@ -53,10 +53,11 @@ class _On(object):
 
 
 class ClipEngine(object):
-    def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True):
+    def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True, graphs=True):
         """steps_per_batch: key-frame steps whose frame jobs are computed in one frame-stage batch
         (steady state: 2 frames per step).  dist_group: torch.distributed group to shard the frame stage over
-        (None = single process).  overlap: use the two-stream pipeline (see module docstring)."""
+        (None = single process).  overlap: use the two-stream pipeline (see module docstring).
+        graphs: replay the frame stage from a hipGraph once a batch shape repeats."""
         self.model = model
         self.steps_per_batch = steps_per_batch
         self.group = dist_group
@@ -69,7 +70,11 @@ class ClipEngine(object):
         self.mean = tuple(model.cfg.INPUT.PIXEL_MEAN)
         self.to_bgr = bool(model.cfg.INPUT.TO_BGR255)
         self.overlap = overlap
+        self.use_graphs = graphs
+        self._fgraphs = {}
         self._streams = None
+        # host-side seconds spent enqueuing / waiting, accumulated over run() calls (diagnostics for bench.py)
+        self.host_times = {"frame_enqueue": 0.0, "aggregate_enqueue": 0.0, "finish_wait": 0.0, "steps": 0}
 
     # ------------------------------------------------------------------ schedule
     def jobs_for_step(self, idx, T, gfor):
@@ -91,24 +96,54 @@ class ClipEngine(object):
     # ------------------------------------------------------------------ frame stage (optionally sharded)
     def _frames(self, clip, ids):
         """clip: uint8 [T,H,W,3] (device) -> preprocessed f32 [n,3,H,W]; or already-preprocessed f32 [T,3,H,W]."""
-        idx = torch.as_tensor(ids, device=clip.device)
+        if clip.is_cuda:   # pinned + non_blocking: the host must not wait for the work already queued on the stream
+            idx = torch.tensor(ids, dtype=torch.int64).pin_memory().to(clip.device, non_blocking=True)
+        else:
+            idx = torch.as_tensor(ids)
         sel = clip.index_select(0, idx)
         if clip.dtype == torch.uint8:
             return ops.preprocess_frames(sel.contiguous(), self.mean, self.to_bgr)
         return sel.contiguous()
+
+    def _frame_stage(self, imgs, want):
+        """model.frame_stage_async, replayed from a hipGraph when this exact batch shape has been seen before.
+        The frame stage is ~130 launches of static shape per batch: as a graph the host pays one replay
+        (microseconds) instead of ~35 us of Python + ctypes per launch.  First occurrence of a shape runs eagerly
+        (warm-up: packs weights, sets kernel attributes, fills the allocator), the second is captured."""
+        m = self.model
+        if not (self.use_graphs and imgs.is_cuda):
+            return m.frame_stage_async(imgs, want)
+        key = (tuple(imgs.shape), tuple(int(w) for w in want), imgs.dtype)
+        ent = self._fgraphs.get(key)
+        if ent is None:
+            self._fgraphs[key] = {}
+            return m.frame_stage_async(imgs, want)
+        if "graph" not in ent:
+            ent["static_in"] = imgs.clone()
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                ent["st"] = m.frame_stage_async(ent["static_in"], want)
+            ent["graph"] = g
+        ent["static_in"].copy_(imgs)
+        ent["graph"].replay()
+        st = ent["st"]
+        # the graph's outputs are overwritten by the next replay: hand out copies (6 MB per 16-frame batch)
+        return {"props": st["props"].clone(), "scores": st["scores"].clone(), "cnt": st["cnt"].clone(),
+                "feats": st["feats"].clone(), "want": st["want"]}
 
     def records_async(self, clip, jobs):
         """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
         records_resolve()."""
         m = self.model
         if self.world == 1:
-            return {"st": m.frame_stage_async(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs])}
+            return {"st": self._frame_stage(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs])}
         # ---- sharded: contiguous slices of the (padded) job list per rank, fixed-size records, one all-gather each
         n = len(jobs)
         per = (n + self.world - 1) // self.world
         padded = jobs + [jobs[-1]] * (per * self.world - n)
         mine = padded[self.rank * per:(self.rank + 1) * per]
-        st = m.frame_stage_async(self._frames(clip, [j[0] for j in mine]), [j[1] for j in mine])
+        st = self._frame_stage(self._frames(clip, [j[0] for j in mine]), [j[1] for j in mine])
         K, dev = m.key_num, clip.device
         feats = torch.zeros((per, K, st["feats"].shape[1]), dtype=st["feats"].dtype, device=dev)
         o = 0
@@ -123,12 +158,18 @@ class ClipEngine(object):
         g["want"] = [j[1] for j in jobs]
         return {"gathered": g}
 
-    def records_resolve(self, h):
-        """handle -> list of frame records (one host read of the proposal counts)."""
+    @staticmethod
+    def _cnt_of(h):
+        return h["st"]["cnt"] if "st" in h else h["gathered"]["cnt"]
+
+    def records_resolve(self, h, counts=None):
+        """handle -> list of frame records.  counts: host list of the per-frame proposal counts (default: read
+        them from the device, one host sync)."""
         if "st" in h:
-            return self.model.frame_stage_resolve(h["st"])
+            return self.model.frame_stage_resolve(h["st"], counts)
         g = h["gathered"]
-        counts = g["cnt"].tolist()
+        if counts is None:
+            counts = g["cnt"].tolist()
         out = []
         for i, w in enumerate(g["want"]):
             n = min(int(counts[i]), w)
@@ -173,17 +214,22 @@ class ClipEngine(object):
             with _On(sF):
                 h = self.records_async(clip, flat)
                 ev = None
-                if use_streams:
+                if use_streams:   # proposal counts -> pinned host memory, async; the event covers the copy
+                    c = self._cnt_of(h)
+                    h["cnt_host"] = torch.empty(c.shape, dtype=c.dtype).pin_memory()
+                    h["cnt_host"].copy_(c, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(sF)
             return per_step, h, ev
 
         def aggregate(b, per_step, h, ev):
             with _On(sB):
+                counts = None
                 if use_streams:
                     sB.wait_event(ev)
-                    ev.synchronize()                  # the proposal counts are read on the host right below
-                recs = self.records_resolve(h)        # counts of a batch that was enqueued one iteration ago
+                    ev.synchronize()                  # host waits for THIS frame-stage batch only, not the stream
+                    counts = h["cnt_host"].tolist()
+                recs = self.records_resolve(h, counts)
                 if use_streams:
                     for r in recs:                    # produced on sF, consumed on sB
                         for t in r.values():
@@ -203,11 +249,22 @@ class ClipEngine(object):
                         pending.append((i, m.step(None, glob, (W, H), defer=True)))
                     else:
                         pending.append((i, m.step(loc[0], glob, (W, H), defer=True)))
+                if use_streams:   # detection counts of the whole batch -> pinned host memory, async + event
+                    dc = torch.cat([pd[3] for _, pd in pending])
+                    host = torch.empty(dc.shape, dtype=dc.dtype).pin_memory()
+                    host.copy_(dc, non_blocking=True)
+                    evb = torch.cuda.Event()
+                    evb.record(sB)
+                    pending.append((host, evb))
             return pending
 
         def finish(pending):
             # one host read per batch of steps: all detection counts, then cut the padded outputs
-            with _On(sB):
+            if use_streams:
+                host, evb = pending.pop()
+                evb.synchronize()                     # waits for this batch's aggregation only
+                counts = host.tolist()
+            else:
                 counts = torch.cat([pd[3] for _, pd in pending]).tolist()
             for (i, pd), n in zip(pending, counts):
                 det = pp.materialize(pd, int(n), (W, H))
@@ -215,13 +272,23 @@ class ClipEngine(object):
                 if on_step is not None:
                     on_step(i, det)
 
+        import time as _time
+        ht = self.host_times
         staged = frame_stage(batches[0]) if batches else None
         prev_pending = None
         for bi, b in enumerate(batches):
+            t0 = _time.perf_counter()
             nxt = frame_stage(batches[bi + 1]) if bi + 1 < len(batches) else None   # F(b+1): async, enqueued first
+            t1 = _time.perf_counter()
             pending = aggregate(b, *staged)                                        # B(b): runs beside F(b+1)
+            t2 = _time.perf_counter()
             if prev_pending is not None:
                 finish(prev_pending)                                               # results of B(b-1)
+            t3 = _time.perf_counter()
+            ht["frame_enqueue"] += t1 - t0
+            ht["aggregate_enqueue"] += t2 - t1
+            ht["finish_wait"] += t3 - t2
+            ht["steps"] += b[1] - b[0]
             prev_pending, staged = pending, nxt
         if prev_pending is not None:
             finish(prev_pending)
