@@ -198,9 +198,17 @@ def main():
         peak = 2500.0 if args.dtype == "bfloat16" else 157.3
         d = summ[dom]
         ach = d["flops"] / (d["ms"] * 1e9)
+        # HBM traffic per launch of the dominant variant, from the committed rocprofv3 PMC passes of this same
+        # command (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction; tools/pmc_summary.py)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc) and args.dtype == "bfloat16":
+            k = json.load(open(pmc))["kernels"].get("igemm_kernel<bf16, bf16, 128, 128>")
+            if k:
+                traffic, traffic_src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/r01_pmc_summary.json"
         roofline = {"bound": "mfma", "kernel": "igemm_kernel<%s> (implicit-GEMM conv / linear)" % args.dtype,
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                     "flops_per_launch": round(d["flops"] / d["launches"], 0),
                     "share_of_gpu_time": round(d["ms"] / tot_ms, 3),
                     "whole_path_frac": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / (peak * 1e12), 5)

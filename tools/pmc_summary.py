@@ -1,0 +1,61 @@
+"""Summarise rocprofv3 PMC passes (one counter per pass, as the MI355X guide prescribes) per kernel.
+
+  python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE/pmc_counter_collection.csv \
+                              gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv  profiles/r01_pmc
+
+writes <prefix>_per_kernel.csv and <prefix>_summary.json.  HBM bytes per launch of a kernel =
+(2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are reported in KiB and, on gfx950 with this
+rocprofv3, FETCH_SIZE counts 64 B per 128-B read request (MI355X_MICROARCH.md, HBM section) -> doubled.
+Infinity-Cache hits are included in these fabric-side counters, so this is an upper bound on true HBM traffic.
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def short(k):
+    if "igemm_kernel" in k:
+        return k[k.index("igemm_kernel"):k.index(">(") + 1].replace("unsigned short", "bf16")
+    k = k.split("(")[0]
+    return k.replace("void ", "").replace("(anonymous namespace)::", "")[-80:]
+
+
+def agg(path, name):
+    d = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name:
+            continue
+        e = d[short(r["Kernel_Name"])]
+        e[0] += 1
+        e[1] += float(r["Counter_Value"])
+        e[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return d
+
+
+def main():
+    f = agg(sys.argv[1], "FETCH_SIZE")
+    w = agg(sys.argv[2], "WRITE_SIZE")
+    prefix = sys.argv[3]
+    rows = []
+    for k, (n, fs, t) in f.items():
+        ws = w.get(k, [1, 0.0, 0.0])
+        rows.append({"kernel": k, "launches": n, "fetch_kib_per_launch": fs / n,
+                     "write_kib_per_launch": ws[1] / max(ws[0], 1), "avg_us_under_pmc": t / n / 1e3,
+                     "hbm_bytes_per_launch_corrected": (2 * fs / n + ws[1] / max(ws[0], 1)) * 1024, "total_us": t / 1e3})
+    rows.sort(key=lambda r: -r["total_us"])
+    with open(prefix + "_per_kernel.csv", "w") as fh:
+        wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        wr.writeheader()
+        for r in rows:
+            wr.writerow({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()})
+    json.dump({"note": __doc__.split("writes")[1].strip(), "kernels": {r["kernel"]: r for r in rows[:12]}},
+              open(prefix + "_summary.json", "w"), indent=1)
+    for r in rows[:10]:
+        print("%-64s x%-5d fetch %9.0f KiB  write %9.0f KiB  -> %7.1f MB/launch" % (
+            r["kernel"][:64], r["launches"], r["fetch_kib_per_launch"], r["write_kib_per_launch"],
+            r["hbm_bytes_per_launch_corrected"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
