@@ -681,13 +681,16 @@ class GeneralizedRCNNMEGA(nn.Module):
         props, scores, cnt = self.rpn.propose(c4, W, H, "key")           # [B,K,4], [B,K], [B] (device)
         want = tuple(int(w) for w in want)
         key = (want, str(imgs.device))
-        cache = getattr(self, "_roi_index_cache", None)
-        if cache is None or cache[0] != key:
+        if not hasattr(self, "_roi_index_cache"):
+            self._roi_index_cache = {}
+        cache = self._roi_index_cache.get(key)
+        if cache is None:
+            # entries are NEVER evicted: a captured hipGraph keeps reading these index tensors on every replay
             K = props.shape[1]
             flat = torch.cat([b * K + torch.arange(w) for b, w in enumerate(want)])
             ids = torch.cat([torch.full((w,), float(b)) for b, w in enumerate(want)]).view(-1, 1)
             cache = (key, flat.to(imgs.device), ids.to(imgs.device))
-            self._roi_index_cache = cache
+            self._roi_index_cache[key] = cache
         boxes = props.view(-1, 4).index_select(0, cache[1])
         rois5 = torch.cat([cache[2], boxes], dim=1)
         feats = fe.box_features(c4, rois5)
