@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--arch", default="R-101")
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
-    ap.add_argument("--steps-per-batch", type=int, default=8)
+    ap.add_argument("--steps-per-batch", type=int, default=10)
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")

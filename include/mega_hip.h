@@ -131,6 +131,15 @@ size_t mega_relation_attention_workspace_bytes(int Nq, int Nk, int groups);
 int mega_preprocess_frames(const unsigned char* in, float* out, int N, int H, int W, float mean0, float mean1,
                            float mean2, int to_bgr, void* stream);
 
+/* FGFA flow-guided aggregation (BASELINE configs[4]): bilinear warp of T frames' [features | embeddings] by their
+ * flow fields (F.grid_sample bilinear / border / align_corners=False), cosine-similarity weights of the embeddings
+ * against the key frame's, softmax over frames, weighted feature sum -- one fused kernel.  Replaces
+ * GeneralizedRCNNFGFA.get_grid / resample / compute_weight + the softmax / sum of _forward_test
+ * (mega_core/modeling/detector/generalized_rcnn_fgfa.py:45-76,:201-211).
+ *   feats [T][H][W][Cf+Ce] NHWC, flow [T][2][H][W] f32, out [H][W][Cf], weights_out [T][H][W] f32 or NULL. */
+int mega_fgfa_warp_aggregate(const void* feats, const float* flow, void* out, float* weights_out, int T, int H,
+                             int W, int Cf, int Ce, int key, int dtype, void* stream);
+
 /* hipGetErrorString of the last launch failure any entry point of this library reported (MEGA_ERR_LAUNCH). */
 const char* mega_last_error_string(void);
 

@@ -18,6 +18,7 @@ SOURCES = {
     "boxes.hip": ["-ffp-contract=off"],
     "relation.hip": [],
     "frames.hip": [],
+    "fgfa.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

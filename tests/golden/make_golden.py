@@ -172,6 +172,19 @@ def golden_ops():
     out["post_logits"], out["post_deltas"], out["post_props"] = logits.numpy(), deltas.numpy(), props.bbox.numpy()
     out["post_boxes"], out["post_scores"] = det.bbox.numpy(), det.get_field("scores").numpy()
     out["post_labels"] = det.get_field("labels").numpy()
+    # FGFA warp + aggregation (detector/generalized_rcnn_fgfa.py:45-76,:201-211), methods of the reference class
+    from mega_core.modeling.detector.generalized_rcnn_fgfa import GeneralizedRCNNFGFA
+    import torch.nn.functional as Fn
+    fg = object.__new__(GeneralizedRCNNFGFA)     # the three methods used below touch no instance state
+    T, Cf, Ce, Hh, Ww = 5, 16, 24, 9, 13
+    feats_all = torch.randn((T, Cf + Ce, Hh, Ww), generator=g)
+    flow = torch.randn((T, 2, Hh, Ww), generator=g) * 2.5
+    flow[2] = 0
+    warped = fg.resample(feats_all, flow)
+    wf, emb = torch.split(warped, (Cf, Ce), dim=1)
+    wts = Fn.softmax(fg.compute_weight(emb.contiguous(), emb[2:3]), dim=0)
+    out["fgfa_feats"], out["fgfa_flow"], out["fgfa_key"] = feats_all.numpy(), flow.numpy(), np.int64(2)
+    out["fgfa_out"], out["fgfa_weights"] = torch.sum(wts * wf, dim=0, keepdim=True).numpy(), wts.numpy()
     np.savez_compressed(os.path.join(HERE, "ref_ops.npz"), **out)
     print("reference op fixtures written: %d arrays" % len(out))
 

@@ -280,3 +280,25 @@ def test_preprocess(dev):
     ref = synth.preprocess_cpu(fr)
     got = ops.preprocess_frames(fr.to(dev), synth.PIXEL_MEAN).cpu()
     assert (got - ref).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(5, 9, 13, 16, 24), (19, 38, 63, 1024, 2048), (21, 12, 17, 64, 128)])
+def test_fgfa_warp_aggregate(dev, dtype, shape):
+    """Fused FGFA warp + cosine weights + softmax + sum vs the oracle restatement of
+    generalized_rcnn_fgfa.py:45-76,:201-211 (config 5: T=19 reference default / 21 BASELINE, 38x63, 1024+2048)."""
+    ops = _ops()
+    from oracle import mega_oracle as mo
+    T, H, W, Cf, Ce = shape
+    g = torch.Generator().manual_seed(T * H)
+    feats = torch.randn((T, Cf + Ce, H, W), generator=g).to(dtype)
+    flow = torch.randn((T, 2, H, W), generator=g) * 3
+    flow[T // 2] *= 0.05
+    flow[0, :, 0, :] = 50.0                                   # far outside: border padding
+    key = T // 2
+    want, want_w = mo.fgfa_aggregate(feats.float(), flow, key, nfeat=Cf)
+    out, w = ops.fgfa_warp_aggregate(feats.permute(0, 2, 3, 1).contiguous().to(dev), flow.to(dev), Cf, key,
+                                     want_weights=True)
+    assert (w.cpu() - want_w[:, 0]).abs().max() < (2e-5 if dtype == torch.float32 else 2e-3)
+    err = _relerr(out.float().cpu().permute(2, 0, 1)[None], want)
+    assert err < (1e-5 if dtype == torch.float32 else 1e-2), err
