@@ -37,7 +37,8 @@ extern "C" {
  * of the box head (H = W = R = S = 1, N = rows): roi_box_feature_extractors.py:894,:907,:826,
  * roi_box_predictors.py:50-57.
  *   in  [N][H][W][Cin]      (in_dtype)        w [Cout][R][S][Cin] (in_dtype)
- *   out [N*Ho*Wo][ldo]      (out_dtype)       y = acc*scale[c] + bias[c] (+ residual[m][c]) (relu)
+ *   out [N*Ho*Wo][ldo]      (out_dtype)       y = act(acc*scale[c] + bias[c] (+ residual[m][c]))
+ *   relu: 0 = identity, 1 = ReLU, 2 = LeakyReLU(0.1) (FlowNetS)
  *   scale / bias: f32 [Cout] or NULL (1 / 0); residual [M][ldr] in_dtype or NULL; ldo/ldr <= 0 -> Cout.
  *   Cin must be a multiple of 64 (bf16) / 32 (f32).  out_dtype may be MEGA_F32 with bf16 inputs. */
 int mega_conv2d_nhwc(const void* in, const void* w, const float* scale, const float* bias, const void* residual,
@@ -52,6 +53,9 @@ int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, const float* s
 
 /* F.max_pool2d(kernel 3, stride 2, padding 1) on NHWC (resnet.py:365). */
 int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
+
+/* nn.AvgPool2d(2, stride 2, ceil_mode=True) on NHWC (FlowNetS, mega_core/modeling/backbone/flownet.py:52,:56,:112). */
+int mega_avgpool2x2_ceil_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
 
 /* ROIAlign forward.  Replaces mega_core._C.roi_align_forward (csrc/ROIAlign.h:11-25,
  * cuda/ROIAlign_cuda.cu:64-122, cpu/ROIAlign_cpu.cpp:113-219).  rois [K][5] f32 = (batch, x1, y1, x2, y2).

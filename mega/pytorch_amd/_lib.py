@@ -17,6 +17,7 @@ SIGNATURES = {
     "mega_conv2d_nhwc": (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_void_p]),
     "mega_stem_conv_bn_relu": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "mega_maxpool3x3s2_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
+    "mega_avgpool2x2_ceil_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "mega_roi_align_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] + [c_int] * 7 + [c_void_p]),
     "mega_nms_full_workspace_bytes": (c_size_t, [c_int]),
     "mega_nms": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

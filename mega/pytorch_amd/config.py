@@ -37,10 +37,23 @@ class CfgNode(dict):
         return self
 
 
-def get_cfg(arch="R-101"):
-    """MEGA test-time defaults.  arch: 'R-101' (configs/MEGA/vid_R_101_C4_MEGA_1x.yaml) or
-    'R-50' (configs/MEGA/vid_R_50_C4_MEGA_1x.yaml)."""
+def get_cfg(arch="R-101", method="mega"):
+    """Test-time defaults.  arch: 'R-101' | 'R-50'; method: 'mega' (configs/MEGA/vid_R_{101,50}_C4_MEGA_1x.yaml)
+    or 'fgfa' (configs/FGFA/vid_R_{101,50}_C4_FGFA_1x.yaml: GeneralizedRCNNFGFA +
+    ResNetConv52MLPFeatureExtractor, no relation attention)."""
     r50 = arch in ("R-50", "R-50-C4")
+    cfg = _mega_cfg(r50)
+    if method == "fgfa":
+        cfg.MODEL.META_ARCHITECTURE = "GeneralizedRCNNFGFA"
+        cfg.MODEL.VID.METHOD = "fgfa"
+        cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "ResNetConv52MLPFeatureExtractor"
+        cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ENABLE = False
+    elif method != "mega":
+        raise ValueError("method must be 'mega' or 'fgfa'")
+    return cfg
+
+
+def _mega_cfg(r50):
     return CfgNode({
         "DTYPE": "float32",                      # defaults.py:541; "bfloat16" selects the bf16 MFMA path
         "INPUT": {"MIN_SIZE_TEST": 600, "MAX_SIZE_TEST": 1000,
@@ -66,6 +79,7 @@ def get_cfg(arch="R-101"):
                 "RPN": {"REF_PRE_NMS_TOP_N": 6000, "REF_POST_NMS_TOP_N": 75},
                 "ROI_BOX_HEAD": {"REDUCE_CHANNEL": bool(r50),
                                  "ATTENTION": {"ENABLE": True, "STAGE": 3, "GROUP": 16, "EMBED_DIM": 64}},
+                "FGFA": {"MIN_OFFSET": -9, "MAX_OFFSET": 9, "ALL_FRAME_INTERVAL": 19, "KEY_FRAME_LOCATION": 9},
                 "MEGA": {"MIN_OFFSET": -12, "MAX_OFFSET": 12, "ALL_FRAME_INTERVAL": 25, "KEY_FRAME_LOCATION": 12,
                          "RATIO": 0.2,
                          "MEMORY": {"ENABLE": True, "SIZE": 25},

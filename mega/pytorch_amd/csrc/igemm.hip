@@ -235,6 +235,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(ConvParams p) {
   const T* __restrict__ res = (const T*)p.res;
   constexpr int OVE = 16 / (int)sizeof(OT);   // output elements per 16-byte vector
   constexpr int VPR = BN / OVE;               // vectors per tile row
+  // activation: relu = 0 none, 1 ReLU, 2 LeakyReLU(0.1) (FlowNetS, mega_core/modeling/backbone/flownet.py:50)
+  const float neg_slope = p.relu == 1 ? 0.f : (p.relu == 2 ? 0.1f : 1.f);
+  auto act = [&](float x) { return x > 0.f ? x : x * neg_slope; };
   const bool vec_ok = (p.ldo % OVE == 0) && (!res || (sizeof(T) == sizeof(OT) && p.ldr % OVE == 0));
   for (int e = tid; e < BM * VPR; e += NTHREADS) {
     const int row = e / VPR, cv = e - row * VPR;
@@ -256,13 +259,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(ConvParams p) {
       uint4 o;
       OT* oe = reinterpret_cast<OT*>(&o);
 #pragma unroll
-      for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, p.relu ? fmaxf(v[t], 0.f) : v[t]);
+      for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, act(v[t]));
       *reinterpret_cast<uint4*>(out + (size_t)m * p.ldo + n) = o;
     } else {
       for (int t = 0; t < OVE && n + t < p.Cout; ++t) {
         float x = v[t];
         if (res) x += Elem<T>::ld(res + (size_t)m * p.ldr + n + t);
-        if (p.relu) x = fmaxf(x, 0.f);
+        x = act(x);
         Elem<OT>::st(out + (size_t)m * p.ldo + n + t, x);
       }
     }

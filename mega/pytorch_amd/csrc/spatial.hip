@@ -170,6 +170,47 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T* __restrict__ fe
   }
 }
 
+// ------------------------------------------------------------------------------------ avg-pool 2x2 s2, ceil_mode
+// nn.AvgPool2d(2, stride=2, ceil_mode=True) of FlowNetS (mega_core/modeling/backbone/flownet.py:52,:56,:112) on
+// NHWC: windows hanging over the edge average the in-bounds taps only (count_include_pad semantics with pad 0).
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H,
+                                                       int W, int C, int Ho, int Wo) {
+  constexpr int VE = Elem<T>::VE;
+  const int cv = C / VE;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % cv);
+    size_t pix = idx / cv;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    int cnt = 0;
+    for (int dy = 0; dy < 2; ++dy) {
+      const int hi = ho * 2 + dy;
+      if (hi >= H) continue;
+      for (int dx = 0; dx < 2; ++dx) {
+        const int wi = wo * 2 + dx;
+        if (wi >= W) continue;
+        const uint4 raw = *reinterpret_cast<const uint4*>(in + (((size_t)n * H + hi) * W + wi) * C + v * VE);
+        const T* rv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += Elem<T>::ld(rv + e);
+        ++cnt;
+      }
+    }
+    uint4 o;
+    T* ov = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) Elem<T>::st(ov + e, acc[e] / (float)cnt);
+    *reinterpret_cast<uint4*>(out + (((size_t)n * Ho + ho) * Wo + wo) * C + v * VE) = o;
+  }
+}
+
 // Channel-vectorised NHWC -> bin-major variant (the hot-path layout): one work item = (bin, 16-byte channel
 // vector); a wave reads 64 consecutive 16-B vectors of one pixel = 1 KiB fully coalesced per neighbour.
 // Same arithmetic, same order of operations as roi_align_kernel.
@@ -313,6 +354,27 @@ extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out
   else if (dtype == MEGA_F32 && out_dtype == MEGA_F32)
     hipLaunchKernelGGL((roi_align_kernel<float, float>), grid, dim3(threads), 0, st, (const float*)feat, rois,
                        (float*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio, in_nhwc, out_nhwc);
+  else
+    return MEGA_ERR_ARG;
+  return mega_check_launch();
+}
+
+extern "C" int mega_avgpool2x2_ceil_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype,
+                                         void* stream) {
+  mega_clear_error();
+  if (!in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MEGA_ERR_ARG;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  hipStream_t st = (hipStream_t)stream;
+  const int ve = dtype == MEGA_BF16 ? 8 : 4;
+  if (C % ve) return MEGA_ERR_ARG;
+  const size_t total = (size_t)N * Ho * Wo * (C / ve);
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (dtype == MEGA_BF16)
+    hipLaunchKernelGGL((avgpool2_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, N, H,
+                       W, C, Ho, Wo);
+  else if (dtype == MEGA_F32)
+    hipLaunchKernelGGL((avgpool2_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)in, (float*)out, N, H, W,
+                       C, Ho, Wo);
   else
     return MEGA_ERR_ARG;
   return mega_check_launch();

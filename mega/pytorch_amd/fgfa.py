@@ -1,0 +1,323 @@
+"""FGFA detector (BASELINE configs[4]) on the HIP kernels: host mirror of
+
+  mega_core/modeling/detector/generalized_rcnn_fgfa.py:21-219   GeneralizedRCNNFGFA (test path)
+  mega_core/modeling/backbone/flownet.py:16-118                 FlowNetS
+  mega_core/modeling/backbone/embednet.py:8-24                  EmbedNet
+  mega_core/modeling/roi_heads/box_head/roi_box_feature_extractors.py:55-118  ResNetConv52MLPFeatureExtractor
+
+with the reference's module / parameter names (state_dict compatible: flownet.*, embednet.*,
+roi_heads.box.feature_extractor.{head,conv,fc6,fc7}.*).
+
+Kernel mapping: every Conv2d / ConvTranspose2d / Linear is the implicit-GEMM MFMA kernel (igemm.hip); a
+ConvTranspose2d(k=4, s=2) is run as a stride-1 4x4 conv with the flipped kernel over the zero-stuffed input;
+channel counts that are not a multiple of the GEMM K-vector (6, 2, 1026, 770, 386, 194) are zero-padded (weights
+too), which changes no result.  The flow-guided warp + cosine weights + softmax + sum is ONE fused kernel
+(fgfa.hip).  torch is used for memory plumbing only (concat / crop / zero-stuffing copies).
+"""
+from collections import deque
+
+import torch
+from torch import nn
+
+from . import ops
+from .modeling import (DETECTION_META_ARCHITECTURES, ROI_BOX_FEATURE_EXTRACTORS, ROI_BOX_PREDICTOR, CombinedROIHeads,
+                       PostProcessor, ResNetHead, _Packed, _nhwc, _nchw_view, _pack_conv, build_backbone, build_rpn,
+                       compute_dtype, convert_to_roi_format)
+from .structures import BoxList, to_image_list
+
+
+def _mult(dtype):
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def _padc(x, mult):
+    """zero-pad the channel (last) dimension of an NHWC tensor to a multiple of `mult`."""
+    c = x.shape[-1]
+    cp = (c + mult - 1) // mult * mult
+    if cp == c:
+        return x.contiguous()
+    z = torch.zeros(x.shape[:-1] + (cp - c,), dtype=x.dtype, device=x.device)
+    return torch.cat([x, z], dim=-1).contiguous()
+
+
+def _pack_w(w_oihw, dtype, mult, scale=1.0):
+    """OIHW -> OHWI with Cin zero-padded to a multiple of mult."""
+    w = (w_oihw.detach().float() * scale).permute(0, 2, 3, 1)
+    return _padc(w, mult).to(dtype).contiguous()
+
+
+def _zero_stuff(x):
+    """[N,H,W,C] -> [N,2H-1,2W-1,C] with the input on the even positions (ConvTranspose2d stride 2 as a conv)."""
+    N, H, W, C = x.shape
+    z = torch.zeros((N, 2 * H - 1, 2 * W - 1, C), dtype=x.dtype, device=x.device)
+    z[:, ::2, ::2] = x
+    return z
+
+
+def _crop_like(x, target):
+    """flownet.py:9-13 crop_like on NHWC."""
+    if x.shape[1:3] == target.shape[1:3]:
+        return x
+    return x[:, 1:target.shape[1] + 1, 1:target.shape[2] + 1].contiguous()
+
+
+class FlowNetS(_Packed):
+    """backbone/flownet.py:16-118 (method "fgfa": returns Convolution5 * 2.5)."""
+
+    CONVS = [("flow_conv1", 6, 64, 7, 2, 3), ("conv2", 64, 128, 5, 2, 2), ("conv3", 128, 256, 5, 2, 2),
+             ("conv3_1", 256, 256, 3, 1, 1), ("conv4", 256, 512, 3, 2, 1), ("conv4_1", 512, 512, 3, 1, 1),
+             ("conv5", 512, 512, 3, 2, 1), ("conv5_1", 512, 512, 3, 1, 1), ("conv6", 512, 1024, 3, 2, 1),
+             ("conv6_1", 1024, 1024, 3, 1, 1)]
+    PREDS = [("Convolution1", 1024), ("Convolution2", 1026), ("Convolution3", 770), ("Convolution4", 386),
+             ("Convolution5", 194)]
+    DECONVS = [("deconv5", 1024, 512), ("deconv4", 1026, 256), ("deconv3", 770, 128), ("deconv2", 386, 64)]
+    UPS = ["upsample_flow6to5", "upsample_flow5to4", "upsample_flow4to3", "upsample_flow3to2"]
+
+    def __init__(self, cfg):
+        super().__init__()
+        for name, ci, co, k, s, p in self.CONVS:
+            setattr(self, name, nn.Conv2d(ci, co, k, stride=s, padding=p))
+        for name, ci in self.PREDS:
+            setattr(self, name, nn.Conv2d(ci, 2, 3, stride=1, padding=1))
+        for name, ci, co in self.DECONVS:
+            setattr(self, name, nn.ConvTranspose2d(ci, co, 4, stride=2))
+        for name in self.UPS:
+            setattr(self, name, nn.ConvTranspose2d(2, 2, 4, stride=2))
+
+    def _pack(self, dtype, device):
+        m = _mult(dtype)
+        pk = {}
+        for name, ci, co, k, s, p in self.CONVS:
+            mod = getattr(self, name)
+            # the image pair is fed un-normalised: the reference's "/ 255" (generalized_rcnn_fgfa.py:198) is linear
+            # and is folded into the first conv's weights
+            pk[name] = (_pack_w(mod.weight, dtype, m, 1.0 / 255 if name == "flow_conv1" else 1.0).to(device),
+                        mod.bias.detach().float().to(device).contiguous(), s, p)
+        for name, _ in self.PREDS:
+            mod = getattr(self, name)
+            pk[name] = (_pack_w(mod.weight, dtype, m).to(device), mod.bias.detach().float().to(device).contiguous())
+        for name in [d[0] for d in self.DECONVS] + self.UPS:
+            mod = getattr(self, name)
+            w = mod.weight.detach().permute(1, 0, 2, 3).flip(2, 3)      # [in,out,kh,kw] -> conv kernel [out,in,kh,kw]
+            pk[name] = (_pack_w(w, dtype, m).to(device), mod.bias.detach().float().to(device).contiguous())
+        pk["x2.5"] = torch.full((2,), 2.5, dtype=torch.float32, device=device)
+        pk["m"] = m
+        return pk
+
+    def _conv(self, pk, name, x, act=2):
+        w, b, s, p = pk[name]
+        return ops.conv2d_nhwc(_padc(x, pk["m"]), w, None, b, stride=s, pad=p, relu=act)
+
+    def _pred(self, pk, name, x):
+        w, b = pk[name]
+        return ops.conv2d_nhwc(x, w, None, b, pad=1, relu=0)
+
+    def _deconv(self, pk, name, x, act):
+        w, b = pk[name]
+        xs = _zero_stuff(_padc(x, pk["m"]))
+        return ops.conv2d_nhwc(xs, w, None, b, pad=3, relu=act)
+
+    def run(self, pair_nhwc):
+        """pair_nhwc [T,H,W,6 (+pad)] un-normalised image pairs (cur | ref) -> flow [T,2,Hf,Wf] f32."""
+        dt = pair_nhwc.dtype
+        pk = self._packed(dt, pair_nhwc.device)
+        m = _mult(dt)
+        x = ops.avgpool2x2_ceil(_padc(pair_nhwc, m))
+        r1 = self._conv(pk, "flow_conv1", x)
+        r2 = self._conv(pk, "conv2", r1)
+        r3 = self._conv(pk, "conv3", r2)
+        r4 = self._conv(pk, "conv3_1", r3)
+        r5 = self._conv(pk, "conv4", r4)
+        r6 = self._conv(pk, "conv4_1", r5)
+        r7 = self._conv(pk, "conv5", r6)
+        r8 = self._conv(pk, "conv5_1", r7)
+        r9 = self._conv(pk, "conv6", r8)
+        r10 = self._conv(pk, "conv6_1", r9)
+
+        def level(feat_in, skip, pred_name, up_name, deconv_name):
+            flow = self._pred(pk, pred_name, feat_in)                       # [.,.,.,2]
+            up = _crop_like(self._deconv(pk, up_name, flow, 0), skip)
+            dec = _crop_like(self._deconv(pk, deconv_name, feat_in, 2), skip)
+            return _padc(torch.cat([skip, dec, up], dim=-1), m)             # concatN (channel-padded)
+        c2 = level(r10, r8, "Convolution1", "upsample_flow6to5", "deconv5")
+        c3 = level(c2, r6, "Convolution2", "upsample_flow5to4", "deconv4")
+        c4 = level(c3, r4, "Convolution3", "upsample_flow4to3", "deconv3")
+        c5 = level(c4, r2, "Convolution4", "upsample_flow3to2", "deconv2")
+        c5 = ops.avgpool2x2_ceil(c5)
+        w, b = pk["Convolution5"]                                            # Convolution5 * 2.5 (flownet.py:118)
+        flow = ops.conv2d_nhwc(c5, w, pk["x2.5"], b * 2.5, pad=1, relu=0, out_dtype=torch.float32)
+        return flow.permute(0, 3, 1, 2).contiguous()
+
+    def forward(self, x):
+        """reference signature: x [T,6,H,W] = cat([cur/255, ref/255]) -> flow [T,2,h,w]."""
+        dt = self._dtype
+        return self.run((x * 255.0).permute(0, 2, 3, 1).contiguous().to(dt))
+
+
+class EmbedNet(_Packed):
+    """backbone/embednet.py:8-24."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.embed_conv1 = nn.Conv2d(1024, 512, 1)
+        self.embed_conv2 = nn.Conv2d(512, 512, 3, padding=1)
+        self.embed_conv3 = nn.Conv2d(512, 2048, 1)
+
+    def _pack(self, dtype, device):
+        return {n: (_pack_conv(getattr(self, n), dtype).to(device), getattr(self, n).bias.detach().float().to(device).contiguous())
+                for n in ("embed_conv1", "embed_conv2", "embed_conv3")}
+
+    def run(self, x):
+        pk = self._packed(x.dtype, x.device)
+        x = ops.conv2d_nhwc(x, pk["embed_conv1"][0], None, pk["embed_conv1"][1], relu=True)
+        x = ops.conv2d_nhwc(x, pk["embed_conv2"][0], None, pk["embed_conv2"][1], pad=1, relu=True)
+        return ops.conv2d_nhwc(x, pk["embed_conv3"][0], None, pk["embed_conv3"][1])
+
+    def forward(self, x):
+        return _nchw_view(self.run(_nhwc(x)))
+
+
+@ROI_BOX_FEATURE_EXTRACTORS.register("ResNetConv52MLPFeatureExtractor")
+class ResNetConv52MLPFeatureExtractor(_Packed):
+    """roi_box_feature_extractors.py:55-118: res5 on the full map (+1x1 reduce) -> ROIAlign -> fc6 -> fc7."""
+
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        rb = cfg.MODEL.ROI_BOX_HEAD
+        self.head = ResNetHead(cfg.MODEL.RESNETS.RES5_DILATION)
+        self.conv = nn.Conv2d(2048, 256, 1) if cfg.MODEL.VID.ROI_BOX_HEAD.REDUCE_CHANNEL else None
+        self.pooled_c = 256 if self.conv is not None else 2048
+        self.resolution, self.scale, self.sampling_ratio = rb.POOLER_RESOLUTION, rb.POOLER_SCALES[0], rb.POOLER_SAMPLING_RATIO
+        rep = rb.MLP_HEAD_DIM
+        self.fc6 = nn.Linear(self.pooled_c * self.resolution ** 2, rep)
+        self.fc7 = nn.Linear(rep, rep)
+        self.out_channels = rep
+
+    def _pack(self, dtype, device):
+        r2 = self.resolution ** 2
+        w6 = self.fc6.weight.detach()
+        w6 = w6.view(w6.shape[0], self.pooled_c, r2).permute(0, 2, 1).reshape(w6.shape[0], -1)   # (c,ph,pw)->(ph,pw,c)
+        pk = {"w6": w6.contiguous().to(dtype).to(device), "b6": self.fc6.bias.detach().float().to(device).contiguous(),
+              "w7": self.fc7.weight.detach().to(dtype).to(device).contiguous(),
+              "b7": self.fc7.bias.detach().float().to(device).contiguous()}
+        if self.conv is not None:
+            pk["rc_w"] = _pack_conv(self.conv, dtype).to(device)
+            pk["rc_b"] = self.conv.bias.detach().float().to(device).contiguous()
+        return pk
+
+    def forward(self, x, proposals):
+        feat = _nhwc(x[0] if isinstance(x, (list, tuple)) else x)
+        pk = self._packed(feat.dtype, feat.device)
+        y = self.head.run(feat)
+        if self.conv is not None:
+            y = ops.conv2d_nhwc(y, pk["rc_w"], None, pk["rc_b"], relu=True)
+        pooled = ops.roi_align(y, convert_to_roi_format(proposals), self.scale, (self.resolution, self.resolution),
+                               self.sampling_ratio)
+        h = ops.linear(pooled.view(pooled.shape[0], -1), pk["w6"], pk["b6"], relu=True)
+        return ops.linear(h, pk["w7"], pk["b7"], relu=True)
+
+
+class ROIBoxHead(nn.Module):
+    """roi_heads/box_head/box_head.py:11-62 (test path)."""
+
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        self.feature_extractor = ROI_BOX_FEATURE_EXTRACTORS[cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR](cfg, in_channels)
+        self.predictor = ROI_BOX_PREDICTOR[cfg.MODEL.ROI_BOX_HEAD.PREDICTOR](cfg, self.feature_extractor.out_channels)
+        self.post_processor = PostProcessor(cfg)
+
+    def forward(self, features, proposals, targets=None):
+        if self.training:
+            raise NotImplementedError("inference path only")
+        x = self.feature_extractor(features, proposals)
+        class_logits, box_regression = self.predictor(x)
+        return x, self.post_processor((class_logits, box_regression), proposals), {}
+
+
+class GeneralizedRCNNFGFA(nn.Module):
+    """detector/generalized_rcnn_fgfa.py:21-219, inference: per-video deques of images and [features | embeddings]
+    (maxlen ALL_FRAME_INTERVAL, key = slot KEY_FRAME_LOCATION), FlowNetS on the (key, frame) pairs, flow-guided
+    aggregation, then the plain RPN + box head on the aggregated map."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.dtype = compute_dtype(cfg)
+        self.backbone = build_backbone(cfg)
+        self.flownet = FlowNetS(cfg)
+        self.flownet._dtype = self.dtype
+        self.embednet = EmbedNet(cfg)
+        self.rpn = build_rpn(cfg, self.backbone.out_channels)
+        self.roi_heads = CombinedROIHeads(cfg, [("box", ROIBoxHead(cfg, self.backbone.out_channels))])
+        self.all_frame_interval = cfg.MODEL.VID.FGFA.ALL_FRAME_INTERVAL
+        self.key_frame_location = cfg.MODEL.VID.FGFA.KEY_FRAME_LOCATION
+        self.eval()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        for m in self.modules():
+            if isinstance(m, _Packed):
+                m._pk = None
+        return out
+
+    @torch.no_grad()
+    def _update_feature(self, img=None, feats=None):
+        """:144-150.  img [1,3,H,W] f32; the stored feature is NHWC [1,h,w,1024+2048] (features | embeddings)."""
+        if feats is None:
+            f = _nhwc(self.backbone(img)[0])
+            feats = torch.cat([f, self.embednet.run(f)], dim=-1)
+        self.images.append(img)
+        self.features.append(feats)
+        return feats
+
+    @torch.no_grad()
+    def forward(self, images, targets=None):
+        """reference call convention (:78-105): images = {"cur", "ref": [frame t+MAX_OFFSET], "frame_category",
+        "seg_len", "pattern", "img_dir", "transforms"}; extension "ref_init": preprocessed frames 1..9 for
+        frame_category 0 (replaces the PIL read inside forward, :166-176)."""
+        if targets is not None:
+            raise ValueError("In testing mode, targets should be None")
+        cur = to_image_list(images["cur"]).tensors.to(self.device).float()
+        H, W = cur.shape[-2:]
+        if images["frame_category"] == 0:
+            self.seg_len = images["seg_len"]
+            self.end_id = 0
+            self.images = deque(maxlen=self.all_frame_interval)
+            self.features = deque(maxlen=self.all_frame_interval)
+            f0 = self._update_feature(cur)
+            while len(self.images) < self.key_frame_location + 1:
+                self._update_feature(cur, f0)
+            init = images.get("ref_init")
+            while len(self.images) < self.all_frame_interval:
+                self.end_id = min(self.end_id + 1, self.seg_len - 1)
+                if self.end_id == 0:
+                    t = cur
+                elif init is not None:
+                    t = to_image_list(init[self.end_id - 1]).tensors
+                else:
+                    from PIL import Image
+                    im = Image.open(images["img_dir"] % (images["pattern"] % self.end_id)).convert("RGB")
+                    t = images["transforms"](im)
+                    t = t[0] if isinstance(t, tuple) else t
+                    t = t.view(1, *t.shape)
+                self._update_feature(t.to(self.device).float())
+        elif images["frame_category"] == 1:
+            self.end_id = min(self.end_id + 1, self.seg_len - 1)
+            self._update_feature(to_image_list(images["ref"][0]).tensors.to(self.device).float())
+        all_images = torch.cat(list(self.images), dim=0)                       # [T,3,H,W]
+        all_features = torch.cat(list(self.features), dim=0)                   # [T,h,w,3072] NHWC
+        cur_image = self.images[self.key_frame_location]
+        T = all_images.shape[0]
+        pair = torch.cat([cur_image.expand(T, -1, -1, -1), all_images], dim=1)  # :196-198 (the /255 lives in conv1)
+        flow = self.flownet.run(pair.permute(0, 2, 3, 1).contiguous().to(self.dtype))
+        nfeat = self.backbone.out_channels
+        agg = ops.fgfa_warp_aggregate(all_features.contiguous(), flow, nfeat, self.key_frame_location)   # [h,w,1024]
+        feats = (_nchw_view(agg.unsqueeze(0)),)
+        il = to_image_list(cur)
+        proposals, _ = self.rpn(il, feats, None)
+        _, result, _ = self.roi_heads(feats, proposals, None)
+        return result
+
+
+DETECTION_META_ARCHITECTURES.register("GeneralizedRCNNFGFA", GeneralizedRCNNFGFA)

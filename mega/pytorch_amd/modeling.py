@@ -349,7 +349,9 @@ class RPNWithRefModule(nn.Module):
 
 def build_rpn(cfg, in_channels):
     """rpn/rpn.py:246-262: METHOD 'mega' -> RPNWithRefModule."""
-    assert cfg.MODEL.VID.METHOD == "mega"
+    # "mega" -> RPNWithRefModule; "fgfa" / "base" use the plain RPNModule in the reference, which is the "key" path
+    # of the same module (identical parameters and proposals)
+    assert cfg.MODEL.VID.METHOD in ("mega", "fgfa", "base")
     return RPNWithRefModule(cfg, in_channels)
 
 

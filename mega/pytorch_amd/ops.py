@@ -90,7 +90,8 @@ def _pe(tok):
 # ------------------------------------------------------------------------------------------------ conv / linear
 def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,
                 out=None):
-    """x [N,H,W,Cin] (contiguous), w [Cout,R,S,Cin] -> [N,Ho,Wo,Cout].  y = conv*scale + bias (+res) (relu)."""
+    """x [N,H,W,Cin] (contiguous), w [Cout,R,S,Cin] -> [N,Ho,Wo,Cout].  y = act(conv*scale + bias (+res));
+    relu: False/0 none, True/1 ReLU, 2 LeakyReLU(0.1)."""
     _gpu(x, w, scale, bias, residual)
     lib = _lib.load()
     N, H, W, Cin = x.shape
@@ -330,3 +331,15 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
     _pe(_tok)
     _lib.check(rc, "mega_fgfa_warp_aggregate")
     return (out, wts) if want_weights else out
+
+
+def avgpool2x2_ceil(x):
+    """nn.AvgPool2d(2, 2, ceil_mode=True) on NHWC."""
+    _gpu(x)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    assert x.is_contiguous()
+    out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
+    rc = lib.mega_avgpool2x2_ceil_nhwc(_ptr(x), _ptr(out), N, H, W, C, _dt(x), _stream())
+    _lib.check(rc, "mega_avgpool2x2_ceil_nhwc")
+    return out

@@ -164,3 +164,38 @@ def preprocess_cpu(frames_u8):
     x = frames_u8.permute(0, 3, 1, 2).float() / 255.0
     x = x[:, [2, 1, 0]] * 255.0
     return x - torch.tensor(PIXEL_MEAN).view(1, 3, 1, 1)
+
+
+def make_fgfa_state_dict(blocks=(3, 4, 6), reduce_channel=True, num_classes=31, seed=0):
+    """Calibrated random weights with the reference's FGFA state_dict layout
+    (backbone.*, flownet.*, embednet.*, rpn.*, roi_heads.box.feature_extractor.{head,conv,fc6,fc7}, predictor)."""
+    base = make_state_dict(blocks=blocks, reduce_channel=reduce_channel, stage=1, global_res_stage=0,
+                           num_classes=num_classes, seed=seed)
+    sd = {k: v for k, v in base.items() if not any(t in k for t in (".l_", ".g_"))}
+    gen = torch.Generator().manual_seed(seed + 1000)
+
+    def conv(name, co, ci, k, gain=1.0, transposed=False):
+        shape = (ci, co, k, k) if transposed else (co, ci, k, k)
+        fan_in = ci * k * k
+        sd[name + ".weight"] = (torch.rand(shape, generator=gen) * 2 - 1) * math.sqrt(3.0 / fan_in) * gain
+        sd[name + ".bias"] = _normal(gen, (co,), 0.02)
+    for name, ci, co, k in [("flow_conv1", 6, 64, 7), ("conv2", 64, 128, 5), ("conv3", 128, 256, 5), ("conv3_1", 256, 256, 3),
+                            ("conv4", 256, 512, 3), ("conv4_1", 512, 512, 3), ("conv5", 512, 512, 3),
+                            ("conv5_1", 512, 512, 3), ("conv6", 512, 1024, 3), ("conv6_1", 1024, 1024, 3)]:
+        conv("flownet." + name, co, ci, k, gain=1.6)
+    for name, ci in [("Convolution1", 1024), ("Convolution2", 1026), ("Convolution3", 770), ("Convolution4", 386),
+                     ("Convolution5", 194)]:
+        conv("flownet." + name, 2, ci, 3, gain=2.0)
+    for name, ci, co in [("deconv5", 1024, 512), ("deconv4", 1026, 256), ("deconv3", 770, 128), ("deconv2", 386, 64)]:
+        conv("flownet." + name, co, ci, 4, gain=1.6, transposed=True)
+    for name in ("upsample_flow6to5", "upsample_flow5to4", "upsample_flow4to3", "upsample_flow3to2"):
+        conv("flownet." + name, 2, 2, 4, gain=1.0, transposed=True)
+    conv("embednet.embed_conv1", 512, 1024, 1)
+    conv("embednet.embed_conv2", 512, 512, 3)
+    conv("embednet.embed_conv3", 2048, 512, 1)
+    pooled_c = 256 if reduce_channel else 2048
+    sd[FE + "fc6.weight"] = _kaiming_uniform(gen, (1024, pooled_c * 49))
+    sd[FE + "fc6.bias"] = _normal(gen, (1024,), 0.01)
+    sd[FE + "fc7.weight"] = _kaiming_uniform(gen, (1024, 1024))
+    sd[FE + "fc7.bias"] = _normal(gen, (1024,), 0.01)
+    return sd

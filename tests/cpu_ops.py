@@ -23,8 +23,10 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
     y = y.permute(0, 2, 3, 1)
     if residual is not None:
         y = y + residual.float()
-    if relu:
+    if int(relu) == 1:
         y = F.relu(y)
+    elif int(relu) == 2:
+        y = F.leaky_relu(y, 0.1)
     return y.contiguous().to(out_dtype or x.dtype)
 
 
@@ -126,7 +128,17 @@ def preprocess_frames(frames_u8, mean, to_bgr=True):
     return x - torch.tensor(mean).view(1, 3, 1, 1)
 
 
-ALL = ["conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+def avgpool2x2_ceil(x):
+    return F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+
+def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
+    out, w = mo.fgfa_aggregate(feats.float().permute(0, 3, 1, 2), flow, key, nfeat=Cf)
+    out = out[0].permute(1, 2, 0).contiguous().to(feats.dtype)
+    return (out, w[:, 0]) if want_weights else out
+
+
+ALL = ["avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames"]
 
 

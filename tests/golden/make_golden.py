@@ -13,6 +13,8 @@
 3. ref_e2e_r50.npz -- GeneralizedRCNNMEGA (R-50 MEGA config, calibrated synthetic weights from
    mega.pytorch_amd.synth, seeded synthetic 160x256 clip) run for a few key frames on CPU: final detections and
    the intermediates named in SURVEY.md 8a.
+4. ref_fgfa_r50.npz -- GeneralizedRCNNFGFA (configs/FGFA/vid_R_50_C4_FGFA_1x.yaml) on a 128x192 clip: flow field,
+   aggregated feature map, predictor logits and final detections per key frame.
 """
 import importlib.util
 import os
@@ -29,6 +31,7 @@ import ref_shim  # noqa: E402
 from mega.pytorch_amd import synth  # noqa: E402
 
 E2E = dict(H=160, W=256, T=30, nkey=4, seed_w=1, seed_clip=3, global_seed=0)
+FGFA = dict(H=128, W=192, T=14, nkey=3, seed_w=2, seed_clip=4)
 
 
 def _load_ref_test(name):
@@ -236,6 +239,46 @@ def golden_e2e():
     np.savez_compressed(os.path.join(HERE, "ref_e2e_r50.npz"), **out)
 
 
+def golden_fgfa():
+    c = FGFA
+    cfg = ref_shim.make_cfg("configs/FGFA/vid_R_50_C4_FGFA_1x.yaml")
+    model = ref_shim.build_model(cfg)
+    model.load_state_dict(synth.make_fgfa_state_dict(seed=c["seed_w"]), strict=True)
+    frames = synth.preprocess_cpu(synth.make_clip(c["T"], c["H"], c["W"], seed=c["seed_clip"]))
+    import mega_core.modeling.detector.generalized_rcnn_fgfa as gm
+
+    class _FakeImg(object):
+        def __init__(self, i): self.i = i
+        def convert(self, m): return self
+
+    class _FakeImage(object):
+        @staticmethod
+        def open(path): return _FakeImg(int(path))
+    gm.Image = _FakeImage
+    trace = {}
+    model.flownet.register_forward_hook(lambda m, i, o: trace.update(flow=o.detach().clone()))
+    model.rpn.register_forward_hook(lambda m, i, o: trace.update(feats=i[1][0].detach().clone()))
+    model.roi_heads.box.predictor.register_forward_hook(
+        lambda m, i, o: trace.update(logits=o[0].detach().clone(), deltas=o[1].detach().clone()))
+    out = {}
+    for idx in range(c["nkey"]):
+        images = {"cur": frames[idx], "ref": [frames[min(c["T"] - 1, idx + 9)]], "frame_category": 0 if idx == 0 else 1,
+                  "seg_len": c["T"], "pattern": "%d", "img_dir": "%s", "transforms": lambda im: frames[im.i]}
+        with torch.no_grad():
+            det = model(images)[0]
+        out["boxes%d" % idx] = det.bbox.numpy()
+        out["scores%d" % idx] = det.get_field("scores").numpy()
+        out["labels%d" % idx] = det.get_field("labels").numpy()
+        out["flow%d" % idx] = trace["flow"].numpy()
+        out["feats%d" % idx] = trace["feats"].numpy()[0, ::16]     # every 16th channel: keeps the fixture small
+        out["logits%d" % idx] = trace["logits"].numpy()
+        out["deltas%d" % idx] = trace["deltas"].numpy()
+        print("fgfa frame", idx, "dets", det.bbox.shape[0], "flow absmax", float(trace["flow"].abs().max()))
+    for k, v in c.items():
+        out["cfg_" + k] = np.int64(v)
+    np.savez_compressed(os.path.join(HERE, "ref_fgfa_r50.npz"), **out)
+
+
 if __name__ == "__main__":
     if not ref_shim.available():
         sys.exit("needs /root/reference")
@@ -243,3 +286,4 @@ if __name__ == "__main__":
     golden_from_reference_tests()
     golden_ops()
     golden_e2e()
+    golden_fgfa()

@@ -125,3 +125,31 @@ def test_reference_call_convention_of_submodules(monkeypatch):
         assert x.shape == (n, 1024)
     with pytest.raises(ValueError):
         model({"cur": img[0], "ref_l": [], "ref_g": [], "frame_category": 0, "seg_len": 1}, targets=[1])
+
+
+def test_fgfa_detector_matches_oracle(monkeypatch):
+    """GeneralizedRCNNFGFA.forward (reference call convention + ref_init) == FgfaOracle frame by frame: FlowNetS on
+    (key, frame) pairs, embedding, flow-guided warp + cosine-softmax aggregation, plain RPN, conv5+2MLP box head."""
+    import mega.pytorch_amd.fgfa  # noqa: F401
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    H, W, T, nkey = 96, 128, 12, 2
+    cfg = config.get_cfg("R-50", "fgfa")
+    cfg.MODEL.DEVICE = "cpu"
+    sd = synth.make_fgfa_state_dict(seed=3)
+    model = modeling.build_detection_model(cfg)
+    assert type(model).__name__ == "GeneralizedRCNNFGFA"
+    model.load_state_dict(sd)
+    frames = synth.preprocess_cpu(synth.make_clip(T, H, W, seed=6))
+    orc = mo.FgfaOracle(sd, mo.OracleCfg(blocks=(3, 4, 6), reduce_channel=True, nms_strict_gt=True))
+    for idx in range(nkey):
+        images = {"cur": frames[idx], "ref": [frames[min(T - 1, idx + 9)]], "frame_category": 0 if idx == 0 else 1,
+                  "seg_len": T, "ref_init": [frames[i] for i in range(1, 10)]}
+        with torch.no_grad():
+            det = model(images)[0]
+            wb, ws, wl = orc.forward_frame(frames[idx:idx + 1], 0 if idx == 0 else 1, ref=frames[min(T - 1, idx + 9)][None],
+                                           seg_len=T, frame_loader=lambda i: frames[i][None])
+        assert len(det) == wb.shape[0]
+        assert torch.equal(det.get_field("labels"), wl)
+        assert (det.bbox - wb).abs().max() < 5e-3
+        assert (det.get_field("scores") - ws).abs().max() < 1e-5

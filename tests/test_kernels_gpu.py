@@ -37,6 +37,8 @@ CONV_CASES = [
     (2, 150, 250, 64, 64, 1, 1, 0, 1, True, False),      # one K-tile (bf16), many blocks: LDS re-use races show up
     (2, 150, 250, 64, 64, 3, 1, 1, 1, True, False),      # odd K-tile count (9)
     (2, 75, 125, 64, 256, 1, 1, 0, 1, False, True),
+    (3, 32, 48, 8, 64, 7, 2, 3, 1, 2, False),            # FlowNetS conv1 (padded Cin 6->8), LeakyReLU(0.1) epilogue
+    (2, 9, 13, 192, 128, 4, 1, 3, 1, 2, False),          # zero-stuffed deconv as a 4x4 conv with pad 3
 ]
 
 
@@ -58,7 +60,7 @@ def test_conv2d_nhwc(dev, case, dtype):
         res = torch.randn(ref.shape, generator=g).to(dtype)
         ref = ref + res.float()
     if relu:
-        ref = F.relu(ref)
+        ref = F.leaky_relu(ref, 0.1) if relu == 2 else F.relu(ref)
     out = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev),
                           w.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev), scale.to(dev), bias.to(dev),
                           None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev),
@@ -302,3 +304,15 @@ def test_fgfa_warp_aggregate(dev, dtype, shape):
     assert (w.cpu() - want_w[:, 0]).abs().max() < (2e-5 if dtype == torch.float32 else 2e-3)
     err = _relerr(out.float().cpu().permute(2, 0, 1)[None], want)
     assert err < (1e-5 if dtype == torch.float32 else 1e-2), err
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 7, 9, 8), (3, 38, 63, 32), (1, 1, 5, 8)])
+def test_avgpool2x2_ceil(dev, dtype, shape):
+    """F.avg_pool2d(x, 2, stride=2, ceil_mode=True) (flownet.py:55,117): edge windows divide by the in-bounds count."""
+    ops = _ops()
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(7)).to(dtype)
+    ref = F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, stride=2, ceil_mode=True).permute(0, 2, 3, 1)
+    got = ops.avgpool2x2_ceil(x.to(dev)).float().cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() < (1e-6 if dtype == torch.float32 else 2e-2)
