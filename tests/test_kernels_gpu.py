@@ -37,7 +37,7 @@ CONV_CASES = [
     (2, 150, 250, 64, 64, 1, 1, 0, 1, True, False),      # one K-tile (bf16), many blocks: LDS re-use races show up
     (2, 150, 250, 64, 64, 3, 1, 1, 1, True, False),      # odd K-tile count (9)
     (2, 75, 125, 64, 256, 1, 1, 0, 1, False, True),
-    (3, 32, 48, 8, 64, 7, 2, 3, 1, 2, False),            # FlowNetS conv1 (padded Cin 6->8), LeakyReLU(0.1) epilogue
+    (3, 32, 48, 64, 64, 7, 2, 3, 1, 2, False),           # FlowNetS conv1 (Cin zero-padded 6->64), LeakyReLU(0.1) epilogue
     (2, 9, 13, 192, 128, 4, 1, 3, 1, 2, False),          # zero-stuffed deconv as a 4x4 conv with pad 3
 ]
 
