@@ -40,7 +40,8 @@ class CfgNode(dict):
 def get_cfg(arch="R-101", method="mega"):
     """Test-time defaults.  arch: 'R-101' | 'R-50'; method: 'mega' (configs/MEGA/vid_R_{101,50}_C4_MEGA_1x.yaml)
     or 'fgfa' (configs/FGFA/vid_R_{101,50}_C4_FGFA_1x.yaml: GeneralizedRCNNFGFA +
-    ResNetConv52MLPFeatureExtractor, no relation attention)."""
+    ResNetConv52MLPFeatureExtractor, no relation attention) or 'base' (configs/vid_R_{50,101}_C4_1x.yaml: the
+    single-frame GeneralizedRCNN, BASELINE config 1)."""
     r50 = arch in ("R-50", "R-50-C4")
     cfg = _mega_cfg(r50)
     if method == "fgfa":
@@ -48,8 +49,13 @@ def get_cfg(arch="R-101", method="mega"):
         cfg.MODEL.VID.METHOD = "fgfa"
         cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "ResNetConv52MLPFeatureExtractor"
         cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ENABLE = False
+    elif method == "base":
+        cfg.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"
+        cfg.MODEL.VID.METHOD = "base"
+        cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "ResNetConv52MLPFeatureExtractor"
+        cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ENABLE = False
     elif method != "mega":
-        raise ValueError("method must be 'mega' or 'fgfa'")
+        raise ValueError("method must be 'mega', 'fgfa' or 'base'")
     return cfg
 
 

@@ -321,3 +321,39 @@ class GeneralizedRCNNFGFA(nn.Module):
 
 
 DETECTION_META_ARCHITECTURES.register("GeneralizedRCNNFGFA", GeneralizedRCNNFGFA)
+
+
+class GeneralizedRCNN(nn.Module):
+    """detector/generalized_rcnn.py:16-65, inference (BASELINE config 1, configs/vid_R_50_C4_1x.yaml): single frame,
+    backbone -> RPN -> box head (ResNetConv52MLPFeatureExtractor); no cross-frame state."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.dtype = compute_dtype(cfg)
+        self.backbone = build_backbone(cfg)
+        self.rpn = build_rpn(cfg, self.backbone.out_channels)
+        self.roi_heads = CombinedROIHeads(cfg, [("box", ROIBoxHead(cfg, self.backbone.out_channels))])
+        self.eval()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        for m in self.modules():
+            if isinstance(m, _Packed):
+                m._pk = None
+        return out
+
+    @torch.no_grad()
+    def forward(self, images, targets=None):
+        if targets is not None:
+            raise ValueError("In testing mode, targets should be None")
+        il = to_image_list(images)
+        il = type(il)(il.tensors.to(self.device).float(), il.image_sizes)
+        features = self.backbone(il.tensors)
+        proposals, _ = self.rpn(il, features, None)
+        _, result, _ = self.roi_heads(features, proposals, None)
+        return result
+
+
+DETECTION_META_ARCHITECTURES.register("GeneralizedRCNN", GeneralizedRCNN)

@@ -239,6 +239,32 @@ def golden_e2e():
     np.savez_compressed(os.path.join(HERE, "ref_e2e_r50.npz"), **out)
 
 
+def golden_base():
+    """ref_base_r50.npz: single-frame GeneralizedRCNN (configs/vid_R_50_C4_1x.yaml, BASELINE config 1)."""
+    c = FGFA
+    cfg = ref_shim.make_cfg("configs/vid_R_50_C4_1x.yaml")
+    model = ref_shim.build_model(cfg)
+    sd = {k: v for k, v in synth.make_fgfa_state_dict(seed=c["seed_w"]).items()
+          if not k.startswith(("flownet.", "embednet."))}
+    model.load_state_dict(sd, strict=True)
+    frames = synth.preprocess_cpu(synth.make_clip(c["T"], c["H"], c["W"], seed=c["seed_clip"]))
+    trace = {}
+    model.roi_heads.box.predictor.register_forward_hook(
+        lambda m, i, o: trace.update(logits=o[0].detach().clone(), deltas=o[1].detach().clone()))
+    out = {}
+    for idx in range(2):
+        with torch.no_grad():
+            det = model(frames[idx])[0]
+        out["boxes%d" % idx] = det.bbox.numpy()
+        out["scores%d" % idx] = det.get_field("scores").numpy()
+        out["labels%d" % idx] = det.get_field("labels").numpy()
+        out["logits%d" % idx] = trace["logits"].numpy()
+        out["deltas%d" % idx] = trace["deltas"].numpy()
+    for k, v in c.items():
+        out["cfg_" + k] = np.int64(v)
+    np.savez_compressed(os.path.join(HERE, "ref_base_r50.npz"), **out)
+
+
 def golden_fgfa():
     c = FGFA
     cfg = ref_shim.make_cfg("configs/FGFA/vid_R_50_C4_FGFA_1x.yaml")
@@ -287,3 +313,4 @@ if __name__ == "__main__":
     golden_ops()
     golden_e2e()
     golden_fgfa()
+    golden_base()

@@ -153,3 +153,49 @@ def test_fgfa_detector_matches_oracle(monkeypatch):
         assert torch.equal(det.get_field("labels"), wl)
         assert (det.bbox - wb).abs().max() < 5e-3
         assert (det.get_field("scores") - ws).abs().max() < 1e-5
+
+
+def test_base_detector_matches_oracle(monkeypatch):
+    """single-frame GeneralizedRCNN (BASELINE config 1) on the CPU twins == BaseOracle."""
+    cpu_ops.install(monkeypatch)
+    cfg = config.get_cfg("R-50", "base")
+    cfg.MODEL.DEVICE = "cpu"
+    sd = {k: v for k, v in synth.make_fgfa_state_dict(seed=3).items() if not k.startswith(("flownet.", "embednet."))}
+    model = modeling.build_detection_model(cfg)
+    assert type(model).__name__ == "GeneralizedRCNN"
+    model.load_state_dict(sd)
+    frames = synth.preprocess_cpu(synth.make_clip(1, 96, 128, seed=6))
+    orc = mo.BaseOracle(sd, mo.OracleCfg(blocks=(3, 4, 6), reduce_channel=True, nms_strict_gt=True))
+    with torch.no_grad():
+        det = model(frames[0])[0]
+        wb, ws, wl = orc.forward_frame(frames[0:1])
+    assert len(det) == wb.shape[0] and torch.equal(det.get_field("labels"), wl)
+    assert (det.bbox - wb).abs().max() < 5e-3 and (det.get_field("scores") - ws).abs().max() < 1e-5
+
+
+def test_mega_short_window_config_matches_oracle(monkeypatch):
+    """BASELINE config 2 ("10 local + 10 global"): ALL_FRAME_INTERVAL 11, KEY_FRAME_LOCATION 5, offsets -5..5."""
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    H, W, T, nkey = 96, 128, 12, 3
+    cfg = _small_cfg()
+    cfg.merge_from_list(["MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 11, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 5,
+                         "MODEL.VID.MEGA.MIN_OFFSET", -5, "MODEL.VID.MEGA.MAX_OFFSET", 5])
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    model = modeling.build_detection_model(cfg)
+    model.load_state_dict(sd)
+    frames = synth.preprocess_cpu(synth.make_clip(T, H, W, seed=2))
+    _, gfor = mo.global_frame_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
+    orc = mo.MegaOracle(sd, mo.OracleCfg(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, nms_strict_gt=True,
+                                         all_frame_interval=11, key_frame_location=5))
+    for idx in range(nkey):
+        nxt = min(T - 1, idx + 5)
+        images = {"cur": frames[idx], "ref_l": [frames[nxt]], "ref_g": [frames[g] for g in gfor(idx)],
+                  "frame_category": 0 if idx == 0 else 1, "seg_len": T, "ref_l_init": [frames[i] for i in range(1, 6)]}
+        with torch.no_grad():
+            det = model(images)[0]
+            wb, ws, wl = orc.forward_frame(frames[idx:idx + 1], 0 if idx == 0 else 1, ref_l=frames[nxt][None],
+                                           ref_g=[frames[g][None] for g in gfor(idx)], seg_len=T,
+                                           frame_loader=lambda i: frames[i][None])
+        assert len(det) == wb.shape[0] and torch.equal(det.get_field("labels"), wl)
+        assert (det.bbox - wb).abs().max() < 5e-3 and (det.get_field("scores") - ws).abs().max() < 1e-5
