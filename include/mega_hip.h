@@ -135,6 +135,16 @@ size_t mega_relation_attention_workspace_bytes(int Nq, int Nk, int groups);
 int mega_preprocess_frames(const unsigned char* in, float* out, int N, int H, int W, float mean0, float mean1,
                            float mean2, int to_bgr, void* stream);
 
+/* Test-time Resize on device: PIL / torchvision F.resize(BILINEAR) of uint8 HWC frames,
+ * [N][Hi][Wi][3] -> [N][Ho][Wo][3], bit-identical to Pillow's 8-bit resampler (libImaging/Resample.c): horizontal
+ * pass to uint8 (tmp [N][Hi][Wo][3], needed only when both dimensions change), then vertical.  bounds_* = int
+ * [out][2] (first tap, tap count), coef_* = int [out][ksize] fixed-point (<<22) taps, both prepared on the host
+ * (mega.pytorch_amd.feed.pil_bilinear_coeffs).  A pass whose size is unchanged is skipped, as in PIL.  Replaces
+ * mega_core/data/transforms/transforms.py:27-66 (Resize.__call__ -> F.resize). */
+int mega_resize_bilinear_u8(const unsigned char* in, unsigned char* out, unsigned char* tmp, int N, int Hi, int Wi,
+                            int Ho, int Wo, const int* bounds_h, const int* coef_h, int ksize_h, const int* bounds_v,
+                            const int* coef_v, int ksize_v, void* stream);
+
 /* FGFA flow-guided aggregation (BASELINE configs[4]): bilinear warp of T frames' [features | embeddings] by their
  * flow fields (F.grid_sample bilinear / border / align_corners=False), cosine-similarity weights of the embeddings
  * against the key frame's, softmax over frames, weighted feature sum -- one fused kernel.  Replaces

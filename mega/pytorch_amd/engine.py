@@ -95,7 +95,10 @@ class ClipEngine(object):
 
     # ------------------------------------------------------------------ frame stage (optionally sharded)
     def _frames(self, clip, ids):
-        """clip: uint8 [T,H,W,3] (device) -> preprocessed f32 [n,3,H,W]; or already-preprocessed f32 [T,3,H,W]."""
+        """clip: uint8 [T,H,W,3] (device) -> preprocessed f32 [n,3,H,W]; or already-preprocessed f32 [T,3,H,W];
+        or a feed.FrameSource (decodes on host threads, resizes on the device)."""
+        if hasattr(clip, "fetch"):
+            return ops.preprocess_frames(clip.fetch(list(ids)).contiguous(), self.mean, self.to_bgr)
         if clip.is_cuda:   # pinned + non_blocking: the host must not wait for the work already queued on the stream
             idx = torch.tensor(ids, dtype=torch.int64).pin_memory().to(clip.device, non_blocking=True)
         else:
@@ -144,7 +147,7 @@ class ClipEngine(object):
         padded = jobs + [jobs[-1]] * (per * self.world - n)
         mine = padded[self.rank * per:(self.rank + 1) * per]
         st = self._frame_stage(self._frames(clip, [j[0] for j in mine]), [j[1] for j in mine])
-        K, dev = m.key_num, clip.device
+        K, dev = m.key_num, st["props"].device
         feats = torch.zeros((per, K, st["feats"].shape[1]), dtype=st["feats"].dtype, device=dev)
         o = 0
         for i, w in enumerate(st["want"]):
@@ -207,6 +210,14 @@ class ClipEngine(object):
             idx = hi
         out = []
         pp = m.roi_heads.box.post_processor
+
+        def prefetch(bi):      # host decodes of a later batch start while this one is being enqueued
+            if hasattr(clip, "prefetch") and bi < len(batches):
+                jobs = [j for i in range(*batches[bi]) for j in self.jobs_for_step(i, T, gfor)]
+                if self.world > 1:     # only this rank's slice of the frame stage (same slicing as records_async)
+                    per = (len(jobs) + self.world - 1) // self.world
+                    jobs = (jobs + [jobs[-1]] * (per * self.world - len(jobs)))[self.rank * per:(self.rank + 1) * per]
+                clip.prefetch([j[0] for j in jobs])
 
         def frame_stage(b):
             per_step = [self.jobs_for_step(i, T, gfor) for i in range(b[0], b[1])]
@@ -274,10 +285,13 @@ class ClipEngine(object):
 
         import time as _time
         ht = self.host_times
+        prefetch(0)
+        prefetch(1)
         staged = frame_stage(batches[0]) if batches else None
         prev_pending = None
         for bi, b in enumerate(batches):
             t0 = _time.perf_counter()
+            prefetch(bi + 2)
             nxt = frame_stage(batches[bi + 1]) if bi + 1 < len(batches) else None   # F(b+1): async, enqueued first
             t1 = _time.perf_counter()
             pending = aggregate(b, *staged)                                        # B(b): runs beside F(b+1)

@@ -1,0 +1,202 @@
+"""Test-time loop and result gathering: the step AFTER the hot path.
+
+Mirror of  mega_core/engine/inference.py:17-47   compute_on_dataset
+           mega_core/engine/inference.py:50-69   _accumulate_predictions_from_multiple_gpus
+           mega_core/engine/inference.py:72-134  inference  (writes <output_folder>/predictions.pth, :119)
+           mega_core/data/datasets/vid.py:55-66  the 4-column VID index file  ("dir  global_id  seg_id  seg_len")
+           mega_core/data/samplers/distributed.py VIDTestDistributedSampler (whole videos per rank)
+
+What changes on MI355X: a video is not fed key frame by key frame through a DataLoader; each video becomes a
+feed.FrameSource driven by ClipEngine (batched frame stage, two streams, hipGraph).  Detections stay on the device
+until the video is finished, then move to the host in one go (the reference does a blocking .to(cpu) per frame).
+
+What does NOT change: the result.  `predictions` is a list[BoxList] indexed by dataset index (line number of the
+index file), boxes in the resized frame's coordinates with fields "scores" / "labels", and predictions.pth unpickles
+inside the reference as mega_core.structures.bounding_box.BoxList objects, so tools/test_prediction.py and the VID
+evaluation keep working on it.
+
+Multi-GPU: videos are independent, so ranks take whole videos (the reference's sampler policy) with NO collective
+on the data path; the only exchange is the final gather of the per-rank {index: BoxList} dicts.
+"""
+import contextlib
+import logging
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+from . import engine as _engine
+from . import feed
+from .structures import BoxList
+
+_REF_MODULE = "mega_core.structures.bounding_box"
+
+
+class VIDTestIndex(object):
+    """vid.py:55-66 for the test split: parses the index file into per-video records; dataset index = line number."""
+
+    def __init__(self, img_index):
+        with open(img_index) as f:
+            lines = [x.strip().split(" ") for x in f.readlines() if x.strip()]
+        if not lines or len(lines[0]) != 4:
+            raise ValueError("expected the 4-column VID index format: '<video dir> <id> <frame_seg_id> <frame_seg_len>'")
+        self.image_set_index = ["%s/%06d" % (x[0], int(x[2])) for x in lines]
+        self.pattern = [x[0] + "/%06d" for x in lines]
+        self.frame_seg_id = [int(x[2]) for x in lines]
+        self.frame_seg_len = [int(x[3]) for x in lines]
+        self.videos = []        # {"start": dataset index of frame 0, "pattern", "seg_len"}
+        for idx, sid in enumerate(self.frame_seg_id):
+            if sid == 0:
+                self.videos.append({"start": idx, "pattern": self.pattern[idx], "seg_len": self.frame_seg_len[idx]})
+        for v in self.videos:   # the reference's sampler and state machine both assume contiguous, complete videos
+            ids = self.frame_seg_id[v["start"]:v["start"] + v["seg_len"]]
+            if ids != list(range(v["seg_len"])):
+                raise ValueError("video %s is not listed contiguously from frame 0" % v["pattern"])
+
+    def __len__(self):
+        return len(self.image_set_index)
+
+
+def videos_for_rank(videos, rank, world):
+    """Whole videos per rank, contiguous chunks balanced by frame count (VIDTestDistributedSampler's policy:
+    a video never straddles two ranks)."""
+    if world == 1:
+        return list(videos)
+    total = sum(v["seg_len"] for v in videos)
+    out, acc, r = [], 0, 0
+    for v in videos:
+        # a video goes to the rank whose share its midpoint falls into
+        mid = acc + v["seg_len"] / 2.0
+        r = min(world - 1, int(mid * world / total))
+        if r == rank:
+            out.append(v)
+        acc += v["seg_len"]
+    return out
+
+
+def compute_on_dataset(model, index, img_dir, device, videos=None, steps_per_batch=10, seed=0, timer=None,
+                       source_kwargs=None, engine_kwargs=None):
+    """inference.py:17-47: -> {dataset index: BoxList on the host}."""
+    model.eval()
+    results = {}
+    videos = index.videos if videos is None else videos
+    eng = _engine.ClipEngine(model, steps_per_batch=steps_per_batch, **(engine_kwargs or {}))
+    gsize = model.cfg.MODEL.VID.MEGA.GLOBAL.SIZE
+    for vi, v in enumerate(videos):
+        src = feed.FrameSource(os.path.join(img_dir, "%s.JPEG"), v["pattern"], v["seg_len"], device,
+                               min_size=model.cfg.INPUT.MIN_SIZE_TEST, max_size=model.cfg.INPUT.MAX_SIZE_TEST,
+                               **(source_kwargs or {}))
+        t0 = time.perf_counter()
+        # vid_mega.py:21-24 shuffles with numpy's global RNG; seeded per video here so runs are reproducible
+        gfor = _engine.global_schedule(v["seg_len"], gsize, seed=seed + v["start"])
+        dets = eng.run(src, v["seg_len"], gfor)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        if timer is not None:
+            timer["inference_s"] = timer.get("inference_s", 0.0) + time.perf_counter() - t0
+        for i, det in enumerate(dets):
+            results[v["start"] + i] = det.to("cpu")
+        src.close()
+    return results
+
+
+def accumulate_predictions(predictions_per_rank, group=None):
+    """inference.py:50-69: gather the per-rank dicts, merge, order by dataset index (main process only)."""
+    dist = torch.distributed
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        gathered = [None] * dist.get_world_size(group)
+        dist.all_gather_object(gathered, predictions_per_rank, group=group)
+        if dist.get_rank(group) != 0:
+            return None
+    else:
+        gathered = [predictions_per_rank]
+    predictions = {}
+    for p in gathered:
+        predictions.update(p)
+    image_ids = list(sorted(predictions.keys()))
+    if image_ids and len(image_ids) != image_ids[-1] + 1:
+        logging.getLogger("mega.pytorch_amd.inference").warning(
+            "Number of images that were gathered from multiple processes is not a contiguous set. "
+            "Some images might be missing from the evaluation")
+    return [predictions[i] for i in image_ids]
+
+
+@contextlib.contextmanager
+def _reference_boxlist_module(cls):
+    """Make `mega_core.structures.bounding_box.BoxList` resolvable for the duration of a pickle dump / load when the
+    reference package itself is not importable (it is a plain attribute container on disk: bbox, size, mode,
+    extra_fields -- bounding_box.py:20-36)."""
+    if _REF_MODULE in sys.modules:
+        yield getattr(sys.modules[_REF_MODULE], "BoxList")
+        return
+    added = []
+    parts = _REF_MODULE.split(".")
+    for i in range(1, len(parts) + 1):
+        name = ".".join(parts[:i])
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+            added.append(name)
+    sys.modules[_REF_MODULE].BoxList = cls
+    try:
+        yield cls
+    finally:
+        for name in added:
+            sys.modules.pop(name, None)
+
+
+def save_predictions(predictions, path):
+    """torch.save(list[BoxList]) whose pickled class is the reference's BoxList (inference.py:119)."""
+    shadow = type("BoxList", (object,), {"__module__": _REF_MODULE})
+    with _reference_boxlist_module(shadow) as ref_cls:
+        out = []
+        for p in predictions:
+            o = ref_cls.__new__(ref_cls)
+            o.__dict__.update({"bbox": p.bbox, "size": tuple(p.size), "mode": p.mode,
+                               "extra_fields": dict(p.extra_fields)})
+            out.append(o)
+        torch.save(out, path)
+
+
+def load_predictions(path):
+    """Read a predictions.pth written by this package OR by the reference -> list of this package's BoxList."""
+    shadow = type("BoxList", (object,), {"__module__": _REF_MODULE})
+    with _reference_boxlist_module(shadow):
+        raw = torch.load(path, map_location="cpu", weights_only=False)
+    out = []
+    for r in raw:
+        b = BoxList(r.bbox, tuple(r.size), r.mode)
+        for k, v in r.extra_fields.items():
+            b.add_field(k, v)
+        out.append(b)
+    return out
+
+
+def inference(cfg, model, img_dir, img_index, output_folder=None, device=None, group=None, **kw):
+    """inference.py:72-134 up to (and including) predictions.pth; evaluation itself (datasets/evaluation) is the
+    reference's and consumes the returned list / the file unchanged."""
+    logger = logging.getLogger("mega.pytorch_amd.inference")
+    device = torch.device(cfg.MODEL.DEVICE if device is None else device)
+    dist = torch.distributed
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    index = VIDTestIndex(img_index)
+    mine = videos_for_rank(index.videos, rank, world)
+    timer = {}
+    t0 = time.perf_counter()
+    preds = compute_on_dataset(model, index, img_dir, device, videos=mine, timer=timer, **kw)
+    if world > 1:
+        dist.barrier(group=group)
+    total = time.perf_counter() - t0
+    logger.info("Total run time: %.1f s (%.4f s / img per device, on %d devices)", total,
+                total * world / max(1, len(index)), world)
+    logger.info("Model inference time: %.1f s", timer.get("inference_s", 0.0))
+    predictions = accumulate_predictions(preds, group)
+    if predictions is None:
+        return None
+    if output_folder:
+        os.makedirs(output_folder, exist_ok=True)
+        save_predictions(predictions, os.path.join(output_folder, "predictions.pth"))
+    return predictions

@@ -284,6 +284,25 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     return out
 
 
+def resize_bilinear_u8(frames_u8, out_hw, tables):
+    """uint8 [N,Hi,Wi,3] -> [N,Ho,Wo,3], Pillow-exact BILINEAR.  tables = feed.ResizeTables (device coefficient tables)."""
+    _gpu(frames_u8)
+    lib = _lib.load()
+    N, Hi, Wi, C = frames_u8.shape
+    Ho, Wo = out_hw
+    assert C == 3 and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+    assert tables.in_hw == (Hi, Wi) and tables.out_hw == (Ho, Wo)
+    out = torch.empty((N, Ho, Wo, 3), dtype=torch.uint8, device=frames_u8.device)
+    tmp = torch.empty((N, Hi, Wo, 3), dtype=torch.uint8, device=frames_u8.device) if (Hi != Ho and Wi != Wo) else None
+    _tok = _pb("resize", 0.0, frames_u8.numel() + out.numel() * 3)
+    rc = lib.mega_resize_bilinear_u8(_ptr(frames_u8), _ptr(out), _ptr(tmp), N, Hi, Wi, Ho, Wo, _ptr(tables.bounds_h),
+                                     _ptr(tables.coef_h), tables.ksize_h, _ptr(tables.bounds_v), _ptr(tables.coef_v),
+                                     tables.ksize_v, _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_resize_bilinear_u8")
+    return out
+
+
 def preprocess_frames(frames_u8, mean, to_bgr=True):
     """uint8 [N,H,W,3] RGB -> f32 [N,3,H,W] (BGR*255 - mean)."""
     _gpu(frames_u8)

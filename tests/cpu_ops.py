@@ -138,8 +138,14 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
     return (out, w[:, 0]) if want_weights else out
 
 
-ALL = ["avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+ALL = ["resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames"]
+
+
+def resize_bilinear_u8(frames_u8, out_hw, tables=None):
+    from oracle import pil_resize
+    a = frames_u8.numpy()
+    return torch.from_numpy(np.stack([pil_resize.resize_bilinear_u8(f, out_hw[0], out_hw[1]) for f in a]))
 
 
 def install(monkeypatch):

@@ -265,6 +265,34 @@ def golden_base():
     np.savez_compressed(os.path.join(HERE, "ref_base_r50.npz"), **out)
 
 
+def golden_feed():
+    """ref_feed.npz: the reference's test-time transform chain (data/transforms/build.py:26-45 with the default
+    INPUT.* of config/defaults.py) on VID-like frame sizes (Resize.get_size) and on one seeded frame (full chain).
+    torchvision is absent here, so its three functional calls the chain makes are bound to the exact Pillow / torch
+    calls torchvision implements them with (F.resize -> PIL resize BILINEAR, F.to_tensor -> HWC u8 / 255 -> CHW,
+    F.normalize -> (x - mean) / std)."""
+    import types
+    from PIL import Image
+    cfg = ref_shim.make_cfg("configs/MEGA/vid_R_101_C4_MEGA_1x.yaml")     # installs the import shims
+    import mega_core.data.transforms.transforms as T
+    Fm = types.SimpleNamespace(
+        resize=lambda img, size: img.resize(size[::-1], Image.BILINEAR),
+        to_tensor=lambda img: torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float().div(255),
+        normalize=lambda t, mean, std: (t - torch.tensor(mean).view(-1, 1, 1)) / torch.tensor(std).view(-1, 1, 1))
+    T.F = Fm
+    chain = T.Compose([T.Resize(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST), T.ToTensor(),
+                       T.Normalize(mean=cfg.INPUT.PIXEL_MEAN, std=cfg.INPUT.PIXEL_STD, to_bgr255=cfg.INPUT.TO_BGR255)])
+    sizes = [(1280, 720), (480, 360), (1920, 1080), (1000, 600), (375, 500), (211, 97), (1000, 333), (640, 480),
+             (500, 500), (320, 240), (1280, 704), (718, 480)]
+    rs = T.Resize(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+    out = {"sizes_wh": np.array(sizes), "get_size_hw": np.array([rs.get_size(s) for s in sizes])}
+    img = synth.make_clip(1, 360, 480, seed=11)[0].numpy()
+    t, _ = chain(Image.fromarray(img), None)
+    out["img"] = img
+    out["transformed"] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_feed.npz"), **out)
+
+
 def golden_fgfa():
     c = FGFA
     cfg = ref_shim.make_cfg("configs/FGFA/vid_R_50_C4_FGFA_1x.yaml")
@@ -314,3 +342,4 @@ if __name__ == "__main__":
     golden_e2e()
     golden_fgfa()
     golden_base()
+    golden_feed()

@@ -1,0 +1,142 @@
+"""Test-time loop + result gathering: index parsing, video-per-rank partition, predictions.pth in
+the reference's on-disk format, and the world-size-2 gather over gloo."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from mega.pytorch_amd import config, engine, inference, modeling, synth  # noqa: E402
+from oracle import pil_resize  # noqa: E402
+
+VIDEOS = [("val/vid_a", 7), ("val/vid_b", 5)]
+H0, W0, MIN_S, MAX_S = 60, 100, 96, 160
+
+
+def _make_dataset(root):
+    """two tiny videos as <root>/Data/<video>/<%06d>.JPEG (lossless PNG payload: Pillow sniffs the content) plus the
+    4-column index file the reference's VIDDataset reads (vid.py:55-66)."""
+    from PIL import Image
+    lines, clips, n = [], {}, 1
+    for vi, (name, L) in enumerate(VIDEOS):
+        os.makedirs(os.path.join(root, "Data", name))
+        clip = synth.make_clip(L, H0, W0, seed=20 + vi).numpy()
+        clips[name] = clip
+        for t in range(L):
+            Image.fromarray(clip[t]).save(os.path.join(root, "Data", name, "%06d.JPEG" % t), format="PNG")
+            lines.append("%s %d %d %d" % (name, n, t, L))
+            n += 1
+    idx = os.path.join(root, "index.txt")
+    with open(idx, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return os.path.join(root, "Data"), idx, clips
+
+
+def _model():
+    cfg = config.get_cfg("R-50")
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = MIN_S, MAX_S
+    m = modeling.build_detection_model(cfg)
+    m.load_state_dict(synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5))
+    return cfg, m
+
+
+def _install_cpu_ops():
+    sys.path.insert(0, HERE)
+    import cpu_ops
+    from mega.pytorch_amd import ops
+    for name in cpu_ops.ALL:
+        setattr(ops, name, getattr(cpu_ops, name))
+
+
+def test_index_and_rank_partition(tmp_path):
+    _, idx, _ = _make_dataset(str(tmp_path))
+    index = inference.VIDTestIndex(idx)
+    assert len(index) == 12 and [v["start"] for v in index.videos] == [0, 7]
+    assert index.image_set_index[8] == "val/vid_b/000001" and index.videos[1]["pattern"] == "val/vid_b/%06d"
+    parts = [inference.videos_for_rank(index.videos, r, 2) for r in range(2)]
+    assert sorted(v["start"] for p in parts for v in p) == [0, 7] and all(len(p) == 1 for p in parts)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("a 1 1 3\na 2 0 3\n")
+    with pytest.raises(ValueError):
+        inference.VIDTestIndex(str(bad))
+
+
+def test_inference_writes_reference_format_predictions(monkeypatch, tmp_path):
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    img_dir, idx, clips = _make_dataset(str(tmp_path))
+    cfg, model = _model()
+    out = str(tmp_path / "out")
+    preds = inference.inference(cfg, model, img_dir, idx, output_folder=out, steps_per_batch=3,
+                                engine_kwargs={"overlap": False, "graphs": False}, source_kwargs={"workers": 2})
+    assert len(preds) == 12
+    # same detections as the engine on the pre-resized resident clip of each video
+    _, model2 = _model()
+    start = 0
+    for name, L in VIDEOS:
+        clip = torch.from_numpy(np.stack([pil_resize.resize_bilinear_u8(f, MIN_S, MAX_S) for f in clips[name]]))
+        ref = engine.ClipEngine(model2, steps_per_batch=2, overlap=False, graphs=False).run(
+            clip, L, engine.global_schedule(L, 10, seed=start))
+        for i, r in enumerate(ref):
+            p = preds[start + i]
+            assert p.size == (MAX_S, MIN_S) and torch.equal(p.bbox, r.bbox)
+            assert torch.equal(p.get_field("scores"), r.get_field("scores"))
+            assert torch.equal(p.get_field("labels"), r.get_field("labels")) and p.get_field("labels").dtype == torch.int64
+        start += L
+    # round trip through the file
+    back = inference.load_predictions(os.path.join(out, "predictions.pth"))
+    assert len(back) == 12 and all(torch.equal(a.bbox, b.bbox) for a, b in zip(back, preds))
+    # ... and the reference itself unpickles it as ITS BoxList (the reference cannot travel to the GPU box)
+    import ref_shim
+    if ref_shim.available():
+        ref_shim.install()
+        from mega_core.structures.bounding_box import BoxList as RefBoxList
+        loaded = torch.load(os.path.join(out, "predictions.pth"), weights_only=False)
+        assert all(type(b) is RefBoxList for b in loaded)
+        assert loaded[3].mode == "xyxy" and loaded[3].size == (MAX_S, MIN_S)
+        assert torch.equal(loaded[3].get_field("scores"), preds[3].get_field("scores"))
+        assert len(loaded[3]) == len(preds[3]) and loaded[3].resize((W0, H0)).size == (W0, H0)
+
+
+def _worker(rank, world, port, root, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_cpu_ops()
+    cfg, model = _model()
+    preds = inference.inference(cfg, model, os.path.join(root, "Data"), os.path.join(root, "index.txt"),
+                                output_folder=outdir, steps_per_batch=3,
+                                engine_kwargs={"overlap": False, "graphs": False}, source_kwargs={"workers": 1})
+    assert (preds is None) == (rank != 0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_video_sharded_inference_world2(monkeypatch, tmp_path):
+    """2 ranks x 1 video each, no data-path collective; rank 0 gathers and writes the same file a single process does."""
+    root = str(tmp_path)
+    _make_dataset(root)
+    port = 31500 + os.getpid() % 2000
+    out2 = os.path.join(root, "out2")
+    mp.spawn(_worker, args=(2, port, root, out2), nprocs=2, join=True)
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    cfg, model = _model()
+    single = inference.inference(cfg, model, os.path.join(root, "Data"), os.path.join(root, "index.txt"),
+                                 steps_per_batch=3, engine_kwargs={"overlap": False, "graphs": False})
+    both = inference.load_predictions(os.path.join(out2, "predictions.pth"))
+    assert len(both) == len(single) == 12
+    for a, b in zip(both, single):
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("labels"), b.get_field("labels"))
