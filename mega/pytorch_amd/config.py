@@ -41,7 +41,8 @@ def get_cfg(arch="R-101", method="mega"):
     """Test-time defaults.  arch: 'R-101' | 'R-50'; method: 'mega' (configs/MEGA/vid_R_{101,50}_C4_MEGA_1x.yaml)
     or 'fgfa' (configs/FGFA/vid_R_{101,50}_C4_FGFA_1x.yaml: GeneralizedRCNNFGFA +
     ResNetConv52MLPFeatureExtractor, no relation attention) or 'base' (configs/vid_R_{50,101}_C4_1x.yaml: the
-    single-frame GeneralizedRCNN, BASELINE config 1)."""
+    single-frame GeneralizedRCNN, BASELINE config 1) or 'rdn' / 'rdn_base' (configs/RDN/vid_R_101_C4_RDN_1x.yaml with
+    the advanced stage / vid_R_{50,101}_C4_RDN_base_1x.yaml without)."""
     r50 = arch in ("R-50", "R-50-C4")
     cfg = _mega_cfg(r50)
     if method == "fgfa":
@@ -49,13 +50,19 @@ def get_cfg(arch="R-101", method="mega"):
         cfg.MODEL.VID.METHOD = "fgfa"
         cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "ResNetConv52MLPFeatureExtractor"
         cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ENABLE = False
+    elif method in ("rdn", "rdn_base"):
+        cfg.MODEL.META_ARCHITECTURE = "GeneralizedRCNNRDN"
+        cfg.MODEL.VID.METHOD = "rdn"
+        cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "RDNFeatureExtractor"
+        cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.STAGE = 2                    # defaults.py:409
+        cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ADVANCED_STAGE = 1 if method == "rdn" else 0
     elif method == "base":
         cfg.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"
         cfg.MODEL.VID.METHOD = "base"
         cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "ResNetConv52MLPFeatureExtractor"
         cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ENABLE = False
     elif method != "mega":
-        raise ValueError("method must be 'mega', 'fgfa' or 'base'")
+        raise ValueError("method must be 'mega', 'fgfa', 'rdn', 'rdn_base' or 'base'")
     return cfg
 
 
@@ -84,7 +91,10 @@ def _mega_cfg(r50):
                 "ENABLE": True, "METHOD": "mega",
                 "RPN": {"REF_PRE_NMS_TOP_N": 6000, "REF_POST_NMS_TOP_N": 75},
                 "ROI_BOX_HEAD": {"REDUCE_CHANNEL": bool(r50),
-                                 "ATTENTION": {"ENABLE": True, "STAGE": 3, "GROUP": 16, "EMBED_DIM": 64}},
+                                 "ATTENTION": {"ENABLE": True, "STAGE": 3, "ADVANCED_STAGE": 0, "GROUP": 16,
+                                               "EMBED_DIM": 64}},
+                "RDN": {"MIN_OFFSET": -18, "MAX_OFFSET": 18, "ALL_FRAME_INTERVAL": 37, "KEY_FRAME_LOCATION": 18,
+                        "RATIO": 0.2},
                 "FGFA": {"MIN_OFFSET": -9, "MAX_OFFSET": 9, "ALL_FRAME_INTERVAL": 19, "KEY_FRAME_LOCATION": 9},
                 "MEGA": {"MIN_OFFSET": -12, "MAX_OFFSET": 12, "ALL_FRAME_INTERVAL": 25, "KEY_FRAME_LOCATION": 12,
                          "RATIO": 0.2,

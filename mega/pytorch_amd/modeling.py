@@ -351,7 +351,7 @@ def build_rpn(cfg, in_channels):
     """rpn/rpn.py:246-262: METHOD 'mega' -> RPNWithRefModule."""
     # "mega" -> RPNWithRefModule; "fgfa" / "base" use the plain RPNModule in the reference, which is the "key" path
     # of the same module (identical parameters and proposals)
-    assert cfg.MODEL.VID.METHOD in ("mega", "fgfa", "base")
+    assert cfg.MODEL.VID.METHOD in ("mega", "rdn", "fgfa", "dff", "base")
     return RPNWithRefModule(cfg, in_channels)
 
 
@@ -643,6 +643,7 @@ class GeneralizedRCNNMEGA(nn.Module):
     rpn/inference.py:116-121, boxlist_ops.py:27-29), instead of being recomputed when the frame becomes
     the key frame (generalized_rcnn_mega.py:211, roi_box_feature_extractors.py:901-907).
     """
+    _ref_key = "ref_l"          # images[...] key of the frame entering the local window
 
     def __init__(self, cfg):
         super().__init__()
@@ -777,13 +778,13 @@ class GeneralizedRCNNMEGA(nn.Module):
             raise NotImplementedError("inference path only (training is out of scope)")
         cur = to_image_list(images["cur"]).tensors.to(self.device)
         H, W = cur.shape[-2:]
-        ref_g = [to_image_list(g).tensors.to(self.device) for g in images.get("ref_g", [])]
+        ref_g = [to_image_list(g).tensors.to(self.device) for g in images.get("ref_g", [])] if self.global_enable else []
         new_local = None
         locals_batch = []
         if images["frame_category"] == 0:
             self._reset(images["seg_len"])
             locals_batch.append(cur)
-            init = images.get("ref_l_init")          # init[j] = preprocessed frame j + 1
+            init = images.get(self._ref_key + "_init")   # init[j] = preprocessed frame j + 1
             for _ in range(self.all_frame_interval - self.key_frame_location - 1):
                 self.end_id = min(self.end_id + 1, self.seg_len - 1)
                 if self.end_id == 0:
@@ -799,7 +800,7 @@ class GeneralizedRCNNMEGA(nn.Module):
                 locals_batch.append(t.to(self.device))
         elif images["frame_category"] == 1:
             self.end_id = min(self.end_id + 1, self.seg_len - 1)
-            locals_batch.append(to_image_list(images["ref_l"][0]).tensors.to(self.device))
+            locals_batch.append(to_image_list(images[self._ref_key][0]).tensors.to(self.device))
         batch = torch.cat(locals_batch + ref_g, dim=0)
         want = [self.key_num] * len(locals_batch) + [self.base_num] * len(ref_g)
         recs = self.frame_stage(batch, want)

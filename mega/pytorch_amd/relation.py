@@ -16,13 +16,14 @@ from . import ops
 
 
 class RelationWeights(object):
-    """Kernel-ready weights of one (kind, index) attention: kind 'l_' (local/memory, with position term)
-    or 'g_' (global)."""
+    """Kernel-ready weights of one (kind, index) attention: kind 'l_' (local/memory, with position term),
+    'g_' (global) or '' (RDN: position term, no u)."""
 
     def __init__(self, sd, pfx, kind, index, dtype, device, with_pos):
         def g(name):
             return sd["%s%s%s.%d%s" % (pfx, kind, name[0], index, name[1])].detach().float()
-        u = sd["%s%sus.%d" % (pfx, kind, index)].detach().float().reshape(-1)       # [16,1,64] -> [1024]
+        ukey = "%s%sus.%d" % (pfx, kind, index)        # RDN's AttentionExtractor (kind '') has no u term
+        u = sd[ukey].detach().float().reshape(-1) if ukey in sd else 0.0             # [16,1,64] -> [1024]
         self.wq = g(("Wqs", ".weight")).to(device=device, dtype=dtype).contiguous()
         self.bq = (g(("Wqs", ".bias")) + u).to(device).contiguous()                   # u folded into the bias
         self.wk = g(("Wks", ".weight")).to(device=device, dtype=dtype).contiguous()
@@ -31,9 +32,9 @@ class RelationWeights(object):
         self.bv = g(("Wvs", ".bias")).to(device).contiguous()
         self.with_pos = with_pos
         if with_pos:
-            wg = sd["%sl_Wgs.%d.weight" % (pfx, index)].detach().float().reshape(16, 64)
+            wg = sd["%s%sWgs.%d.weight" % (pfx, kind, index)].detach().float().reshape(16, 64)
             self.wg_t = wg.t().contiguous().to(device)                                 # [64,16]
-            self.bg = sd["%sl_Wgs.%d.bias" % (pfx, index)].detach().float().to(device).contiguous()
+            self.bg = sd["%s%sWgs.%d.bias" % (pfx, kind, index)].detach().float().to(device).contiguous()
             feat_range = torch.arange(0, 64 / 8)
             self.dim_mat = torch.full((len(feat_range),), 1000.0).pow(8.0 / 64 * feat_range).to(device)
 

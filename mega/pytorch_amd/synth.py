@@ -199,3 +199,28 @@ def make_fgfa_state_dict(blocks=(3, 4, 6), reduce_channel=True, num_classes=31, 
     sd[FE + "fc7.weight"] = _kaiming_uniform(gen, (1024, 1024))
     sd[FE + "fc7.bias"] = _normal(gen, (1024,), 0.01)
     return sd
+
+
+def make_rdn_state_dict(blocks=(3, 4, 6), reduce_channel=True, base_stage=2, advanced_stage=0, num_classes=31, seed=0):
+    """Calibrated random weights with the reference's RDN state_dict layout (RDNFeatureExtractor:
+    fcs.i / Wgs.i / Wqs.i / Wks.i / Wvs.i, roi_box_feature_extractors.py:311-333)."""
+    base = make_state_dict(blocks=blocks, reduce_channel=reduce_channel, stage=1, global_res_stage=0,
+                           num_classes=num_classes, seed=seed)
+    sd = {k: v for k, v in base.items() if not any(t in k for t in (".l_", ".g_"))}
+    gen = torch.Generator().manual_seed(seed + 2000)
+    pooled_c = 256 if reduce_channel else 2048
+    n_fc = base_stage + advanced_stage
+    n_att = base_stage + advanced_stage + 1 if advanced_stage > 0 else base_stage
+    for i in range(n_fc):
+        sd["%sfcs.%d.weight" % (FE, i)] = _kaiming_uniform(gen, (1024, pooled_c * 49 if i == 0 else 1024))
+        sd["%sfcs.%d.bias" % (FE, i)] = _normal(gen, (1024,), 0.01)
+    for i in range(n_att):
+        sd["%sWgs.%d.weight" % (FE, i)] = _normal(gen, (16, 64, 1, 1), 0.05)
+        sd["%sWgs.%d.bias" % (FE, i)] = _normal(gen, (16,), 0.02)
+        sd["%sWqs.%d.weight" % (FE, i)] = _kaiming_uniform(gen, (1024, 1024)) * 0.3
+        sd["%sWqs.%d.bias" % (FE, i)] = _normal(gen, (1024,), 0.01)
+        sd["%sWks.%d.weight" % (FE, i)] = _kaiming_uniform(gen, (1024, 1024)) * 0.3
+        sd["%sWks.%d.bias" % (FE, i)] = _normal(gen, (1024,), 0.01)
+        sd["%sWvs.%d.weight" % (FE, i)] = _normal(gen, (1024, 1024, 1, 1), 0.02)
+        sd["%sWvs.%d.bias" % (FE, i)] = _normal(gen, (1024,), 0.01)
+    return sd

@@ -13,6 +13,7 @@
 3. ref_e2e_r50.npz -- GeneralizedRCNNMEGA (R-50 MEGA config, calibrated synthetic weights from
    mega.pytorch_amd.synth, seeded synthetic 160x256 clip) run for a few key frames on CPU: final detections and
    the intermediates named in SURVEY.md 8a.
+5. ref_base_r50.npz / ref_rdn_r50.npz / ref_feed.npz -- see golden_base / golden_rdn / golden_feed.
 4. ref_fgfa_r50.npz -- GeneralizedRCNNFGFA (configs/FGFA/vid_R_50_C4_FGFA_1x.yaml) on a 128x192 clip: flow field,
    aggregated feature map, predictor logits and final detections per key frame.
 """
@@ -32,6 +33,7 @@ from mega.pytorch_amd import synth  # noqa: E402
 
 E2E = dict(H=160, W=256, T=30, nkey=4, seed_w=1, seed_clip=3, global_seed=0)
 FGFA = dict(H=128, W=192, T=14, nkey=3, seed_w=2, seed_clip=4)
+RDN = dict(H=128, W=192, T=24, nkey=3, seed_w=2, seed_clip=4)
 
 
 def _load_ref_test(name):
@@ -265,6 +267,49 @@ def golden_base():
     np.savez_compressed(os.path.join(HERE, "ref_base_r50.npz"), **out)
 
 
+def golden_rdn():
+    """ref_rdn_r50.npz: GeneralizedRCNNRDN (configs/RDN/vid_R_50_C4_RDN_base_1x.yaml + ADVANCED_STAGE 1, i.e. the
+    full RDN head of vid_R_101_C4_RDN_1x.yaml on the R-50 body), 128x192 clip, 3 key frames."""
+    c = RDN
+    cfg = ref_shim.make_cfg("configs/RDN/vid_R_50_C4_RDN_base_1x.yaml",
+                            ["MODEL.VID.ROI_BOX_HEAD.ATTENTION.ADVANCED_STAGE", 1])
+    model = ref_shim.build_model(cfg)
+    model.load_state_dict(synth.make_rdn_state_dict(advanced_stage=1, seed=c["seed_w"]), strict=True)
+    frames = synth.preprocess_cpu(synth.make_clip(c["T"], c["H"], c["W"], seed=c["seed_clip"]))
+    import mega_core.modeling.detector.generalized_rcnn_rdn as gm
+    from mega_core.structures.image_list import to_image_list
+
+    class _FakeImg(object):
+        def __init__(self, i): self.i = i
+        def convert(self, m): return self
+
+    class _FakeImage(object):
+        @staticmethod
+        def open(path): return _FakeImg(int(path))
+    gm.Image = _FakeImage
+    trace = {}
+    model.roi_heads.box.predictor.register_forward_hook(
+        lambda m, i, o: trace.update(x=i[0].detach().clone(), logits=o[0].detach().clone(), deltas=o[1].detach().clone()))
+    out = {}
+    for idx in range(c["nkey"]):
+        nxt = min(c["T"] - 1, idx + 18)
+        images = {"cur": to_image_list(frames[idx]), "ref": [to_image_list(frames[nxt])],
+                  "frame_category": 0 if idx == 0 else 1, "seg_len": c["T"], "pattern": "%d", "img_dir": "%s",
+                  "transforms": lambda im: frames[im.i]}
+        with torch.no_grad():
+            det = model(images)[0]
+        out["boxes%d" % idx] = det.bbox.numpy()
+        out["scores%d" % idx] = det.get_field("scores").numpy()
+        out["labels%d" % idx] = det.get_field("labels").numpy()
+        out["x%d" % idx] = trace["x"].numpy()[:48]
+        out["logits%d" % idx] = trace["logits"].numpy()
+        out["deltas%d" % idx] = trace["deltas"].numpy()
+        print("rdn frame", idx, "dets", det.bbox.shape[0])
+    for k, v in c.items():
+        out["cfg_" + k] = np.int64(v)
+    np.savez_compressed(os.path.join(HERE, "ref_rdn_r50.npz"), **out)
+
+
 def golden_feed():
     """ref_feed.npz: the reference's test-time transform chain (data/transforms/build.py:26-45 with the default
     INPUT.* of config/defaults.py) on VID-like frame sizes (Resize.get_size) and on one seeded frame (full chain).
@@ -343,3 +388,4 @@ if __name__ == "__main__":
     golden_fgfa()
     golden_base()
     golden_feed()
+    golden_rdn()

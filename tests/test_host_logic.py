@@ -199,3 +199,30 @@ def test_mega_short_window_config_matches_oracle(monkeypatch):
                                            frame_loader=lambda i: frames[i][None])
         assert len(det) == wb.shape[0] and torch.equal(det.get_field("labels"), wl)
         assert (det.bbox - wb).abs().max() < 5e-3 and (det.get_field("scores") - ws).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("advanced", [0, 1])
+def test_rdn_detector_matches_oracle(monkeypatch, advanced):
+    """GeneralizedRCNNRDN (reference call convention + ref_init; 8f row 3) == RdnOracle, base and advanced stage."""
+    import mega.pytorch_amd.rdn  # noqa: F401
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    H, W, T, nkey = 96, 128, 22, 2
+    cfg = config.get_cfg("R-50", "rdn" if advanced else "rdn_base")
+    cfg.MODEL.DEVICE = "cpu"
+    sd = synth.make_rdn_state_dict(advanced_stage=advanced, seed=3)
+    model = modeling.build_detection_model(cfg)
+    assert type(model).__name__ == "GeneralizedRCNNRDN"
+    model.load_state_dict(sd)
+    frames = synth.preprocess_cpu(synth.make_clip(T, H, W, seed=6))
+    orc = mo.RdnOracle(sd, mo.OracleCfg(blocks=(3, 4, 6), reduce_channel=True, nms_strict_gt=True), advanced_stage=advanced)
+    for idx in range(nkey):
+        nxt = min(T - 1, idx + 18)
+        images = {"cur": frames[idx], "ref": [frames[nxt]], "frame_category": 0 if idx == 0 else 1, "seg_len": T,
+                  "ref_init": [frames[i] for i in range(1, 19)]}
+        with torch.no_grad():
+            det = model(images)[0]
+            wb, ws, wl = orc.forward_frame(frames[idx:idx + 1], 0 if idx == 0 else 1, ref=frames[nxt][None], seg_len=T,
+                                           frame_loader=lambda i: frames[i][None])
+        assert len(det) == wb.shape[0] and torch.equal(det.get_field("labels"), wl)
+        assert (det.bbox - wb).abs().max() < 5e-3 and (det.get_field("scores") - ws).abs().max() < 1e-5
