@@ -1,7 +1,8 @@
 """Builds libmega_hip.so (the C-ABI kernel library) in-tree with hipcc for gfx950.
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
-gpurun snapshot.  Flags: boxes.hip is built with -ffp-contract=off (see its header).
+gpurun snapshot.  Flags: boxes.hip and frames.hip are built with -ffp-contract=off (bit-exact
+box / pixel arithmetic: no FMA contraction the reference's separate torch ops do not have).
 """
 import hashlib
 import os
@@ -17,7 +18,7 @@ SOURCES = {
     "spatial.hip": [],
     "boxes.hip": ["-ffp-contract=off"],
     "relation.hip": [],
-    "frames.hip": [],
+    "frames.hip": ["-ffp-contract=off"],      # (x / 255) * 255 - mean must round like the reference's three torch ops
     "fgfa.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

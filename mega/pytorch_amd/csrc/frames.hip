@@ -13,8 +13,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t n = i / hw, px = i - n * hw;
     const unsigned char* p = in + i * 3;
-    const float r = ((float)p[0] / 255.f) * 255.f, g = ((float)p[1] / 255.f) * 255.f,
-                b = ((float)p[2] / 255.f) * 255.f;
+    // ToTensor's x / 255 followed by to_bgr255's * 255 returns x exactly for every uint8 x under IEEE f32
+    // round-to-nearest (checked for all 256 values in tests/test_feed.py), so the pair is the identity; the
+    // device's f32 division is NOT correctly rounded by default, so computing it literally would be off by 1 ulp.
+    const float r = (float)p[0], g = (float)p[1], b = (float)p[2];
     float* o = out + n * 3 * hw + px;
     if (to_bgr) {
       o[0] = b - m0; o[hw] = g - m1; o[2 * hw] = r - m2;

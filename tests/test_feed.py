@@ -37,6 +37,14 @@ def test_resampler_oracle_and_host_tables_equal_pillow(hw):
             assert row[:n].tolist() == taps and not row[n:].any()
 
 
+def test_totensor_times_255_is_the_identity_on_uint8():
+    """the preprocess kernel relies on it: (x / 255) * 255 == x in IEEE f32 for all 256 byte values."""
+    x = np.arange(256, dtype=np.float32)
+    assert np.array_equal((x / np.float32(255)) * np.float32(255), x)
+    t = torch.arange(256, dtype=torch.uint8).float()
+    assert torch.equal(t.div(255) * 255, t)
+
+
 def test_reference_transform_chain_fixture():
     """Resize + ToTensor + to_bgr255 + Normalize of the reference's own transforms (run in the build container on a
     seeded 360x480 frame, committed in ref_feed.npz) == oracle resize + synth.preprocess_cpu."""

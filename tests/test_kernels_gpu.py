@@ -281,7 +281,9 @@ def test_preprocess(dev):
     fr = synth.make_clip(2, 40, 64, seed=1)
     ref = synth.preprocess_cpu(fr)
     got = ops.preprocess_frames(fr.to(dev), synth.PIXEL_MEAN).cpu()
-    assert (got - ref).abs().max() < 1e-4
+    assert torch.equal(got, ref)          # ToTensor (/255), *255, -mean: three separately rounded f32 ops, no FMA
+    allv = torch.arange(256, dtype=torch.uint8).repeat(3, 1).t().reshape(1, 16, 16, 3).contiguous()
+    assert torch.equal(ops.preprocess_frames(allv.to(dev), synth.PIXEL_MEAN).cpu(), synth.preprocess_cpu(allv))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
