@@ -154,6 +154,12 @@ int mega_resize_bilinear_u8(const unsigned char* in, unsigned char* out, unsigne
 int mega_fgfa_warp_aggregate(const void* feats, const float* flow, void* out, float* weights_out, int T, int H,
                              int W, int Cf, int Ce, int key, int dtype, void* stream);
 
+/* DFF feature propagation: out[H][W][C] = bilinear warp (same grid convention as above) of the
+ * key frame's NHWC feature map by flow [2][H][W], times the per-element scale map [H][W][C].  Replaces
+ * GeneralizedRCNNDFF.get_grid / resample and the scale multiply (detector/generalized_rcnn_dff.py:41-60,:132-135). */
+int mega_dff_warp_scale(const void* feats, const float* flow, const void* scale, void* out, int H, int W, int C,
+                        int dtype, void* stream);
+
 /* hipGetErrorString of the last launch failure any entry point of this library reported (MEGA_ERR_LAUNCH). */
 const char* mega_last_error_string(void);
 

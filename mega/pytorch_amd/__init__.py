@@ -10,5 +10,5 @@ There is no CPU fallback: everything raises if libmega_hip.so is missing (build:
 """
 from .config import get_cfg  # noqa: F401
 from .modeling import build_detection_model, GeneralizedRCNNMEGA  # noqa: F401
-from .fgfa import GeneralizedRCNNFGFA, GeneralizedRCNN  # noqa: F401  (registers the FGFA / single-frame meta-architectures)
+from .fgfa import GeneralizedRCNNFGFA, GeneralizedRCNNDFF, GeneralizedRCNN  # noqa: F401  (registers the FGFA / single-frame meta-architectures)
 from .rdn import GeneralizedRCNNRDN  # noqa: F401  (registers the RDN meta-architecture + feature extractor)

@@ -56,13 +56,18 @@ def get_cfg(arch="R-101", method="mega"):
         cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "RDNFeatureExtractor"
         cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.STAGE = 2                    # defaults.py:409
         cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ADVANCED_STAGE = 1 if method == "rdn" else 0
+    elif method == "dff":
+        cfg.MODEL.META_ARCHITECTURE = "GeneralizedRCNNDFF"
+        cfg.MODEL.VID.METHOD = "dff"
+        cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "ResNetConv52MLPFeatureExtractor"
+        cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ENABLE = False
     elif method == "base":
         cfg.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"
         cfg.MODEL.VID.METHOD = "base"
         cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "ResNetConv52MLPFeatureExtractor"
         cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.ENABLE = False
     elif method != "mega":
-        raise ValueError("method must be 'mega', 'fgfa', 'rdn', 'rdn_base' or 'base'")
+        raise ValueError("method must be 'mega', 'fgfa', 'dff', 'rdn', 'rdn_base' or 'base'")
     return cfg
 
 
@@ -93,6 +98,7 @@ def _mega_cfg(r50):
                 "ROI_BOX_HEAD": {"REDUCE_CHANNEL": bool(r50),
                                  "ATTENTION": {"ENABLE": True, "STAGE": 3, "ADVANCED_STAGE": 0, "GROUP": 16,
                                                "EMBED_DIM": 64}},
+                "DFF": {"MIN_OFFSET": -9, "MAX_OFFSET": 0},
                 "RDN": {"MIN_OFFSET": -18, "MAX_OFFSET": 18, "ALL_FRAME_INTERVAL": 37, "KEY_FRAME_LOCATION": 18,
                         "RATIO": 0.2},
                 "FGFA": {"MIN_OFFSET": -9, "MAX_OFFSET": 9, "ALL_FRAME_INTERVAL": 19, "KEY_FRAME_LOCATION": 9},

@@ -115,7 +115,71 @@ __global__ __launch_bounds__(256) void fgfa_kernel(const T* __restrict__ feats, 
   }
 }
 
+
+// DFF (generalized_rcnn_dff.py:41-60,:132-135): out = grid_sample(key_feats, flow grid, bilinear, border) * scale_map.
+// One thread per (pixel, 16-byte channel vector): pure gather + multiply, HBM/L2-bound.
+template <typename T>
+__global__ __launch_bounds__(256) void dff_warp_scale_kernel(const T* __restrict__ feats, const float* __restrict__ flow,
+                                                             const T* __restrict__ scale, T* __restrict__ out, int H,
+                                                             int W, int C) {
+  constexpr int VE = Elem<T>::VE;
+  const int nvec = C / VE;
+  const size_t total = (size_t)H * W * nvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nvec);
+    const int pix = (int)(i / nvec);
+    const int px = pix % W, py = pix / W;
+    const float fx = flow[(size_t)pix], fy = flow[(size_t)H * W + pix];
+    const float gx = ((float)px + fx) / ((float)(W - 1) / 2.f) - 1.f;
+    const float gy = ((float)py + fy) / ((float)(H - 1) / 2.f) - 1.f;
+    float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+    float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    const float flx = floorf(ix), fly = floorf(iy);
+    const int x0 = (int)flx, y0 = (int)fly, x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float wx = ix - flx, wy = iy - fly;
+    const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy), w10 = (1.f - wx) * wy, w11 = wx * wy;
+    const T* base = feats + (size_t)v * VE;
+    const uint4 a = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * W + x0) * C);
+    const uint4 b = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * W + x1) * C);
+    const uint4 c = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x0) * C);
+    const uint4 d = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * W + x1) * C);
+    const uint4 sc = *reinterpret_cast<const uint4*>(scale + (size_t)pix * C + (size_t)v * VE);
+    const T* ea = reinterpret_cast<const T*>(&a); const T* eb = reinterpret_cast<const T*>(&b);
+    const T* ec = reinterpret_cast<const T*>(&c); const T* ed = reinterpret_cast<const T*>(&d);
+    const T* es = reinterpret_cast<const T*>(&sc);
+    T* o = out + (size_t)pix * C + (size_t)v * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const float w = w00 * Elem<T>::ld(ea + e) + w01 * Elem<T>::ld(eb + e) + w10 * Elem<T>::ld(ec + e) +
+                      w11 * Elem<T>::ld(ed + e);
+      Elem<T>::st(o + e, w * Elem<T>::ld(es + e));
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int mega_dff_warp_scale(const void* feats, const float* flow, const void* scale, void* out, int H, int W,
+                                   int C, int dtype, void* stream) {
+  mega_clear_error();
+  if (!feats || !flow || !scale || !out || H <= 1 || W <= 1 || C <= 0) return MEGA_ERR_ARG;
+  const int ve = dtype == MEGA_BF16 ? 8 : 4;
+  if (C % ve) return MEGA_ERR_ARG;
+  const size_t total = (size_t)H * W * (C / ve);
+  const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MEGA_BF16)
+    hipLaunchKernelGGL((dff_warp_scale_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)feats, flow,
+                       (const bf16_t*)scale, (bf16_t*)out, H, W, C);
+  else if (dtype == MEGA_F32)
+    hipLaunchKernelGGL((dff_warp_scale_kernel<float>), grid, dim3(256), 0, st, (const float*)feats, flow,
+                       (const float*)scale, (float*)out, H, W, C);
+  else
+    return MEGA_ERR_ARG;
+  return mega_check_launch();
+}
 
 extern "C" int mega_fgfa_warp_aggregate(const void* feats, const float* flow, void* out, float* weights_out, int T,
                                         int H, int W, int Cf, int Ce, int key, int dtype, void* stream) {

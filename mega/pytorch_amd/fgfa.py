@@ -75,6 +75,10 @@ class FlowNetS(_Packed):
 
     def __init__(self, cfg):
         super().__init__()
+        self.method = cfg.MODEL.VID.METHOD
+        if self.method == "dff":           # flownet.py:36-38: 1x1 conv 194 -> 1024 without bias, "+ 1" in forward
+            self.Convolution5_scale = nn.Conv2d(194, 1024, 1, bias=False)
+            nn.init.zeros_(self.Convolution5_scale.weight)
         for name, ci, co, k, s, p in self.CONVS:
             setattr(self, name, nn.Conv2d(ci, co, k, stride=s, padding=p))
         for name, ci in self.PREDS:
@@ -100,6 +104,9 @@ class FlowNetS(_Packed):
             mod = getattr(self, name)
             w = mod.weight.detach().permute(1, 0, 2, 3).flip(2, 3)      # [in,out,kh,kw] -> conv kernel [out,in,kh,kw]
             pk[name] = (_pack_w(w, dtype, m).to(device), mod.bias.detach().float().to(device).contiguous())
+        if self.method == "dff":
+            pk["scale_w"] = _pack_w(self.Convolution5_scale.weight, dtype, m).to(device)
+            pk["ones"] = torch.ones((1024,), dtype=torch.float32, device=device)
         pk["x2.5"] = torch.full((2,), 2.5, dtype=torch.float32, device=device)
         pk["m"] = m
         return pk
@@ -146,12 +153,18 @@ class FlowNetS(_Packed):
         c5 = ops.avgpool2x2_ceil(c5)
         w, b = pk["Convolution5"]                                            # Convolution5 * 2.5 (flownet.py:118)
         flow = ops.conv2d_nhwc(c5, w, pk["x2.5"], b * 2.5, pad=1, relu=0, out_dtype=torch.float32)
-        return flow.permute(0, 3, 1, 2).contiguous()
+        flow = flow.permute(0, 3, 1, 2).contiguous()
+        if self.method == "dff":          # Convolution5_scale + 1 (flownet.py:112-116), NHWC [T,h,w,1024]
+            return flow, ops.conv2d_nhwc(c5, pk["scale_w"], None, pk["ones"], relu=0)
+        return flow
 
     def forward(self, x):
         """reference signature: x [T,6,H,W] = cat([cur/255, ref/255]) -> flow [T,2,h,w]."""
         dt = self._dtype
-        return self.run((x * 255.0).permute(0, 2, 3, 1).contiguous().to(dt))
+        out = self.run((x * 255.0).permute(0, 2, 3, 1).contiguous().to(dt))
+        if self.method == "dff":
+            return out[0], _nchw_view(out[1])
+        return out
 
 
 class EmbedNet(_Packed):
@@ -357,3 +370,52 @@ class GeneralizedRCNN(nn.Module):
 
 
 DETECTION_META_ARCHITECTURES.register("GeneralizedRCNN", GeneralizedRCNN)
+
+
+class GeneralizedRCNNDFF(nn.Module):
+    """detector/generalized_rcnn_dff.py:19-138, inference: the backbone runs on key frames only
+    (images["is_key_frame"], every KEY_FRAME_INTERVAL-th frame in data/datasets/vid_dff.py); every frame's features
+    are the key frame's C4 map warped by FlowNetS(frame, key) and multiplied by the predicted scale map."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.dtype = compute_dtype(cfg)
+        self.backbone = build_backbone(cfg)
+        self.flownet = FlowNetS(cfg)
+        self.flownet._dtype = self.dtype
+        self.rpn = build_rpn(cfg, self.backbone.out_channels)
+        self.roi_heads = CombinedROIHeads(cfg, [("box", ROIBoxHead(cfg, self.backbone.out_channels))])
+        self.key_images = None
+        self.key_feats = None
+        self.eval()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        for m in self.modules():
+            if isinstance(m, _Packed):
+                m._pk = None
+        return out
+
+    @torch.no_grad()
+    def forward(self, images, targets=None):
+        """images = {"cur", "is_key_frame", ...} (vid_dff.py test feed)."""
+        if targets is not None:
+            raise ValueError("In testing mode, targets should be None")
+        cur = to_image_list(images["cur"]).tensors.to(self.device).float()
+        if images["is_key_frame"]:
+            self.key_images = cur
+            self.key_feats = _nhwc(self.backbone(cur)[0]).contiguous()
+        if self.key_feats is None:
+            raise RuntimeError("the first frame of a video must be a key frame")
+        pair = torch.cat([cur, self.key_images], dim=1)                         # :132 (the /255 lives in conv1)
+        flow, scale = self.flownet.run(pair.permute(0, 2, 3, 1).contiguous().to(self.dtype))
+        agg = ops.dff_warp_scale(self.key_feats[0], flow[0].contiguous(), scale[0].contiguous())
+        feats = (_nchw_view(agg.unsqueeze(0)),)
+        proposals, _ = self.rpn(to_image_list(cur), feats, None)
+        _, result, _ = self.roi_heads(feats, proposals, None)
+        return result
+
+
+DETECTION_META_ARCHITECTURES.register("GeneralizedRCNNDFF", GeneralizedRCNNDFF)

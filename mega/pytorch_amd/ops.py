@@ -336,6 +336,21 @@ def linear_transposed(w, x, ld):
     return out
 
 
+def dff_warp_scale(feats, flow, scale):
+    """feats NHWC [H,W,C] (key frame), flow [2,H,W] f32, scale [H,W,C] -> warp(feats, flow) * scale  [H,W,C]."""
+    _gpu(feats, flow, scale)
+    lib = _lib.load()
+    H, W, C = feats.shape
+    assert feats.is_contiguous() and flow.is_contiguous() and scale.is_contiguous()
+    assert flow.dtype == torch.float32 and flow.shape == (2, H, W) and scale.shape == feats.shape and scale.dtype == feats.dtype
+    out = torch.empty_like(feats)
+    _tok = _pb("dff_warp", 0.0, 6.0 * feats.numel() * feats.element_size())
+    rc = lib.mega_dff_warp_scale(_ptr(feats), _ptr(flow), _ptr(scale), _ptr(out), H, W, C, _dt(feats), _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_dff_warp_scale")
+    return out
+
+
 def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
     """feats NHWC [T,H,W,Cf+Ce], flow [T,2,H,W] f32 -> aggregated key-frame features [H,W,Cf] (+ weights [T,H,W])."""
     _gpu(feats, flow)

@@ -166,6 +166,15 @@ def preprocess_cpu(frames_u8):
     return x - torch.tensor(PIXEL_MEAN).view(1, 3, 1, 1)
 
 
+def make_dff_state_dict(blocks=(3, 4, 6), reduce_channel=True, num_classes=31, seed=0):
+    """FGFA layout minus embednet.*, plus flownet.Convolution5_scale.weight [1024,194,1,1] (flownet.py:36-38)."""
+    sd = {k: v for k, v in make_fgfa_state_dict(blocks, reduce_channel, num_classes, seed).items()
+          if not k.startswith("embednet.")}
+    gen = torch.Generator().manual_seed(seed + 3000)
+    sd["flownet.Convolution5_scale.weight"] = _normal(gen, (1024, 194, 1, 1), 0.02)
+    return sd
+
+
 def make_fgfa_state_dict(blocks=(3, 4, 6), reduce_channel=True, num_classes=31, seed=0):
     """Calibrated random weights with the reference's FGFA state_dict layout
     (backbone.*, flownet.*, embednet.*, rpn.*, roi_heads.box.feature_extractor.{head,conv,fc6,fc7}, predictor)."""

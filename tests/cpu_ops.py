@@ -138,8 +138,15 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
     return (out, w[:, 0]) if want_weights else out
 
 
-ALL = ["resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+ALL = ["dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames"]
+
+
+def dff_warp_scale(feats, flow, scale):
+    f = feats.float().permute(2, 0, 1)[None]
+    grid = mo.fgfa_get_grid(flow[None])
+    w = F.grid_sample(f, grid, mode="bilinear", padding_mode="border", align_corners=False)
+    return (w[0].permute(1, 2, 0) * scale.float()).to(feats.dtype).contiguous()
 
 
 def resize_bilinear_u8(frames_u8, out_hw, tables=None):

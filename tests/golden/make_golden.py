@@ -310,6 +310,70 @@ def golden_rdn():
     np.savez_compressed(os.path.join(HERE, "ref_rdn_r50.npz"), **out)
 
 
+def golden_dff():
+    """ref_dff_r50.npz: GeneralizedRCNNDFF (configs/DFF/vid_R_50_C4_DFF_1x.yaml), key frame every 3rd frame."""
+    c = FGFA
+    cfg = ref_shim.make_cfg("configs/DFF/vid_R_50_C4_DFF_1x.yaml")
+    model = ref_shim.build_model(cfg)
+    model.load_state_dict(synth.make_dff_state_dict(seed=c["seed_w"]), strict=True)
+    frames = synth.preprocess_cpu(synth.make_clip(c["T"], c["H"], c["W"], seed=c["seed_clip"]))
+    trace = {}
+    model.roi_heads.box.predictor.register_forward_hook(
+        lambda m, i, o: trace.update(logits=o[0].detach().clone(), deltas=o[1].detach().clone()))
+    model.rpn.register_forward_hook(lambda m, i, o: trace.update(feats=i[1][0].detach().clone()))
+    out = {}
+    for idx in range(4):
+        with torch.no_grad():
+            det = model({"cur": frames[idx], "is_key_frame": idx % 3 == 0})[0]
+        out["boxes%d" % idx] = det.bbox.numpy()
+        out["scores%d" % idx] = det.get_field("scores").numpy()
+        out["labels%d" % idx] = det.get_field("labels").numpy()
+        out["logits%d" % idx] = trace["logits"].numpy()
+        out["feats%d" % idx] = trace["feats"].numpy()[0, ::16]
+    for k, v in c.items():
+        out["cfg_" + k] = np.int64(v)
+    np.savez_compressed(os.path.join(HERE, "ref_dff_r50.npz"), **out)
+
+
+def golden_checkpoint():
+    """ref_checkpoint.json: (1) the reference's Caffe2 -> torch renaming (c2_model_loading._rename_weights_for_resnet)
+    of a Detectron-style R-50 blob list, (2) the key alignment its load_state_dict computes when those weights (and,
+    separately, a 'module.'-prefixed full checkpoint, and a FlowNet file) are loaded into its own MEGA / FGFA models."""
+    import json
+    cfg = ref_shim.make_cfg("configs/MEGA/vid_R_50_C4_MEGA_1x.yaml")
+    from mega_core.utils import c2_model_loading as c2
+    from mega_core.utils import model_serialization as ms
+    blobs = ["conv1_w", "res_conv1_bn_s", "res_conv1_bn_b", "fc1000_w", "fc1000_b", "pred_w", "conv1_w_momentum",
+             "conv_rpn_w", "conv_rpn_b", "rpn_cls_logits_w", "rpn_cls_logits_b", "rpn_bbox_pred_w", "rpn_bbox_pred_b",
+             "cls_score_w", "cls_score_b", "bbox_pred_w", "bbox_pred_b"]
+    for stage, nblk in (("res2", 3), ("res3", 4), ("res4", 6), ("res5", 3)):
+        for b in range(nblk):
+            for br in ("branch2a", "branch2b", "branch2c") + (("branch1",) if b == 0 else ()):
+                blobs += ["%s_%d_%s_w" % (stage, b, br), "%s_%d_%s_bn_s" % (stage, b, br), "%s_%d_%s_bn_b" % (stage, b, br)]
+    weights = {k: np.zeros((1,), np.float32) for k in blobs}
+    renamed = c2._rename_weights_for_resnet(weights, c2._C2_STAGE_NAMES["R-50"])
+    out = {"c2_blobs": sorted(blobs), "c2_renamed": list(renamed.keys())}
+
+    def alignment(model, loaded_keys, flownet):
+        class _Named(object):                                    # stands in for a tensor: the reference logs .shape
+            shape = ()
+            def __init__(self, name): self.name = name
+        msd = {k: None for k in model.state_dict().keys()}       # matched entries are replaced by the loaded value
+        ms.align_and_update_state_dicts(msd, {k: _Named(k) for k in loaded_keys}, flownet=flownet)
+        return {k: (v.name if v is not None else None) for k, v in msd.items()}
+    model = ref_shim.build_model(cfg)
+    out["mega_from_c2"] = alignment(model, list(renamed.keys()), False)
+    full = ["module." + k for k in model.state_dict().keys()]
+    out["mega_from_module_prefixed"] = alignment(model, list(ms.strip_prefix_if_present({k: 0 for k in full}, "module.").keys()), False)
+    fcfg = ref_shim.make_cfg("configs/FGFA/vid_R_50_C4_FGFA_1x.yaml")
+    fmodel = ref_shim.build_model(fcfg)
+    flow_keys = [k[len("flownet."):] for k in fmodel.state_dict().keys() if k.startswith("flownet.")]
+    out["fgfa_flownet_file"] = alignment(fmodel, flow_keys, True)
+    out["fgfa_from_c2"] = alignment(fmodel, list(renamed.keys()), False)
+    with open(os.path.join(HERE, "ref_checkpoint.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
 def golden_feed():
     """ref_feed.npz: the reference's test-time transform chain (data/transforms/build.py:26-45 with the default
     INPUT.* of config/defaults.py) on VID-like frame sizes (Resize.get_size) and on one seeded frame (full chain).
@@ -389,3 +453,5 @@ if __name__ == "__main__":
     golden_base()
     golden_feed()
     golden_rdn()
+    golden_dff()
+    golden_checkpoint()

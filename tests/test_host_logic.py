@@ -226,3 +226,26 @@ def test_rdn_detector_matches_oracle(monkeypatch, advanced):
                                            frame_loader=lambda i: frames[i][None])
         assert len(det) == wb.shape[0] and torch.equal(det.get_field("labels"), wl)
         assert (det.bbox - wb).abs().max() < 5e-3 and (det.get_field("scores") - ws).abs().max() < 1e-5
+
+
+def test_dff_detector_matches_oracle(monkeypatch):
+    """GeneralizedRCNNDFF (8f row 4) on the CPU twins == DffOracle: key frames run the backbone, the others re-use it."""
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    cfg = config.get_cfg("R-50", "dff")
+    cfg.MODEL.DEVICE = "cpu"
+    sd = synth.make_dff_state_dict(seed=3)
+    model = modeling.build_detection_model(cfg)
+    assert type(model).__name__ == "GeneralizedRCNNDFF"
+    model.load_state_dict(sd)
+    frames = synth.preprocess_cpu(synth.make_clip(3, 96, 128, seed=6))
+    orc = mo.DffOracle(sd, mo.OracleCfg(blocks=(3, 4, 6), reduce_channel=True, nms_strict_gt=True))
+    calls = []
+    model.backbone.register_forward_hook(lambda m, i, o: calls.append(1))
+    for idx in range(3):
+        with torch.no_grad():
+            det = model({"cur": frames[idx], "is_key_frame": idx == 0})[0]
+            wb, ws, wl = orc.forward_frame(frames[idx:idx + 1], idx == 0)
+        assert len(det) == wb.shape[0] and torch.equal(det.get_field("labels"), wl)
+        assert (det.bbox - wb).abs().max() < 5e-3 and (det.get_field("scores") - ws).abs().max() < 1e-5
+    assert len(calls) == 1

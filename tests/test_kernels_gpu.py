@@ -318,3 +318,19 @@ def test_avgpool2x2_ceil(dev, dtype, shape):
     got = ops.avgpool2x2_ceil(x.to(dev)).float().cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max() < (1e-6 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dff_warp_scale(dev, dtype):
+    """warp(key feats, flow) * scale vs F.grid_sample(bilinear, border) (generalized_rcnn_dff.py:41-60,:134-135)."""
+    import cpu_ops
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    H, W, C = 19, 31, 64
+    feats = torch.randn((H, W, C), generator=g).to(dtype)
+    scale = (1 + 0.2 * torch.randn((H, W, C), generator=g)).to(dtype)
+    flow = torch.randn((2, H, W), generator=g) * 3
+    flow[:, 0, :] -= 8          # exercise the border clamp
+    ref = cpu_ops.dff_warp_scale(feats.float(), flow, scale.float())
+    got = ops.dff_warp_scale(feats.to(dev), flow.to(dev), scale.to(dev)).float().cpu()
+    assert (got - ref).abs().max() < (1e-5 if dtype == torch.float32 else 3e-2) * max(1.0, ref.abs().max().item())
