@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run frame stage and aggregation on one stream")
     ap.add_argument("--no-graphs", action="store_true", help="launch the frame stage kernel by kernel (no hipGraph)")
+    ap.add_argument("--reuse-records", action="store_true",
+                    help="compute each frame's record once per video (engine option; NOT the headline configuration)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     return ap.parse_args()
 
@@ -147,7 +149,7 @@ def main():
     clip = make_clip(T, args.height, args.width, device)
     gfor = eng.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
     runner = eng.ClipEngine(model, steps_per_batch=args.steps_per_batch, dist_group=group, overlap=not args.no_overlap,
-                            graphs=not args.no_graphs)
+                            graphs=not args.no_graphs, reuse_records=args.reuse_records)
 
     def barrier():
         torch.cuda.synchronize()
@@ -165,10 +167,12 @@ def main():
     log("warm-up done; timing %d steps" % K)
     for k in runner.host_times:
         runner.host_times[k] = 0
+    fc_before = runner.frames_computed
     t0 = time.perf_counter()
     dets = runner.run(clip, T, gfor, first=Wm, last=Wm + K)
     barrier()
     elapsed = time.perf_counter() - t0
+    runner_frames_after = runner.frames_computed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -229,6 +233,8 @@ def main():
                                    "300 key / 75 ref proposals, 3 attention stages (BASELINE configs[2]%s)"
                                    % (args.arch, args.width, args.height, "" if world == 1 else " sharded = configs[3]"),
                        "steps_per_batch": args.steps_per_batch, "parallelism": "frame-sharded x%d" % world,
+                       "frame_record_reuse": bool(args.reuse_records),
+                       "frames_through_frame_stage_per_step": round((runner_frames_after - fc_before) / K, 2),
                        "avg_detections": round(ndet, 1),
                        "key_proposals_last_frame": int(model.records[model.key_frame_location]["boxes"].shape[0])},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_families": fam,

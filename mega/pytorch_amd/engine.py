@@ -53,11 +53,16 @@ class _On(object):
 
 
 class ClipEngine(object):
-    def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True, graphs=True):
+    def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True, graphs=True, reuse_records=False):
         """steps_per_batch: key-frame steps whose frame jobs are computed in one frame-stage batch
         (steady state: 2 frames per step).  dist_group: torch.distributed group to shard the frame stage over
         (None = single process).  overlap: use the two-stream pipeline (see module docstring).
-        graphs: replay the frame stage from a hipGraph once a batch shape repeats."""
+        graphs: replay the frame stage from a hipGraph once a batch shape repeats.
+        reuse_records: keep every frame's record (0.6 MB) for the rest of the video.  A frame is consumed twice --
+        once entering the local window, once entering the global pool (vid_mega.py:104-120) -- and the reference
+        runs backbone + RPN + res5 + fc0 both times; the record is a pure function of the frame, so the second
+        use can take the stored one (first 75 rows for the global role).  Identical detections, ~half the frame-stage
+        work over a whole video.  Off by default: the benchmark's headline keeps the reference's two passes."""
         self.model = model
         self.steps_per_batch = steps_per_batch
         self.group = dist_group
@@ -72,6 +77,11 @@ class ClipEngine(object):
         self.overlap = overlap
         self.use_graphs = graphs
         self._fgraphs = {}
+        self._graph_pool = None
+        self.reuse_records = reuse_records
+        self._rec_cache = {}              # frame id -> record (reuse_records)
+        self._rec_pending = set()         # frame ids whose record is being computed by an enqueued batch
+        self.frames_computed = 0
         self._streams = None
         # host-side seconds spent enqueuing / waiting, accumulated over run() calls (diagnostics for bench.py)
         self.host_times = {"frame_enqueue": 0.0, "aggregate_enqueue": 0.0, "finish_wait": 0.0, "steps": 0}
@@ -125,7 +135,9 @@ class ClipEngine(object):
             ent["static_in"] = imgs.clone()
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            if self._graph_pool is None:          # all frame-stage graphs replay one after the other on one stream:
+                self._graph_pool = torch.cuda.graph_pool_handle()    # they can share one activation pool
+            with torch.cuda.graph(g, pool=self._graph_pool):
                 ent["st"] = m.frame_stage_async(ent["static_in"], want)
             ent["graph"] = g
         ent["static_in"].copy_(imgs)
@@ -219,11 +231,25 @@ class ClipEngine(object):
                     jobs = (jobs + [jobs[-1]] * (per * self.world - len(jobs)))[self.rank * per:(self.rank + 1) * per]
                 clip.prefetch([j[0] for j in jobs])
 
+        if first == 0:
+            self._rec_cache, self._rec_pending = {}, set()
+
         def frame_stage(b):
             per_step = [self.jobs_for_step(i, T, gfor) for i in range(b[0], b[1])]
             flat = [j for js in per_step for j in js]
+            if self.reuse_records:      # every frame once per video, always with the key-role row count
+                todo = []
+                for f, _, _ in flat:
+                    if f not in self._rec_cache and f not in self._rec_pending:
+                        self._rec_pending.add(f)
+                        todo.append((f, m.key_num, "l"))
+                flat = todo
+            self.frames_computed += len(flat)
+            if not flat:
+                return per_step, {"none": True, "jobs": flat}, None
             with _On(sF):
                 h = self.records_async(clip, flat)
+                h["jobs"] = flat
                 ev = None
                 if use_streams:   # proposal counts -> pinned host memory, async; the event covers the copy
                     c = self._cnt_of(h)
@@ -236,19 +262,26 @@ class ClipEngine(object):
         def aggregate(b, per_step, h, ev):
             with _On(sB):
                 counts = None
-                if use_streams:
+                if use_streams and ev is not None:
                     sB.wait_event(ev)
                     ev.synchronize()                  # host waits for THIS frame-stage batch only, not the stream
                     counts = h["cnt_host"].tolist()
-                recs = self.records_resolve(h, counts)
+                recs = [] if h.get("none") else self.records_resolve(h, counts)
                 if use_streams:
                     for r in recs:                    # produced on sF, consumed on sB
                         for t in r.values():
                             t.record_stream(sB)
+                if self.reuse_records:
+                    for (f, _, _), r in zip(h["jobs"], recs):
+                        self._rec_cache[f] = r
+                        self._rec_pending.discard(f)
                 pending, o = [], 0
                 for i, js in zip(range(b[0], b[1]), per_step):
-                    r = recs[o:o + len(js)]
-                    o += len(js)
+                    if self.reuse_records:
+                        r = [self._rec_cache[j[0]] for j in js]
+                    else:
+                        r = recs[o:o + len(js)]
+                        o += len(js)
                     loc = [x for x, j in zip(r, js) if j[2] == "l"]
                     glob = [x for x, j in zip(r, js) if j[2] == "g"]
                     if i == 0:

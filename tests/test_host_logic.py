@@ -249,3 +249,26 @@ def test_dff_detector_matches_oracle(monkeypatch):
         assert len(det) == wb.shape[0] and torch.equal(det.get_field("labels"), wl)
         assert (det.bbox - wb).abs().max() < 5e-3 and (det.get_field("scores") - ws).abs().max() < 1e-5
     assert len(calls) == 1
+
+
+def test_engine_record_reuse_gives_same_detections(monkeypatch):
+    """ClipEngine(reuse_records=True): each frame's record is computed once per video and serves both its local-window
+    and its global-pool role; detections equal the two-pass schedule (CPU twins: batch-order round-off only)."""
+    from mega.pytorch_amd import engine
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    T, nkey = 18, 6
+    cfg = _small_cfg()
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    frames = synth.preprocess_cpu(synth.make_clip(T, 96, 128, seed=2))
+    outs, computed = [], []
+    for reuse in (False, True):
+        model = modeling.build_detection_model(cfg)
+        model.load_state_dict(sd)
+        eng = engine.ClipEngine(model, steps_per_batch=2, overlap=False, graphs=False, reuse_records=reuse)
+        outs.append(eng.run(frames, T, last=nkey))
+        computed.append(eng.frames_computed)
+    for a, b in zip(*outs):
+        assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels"))
+        assert (a.bbox - b.bbox).abs().max() < 1e-3 and (a.get_field("scores") - b.get_field("scores")).abs().max() < 1e-5
+    assert computed[0] == 13 + 10 + 2 * (nkey - 1) and computed[1] <= T and computed[1] < computed[0]
