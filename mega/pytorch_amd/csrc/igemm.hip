@@ -16,6 +16,9 @@
 // v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact f32).  Two LDS buffers, one
 // barrier per K-tile.  blockIdx -> tile map is XCD-aware (blocks of one XCD share A row panels in
 // that XCD's L2).
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -58,7 +61,7 @@ template <> struct Mma<float> {
 };
 
 template <typename T, typename OT, int BM, int BN>
-__global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igemm_kernel(ConvParams p) {
   constexpr int KE = KTB / (int)sizeof(T);   // K elements per tile
   constexpr int VE = 16 / (int)sizeof(T);    // elements per 16-B vector
   constexpr int AV = BM / 32;                // A vectors per thread per tile
@@ -213,24 +216,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(ConvParams p) {
   }
 
   // ---- epilogue.  Accumulators (lane owns column n = lane&31, rows (r&3)+8*(r>>2)+4*(lane>>5)) are scaled /
-  //      biased, staged through LDS as an f32 [BM][BN+4] tile, then written as whole 16-byte vectors along n:
-  //      coalesced row segments instead of 2-byte-per-lane stores; the residual is read the same way.
-  constexpr int CST = BN + 4;  // f32 row stride of the staged tile
+  //      biased and staged through LDS as f32, 64 tile rows at a time (the i-th 32-row slab of both wave rows:
+  //      [2][32][BN+4] floats, so the staging area never exceeds the main loop's LDS even for 256-wide tiles),
+  //      then written as whole 16-byte vectors along n: coalesced row segments instead of 2-byte-per-lane stores;
+  //      the residual is read the same way.
+  constexpr int CST = BN + 4;  // f32 row stride of the staged slab
+  static_assert(64 * CST * 4 <= 2 * (BM + BN) * LDS_STRIDE, "staging slab must fit in the main-loop LDS");
   float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nl = wn * WTN + j * 32 + (lane & 31);
-    const int n = n0 + nl;
-    const float sc = (p.scale && n < p.Cout) ? p.scale[n] : 1.f;
-    const float bi = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = wm * WTM + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cs[(mb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][j][r] * sc + bi;
-    }
-  }
-  __syncthreads();
   OT* __restrict__ out = (OT*)p.out;
   const T* __restrict__ res = (const T*)p.res;
   constexpr int OVE = 16 / (int)sizeof(OT);   // output elements per 16-byte vector
@@ -239,34 +231,53 @@ __global__ __launch_bounds__(NTHREADS, 2) void igemm_kernel(ConvParams p) {
   const float neg_slope = p.relu == 1 ? 0.f : (p.relu == 2 ? 0.1f : 1.f);
   auto act = [&](float x) { return x > 0.f ? x : x * neg_slope; };
   const bool vec_ok = (p.ldo % OVE == 0) && (!res || (sizeof(T) == sizeof(OT) && p.ldr % OVE == 0));
-  for (int e = tid; e < BM * VPR; e += NTHREADS) {
-    const int row = e / VPR, cv = e - row * VPR;
-    const int m = m0 + row, n = n0 + cv * OVE;
-    if (m >= p.M || n >= p.Cout) continue;
-    float v[OVE];
+  float sc[TN], bi[TN];
 #pragma unroll
-    for (int t = 0; t < OVE; t += 4) {
-      const float4 f = *reinterpret_cast<const float4*>(cs + row * CST + cv * OVE + t);
-      v[t] = f.x; v[t + 1] = f.y; v[t + 2] = f.z; v[t + 3] = f.w;
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+    sc[j] = (p.scale && n < p.Cout) ? p.scale[n] : 1.f;
+    bi[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i > 0) __syncthreads();               // the previous slab has been read out
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = wn * WTN + j * 32 + (lane & 31);
+      const int rb = wm * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][j][r] * sc[j] + bi[j];
     }
-    if (vec_ok && n + OVE <= p.Cout) {
-      if (res) {
-        const uint4 rr = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
-        const T* re = reinterpret_cast<const T*>(&rr);
+    __syncthreads();
+    for (int e = tid; e < 64 * VPR; e += NTHREADS) {
+      const int row = e / VPR, cv = e - row * VPR;
+      const int m = m0 + (row >> 5) * WTM + i * 32 + (row & 31), n = n0 + cv * OVE;
+      if (m >= p.M || n >= p.Cout) continue;
+      float v[OVE];
 #pragma unroll
-        for (int t = 0; t < OVE; ++t) v[t] += Elem<T>::ld(re + t);
+      for (int t = 0; t < OVE; t += 4) {
+        const float4 f = *reinterpret_cast<const float4*>(cs + row * CST + cv * OVE + t);
+        v[t] = f.x; v[t + 1] = f.y; v[t + 2] = f.z; v[t + 3] = f.w;
       }
-      uint4 o;
-      OT* oe = reinterpret_cast<OT*>(&o);
+      if (vec_ok && n + OVE <= p.Cout) {
+        if (res) {
+          const uint4 rr = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
+          const T* re = reinterpret_cast<const T*>(&rr);
 #pragma unroll
-      for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, act(v[t]));
-      *reinterpret_cast<uint4*>(out + (size_t)m * p.ldo + n) = o;
-    } else {
-      for (int t = 0; t < OVE && n + t < p.Cout; ++t) {
-        float x = v[t];
-        if (res) x += Elem<T>::ld(res + (size_t)m * p.ldr + n + t);
-        x = act(x);
-        Elem<OT>::st(out + (size_t)m * p.ldo + n + t, x);
+          for (int t = 0; t < OVE; ++t) v[t] += Elem<T>::ld(re + t);
+        }
+        uint4 o;
+        OT* oe = reinterpret_cast<OT*>(&o);
+#pragma unroll
+        for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, act(v[t]));
+        *reinterpret_cast<uint4*>(out + (size_t)m * p.ldo + n) = o;
+      } else {
+        for (int t = 0; t < OVE && n + t < p.Cout; ++t) {
+          float x = v[t];
+          if (res) x += Elem<T>::ld(res + (size_t)m * p.ldr + n + t);
+          x = act(x);
+          Elem<OT>::st(out + (size_t)m * p.ldo + n + t, x);
+        }
       }
     }
   }
@@ -285,13 +296,27 @@ int launch(const ConvParams& p, hipStream_t st) {
   return mega_check_launch();
 }
 
+// Tile choice, from measurements on MI355X (tools/bench_kernels.py --tiles ..., profiles/README.md): 128x128 at two
+// blocks per CU wins every shape of the path except the very long-K 1024->1024 3x3 RPN conv, where 256x256 at one
+// block per CU is ~10 % faster; 256x128 never wins (one block of 4 waves per CU hides too little latency).  Small
+// grids shrink the tile to keep >= ~1.5 rounds of blocks over the 256 CUs.
 template <typename T, typename OT>
 int dispatch_tile(const ConvParams& p, hipStream_t st) {
-  // Tile choice: big tiles when they still give >= ~1.5 waves of blocks over 256 CUs, else shrink.
-  const long b128 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  const long b12864 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 64);
-  if (p.Cout > 64 && b128 >= 384) return launch<T, OT, 128, 128>(p, st);
-  if (b12864 >= 384) return launch<T, OT, 128, 64>(p, st);
+  const char* force = getenv("MEGA_IGEMM_TILE");   // e.g. "256x128": experiments / tests only
+  int bm = 0, bn = 0;
+  if (!(force && sscanf(force, "%dx%d", &bm, &bn) == 2)) {
+    const long b256 = (long)cdiv(p.M, 256) * cdiv(p.Cout, 256);
+    const long b128 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 128);
+    const long b12864 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 64);
+    if (p.K >= 8192 && p.Cout >= 1024 && b256 >= 700) { bm = 256; bn = 256; }
+    else if (p.Cout > 64 && b128 >= 384) { bm = 128; bn = 128; }
+    else if (b12864 >= 384) { bm = 128; bn = 64; }
+    else { bm = 64; bn = 64; }
+  }
+  if (bm == 256 && bn == 256) return launch<T, OT, 256, 256>(p, st);
+  if (bm == 256 && bn == 128) return launch<T, OT, 256, 128>(p, st);
+  if (bm == 128 && bn == 128) return launch<T, OT, 128, 128>(p, st);
+  if (bm == 128 && bn == 64) return launch<T, OT, 128, 64>(p, st);
   return launch<T, OT, 64, 64>(p, st);
 }
 

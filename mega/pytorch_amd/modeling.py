@@ -452,9 +452,10 @@ class MEGAFeatureExtractor(_Packed):
 
     # ---- test-time state (:657-688)
     def init_memory(self):
-        self.mem_queue_list = [{"rois": deque(maxlen=self.all_frame_interval),
-                                "feats": deque(maxlen=self.all_frame_interval)} for _ in range(self.stage)]
-        self.mem = [dict() for _ in range(self.stage)]
+        n = self.all_frame_interval
+        self.mem_queue_list = [{"rois": deque(maxlen=n), "feats": deque(maxlen=n),
+                                "k": deque(maxlen=n), "vt": deque(maxlen=n)} for _ in range(self.stage)]   # k / vt:
+        self.mem = [dict() for _ in range(self.stage)]      # the rows' Wk / Wv projections, kept with the rows
 
     def init_global(self):
         self.global_queue_list = [{"feats": deque(maxlen=self.global_size)}]
@@ -470,6 +471,16 @@ class MEGAFeatureExtractor(_Packed):
         self.mem_queue_list[i]["feats"].append(cache["feats_ref"][:n])
         self.mem[i] = {"rois": torch.cat(list(self.mem_queue_list[i]["rois"]), dim=0),
                        "feats": torch.cat(list(self.mem_queue_list[i]["feats"]), dim=0)}
+
+    def _remember_kv(self, i, k, vt):
+        """The rows update_memory(i, .) pushed this step are the first rows of this step's `ref`: keep their key /
+        value projections (k [Nr,1024], vt [1024,ld] of the whole ref) with them -- next steps read them as memory."""
+        n = self.mem_queue_list[i]["feats"][-1].shape[0]
+        q = self.mem_queue_list[i]
+        q["k"].append(k[:n])
+        q["vt"].append(vt[:, :n])
+        self.mem[i]["k"] = torch.cat(list(q["k"]), dim=0)
+        self.mem[i]["vt"] = torch.cat(list(q["vt"]), dim=1)
 
     def update_lm(self, feats, i=0):
         pk = self._packed(feats.dtype, feats.device)
@@ -505,11 +516,18 @@ class MEGAFeatureExtractor(_Packed):
                 self.update_memory(i, cache[i])
             rois_cur, rois_ref = cache[i]["rois_cur"], cache[i]["rois_ref"]
             feats_cur, feats_ref = cache[i]["feats_cur"], cache[i]["feats_ref"]
+            mem_kv = None
             if memory is not None:
                 rois_ref = torch.cat([rois_ref, memory["rois"]], dim=0)
-                feats_ref = torch.cat([feats_ref, memory["feats"]], dim=0)
-            feats_cur = relation_attention_forward(pk["local"][i], feats_cur.contiguous(), feats_ref.contiguous(),
-                                                   rois_cur.contiguous(), rois_ref.contiguous(), residual=True)
+                if "k" in memory:      # projections made when these rows were in the local window (same values)
+                    mem_kv = (memory["k"], memory["vt"])
+                else:
+                    feats_ref = torch.cat([feats_ref, memory["feats"]], dim=0)
+            feats_cur, k_loc, vt_loc = relation_attention_forward(
+                pk["local"][i], feats_cur.contiguous(), feats_ref.contiguous(), rois_cur.contiguous(),
+                rois_ref.contiguous(), residual=True, mem_kv=mem_kv, return_kv=True)
+            if self.memory_enable:
+                self._remember_kv(i, k_loc, vt_loc)
             if i != self.stage - 1:
                 feats_cur = ops.linear(feats_cur, pk["fc_w"][i + 1], pk["fc_b"][i + 1], relu=True)
             if i == self.stage - 1:

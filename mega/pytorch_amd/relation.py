@@ -39,16 +39,32 @@ class RelationWeights(object):
             self.dim_mat = torch.full((len(feat_range),), 1000.0).pow(8.0 / 64 * feat_range).to(device)
 
 
-def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=True):
-    """x [Nq,1024] queries, ref [Nk,1024] keys/values (both dtype of w), rois_* [N,4] f32 when w.with_pos.
+def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=True, mem_kv=None, return_kv=False):
+    """x [Nq,1024] queries, ref [Nr,1024] keys/values (both dtype of w), rois_* [N,4] f32 when w.with_pos.
     Returns x + attention(x, ref) (residual=True, as every call site of the reference does,
-    roi_box_feature_extractors.py:697,:824) or the bare attention output."""
-    Nk = ref.shape[0]
-    q = ops.linear(x, w.wq, w.bq)
+    roi_box_feature_extractors.py:697,:824) or the bare attention output.
+
+    mem_kv = (k_mem [Nm,1024], vt_mem [1024,Nm]): already-projected keys / values of FURTHER reference rows that
+    follow `ref` in key order (the memory pool: its features never change once pushed, so their Wk / Wv projections
+    are computed once, when the rows were part of `ref`, instead of every step).  rois_k then covers Nr + Nm rows.
+    return_kv: also return this call's (k [Nr,1024], vt [1024,ld]) of `ref` so the caller can keep slices of them."""
+    Nr = ref.shape[0]
     k = ops.linear(ref, w.wk, w.bk)
-    ldv = (Nk + 31) // 32 * 32
-    vt = ops.linear_transposed(w.wv, ref, ldv)
+    ldr = (Nr + 31) // 32 * 32
+    vt = ops.linear_transposed(w.wv, ref, ldr)
+    k_all, vt_all, Nk = k, vt, Nr
+    if mem_kv is not None:
+        k_mem, vt_mem = mem_kv
+        Nk = Nr + k_mem.shape[0]
+        ldv = (Nk + 31) // 32 * 32
+        k_all = torch.cat([k, k_mem], dim=0)
+        parts = [vt[:, :Nr], vt_mem]
+        if ldv > Nk:
+            parts.append(vt.new_zeros((vt.shape[0], ldv - Nk)))
+        vt_all = torch.cat(parts, dim=1)
+    q = ops.linear(x, w.wq, w.bq)
     pos = None
     if w.with_pos:
         pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=(x.dtype == torch.float32))
-    return ops.relation_attention(q, k, vt, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
+    out = ops.relation_attention(q, k_all, vt_all, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
+    return (out, k, vt) if return_kv else out

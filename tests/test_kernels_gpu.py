@@ -334,3 +334,31 @@ def test_dff_warp_scale(dev, dtype):
     ref = cpu_ops.dff_warp_scale(feats.float(), flow, scale.float())
     got = ops.dff_warp_scale(feats.to(dev), flow.to(dev), scale.to(dev)).float().cpu()
     assert (got - ref).abs().max() < (1e-5 if dtype == torch.float32 else 3e-2) * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("tile", ["64x64", "128x64", "128x128", "256x128", "256x256"])
+def test_conv_every_tile_shape(dev, tile, monkeypatch):
+    """every instantiated igemm tile (normally picked by the cost model) on shapes with M / N / K tails, odd K-tile
+    counts, residual + ReLU and f32 output: forced through MEGA_IGEMM_TILE."""
+    ops = _ops()
+    monkeypatch.setenv("MEGA_IGEMM_TILE", tile)
+    g = torch.Generator().manual_seed(11)
+    for (N, H, W, Cin, Cout, R, pad, res, odt) in [(2, 37, 41, 192, 320, 1, 0, True, torch.bfloat16),
+                                                   (1, 29, 31, 64, 200, 3, 1, False, torch.float32),
+                                                   (700, 1, 1, 1024, 155, 1, 0, False, torch.float32)]:
+        x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16)
+        w = (torch.randn((Cout, R, R, Cin), generator=g) / math.sqrt(Cin * R * R)).to(torch.bfloat16)
+        sc = torch.rand((Cout,), generator=g) + 0.5
+        bi = torch.randn((Cout,), generator=g) * 0.1
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=pad)
+        ref = ref * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)
+        r = None
+        if res:
+            r = torch.randn(ref.permute(0, 2, 3, 1).shape, generator=g).to(torch.bfloat16)
+            ref = ref + r.float().permute(0, 3, 1, 2)
+        ref = F.relu(ref)
+        out = ops.conv2d_nhwc(x.to(dev), w.to(dev), sc.to(dev), bi.to(dev), None if r is None else r.contiguous().to(dev),
+                              pad=pad, relu=True, out_dtype=odt)
+        got = out.float().cpu().permute(0, 3, 1, 2)
+        err = _relerr(got, ref)
+        assert err < (2e-2 if odt == torch.bfloat16 else 1e-4), "tile %s shape %s relerr %.3g" % (tile, (N, H, W, Cin, Cout, R), err)

@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--what", default="conv,attn,roi,pos")
+    ap.add_argument("--tiles", default="", help="comma list of forced igemm tiles to compare, e.g. 128x128,256x128")
     a = ap.parse_args()
     dt = {"bfloat16": torch.bfloat16, "float32": torch.float32}[a.dtype]
     dev = torch.device("cuda:0")
@@ -77,11 +78,20 @@ def main():
             sc = torch.ones((Cout,), device=dev); bi = torch.zeros((Cout,), device=dev)
             Ho = (H + 2 * pad - dil * (R - 1) - 1) // st + 1
             Wo = (W + 2 * pad - dil * (R - 1) - 1) // st + 1
+            extra = ""
+            for tl in [t for t in a.tiles.split(",") if t]:
+                os.environ["MEGA_IGEMM_TILE"] = tl
+                try:
+                    tms = timeit(lambda: ops.conv2d_nhwc(x, w, sc, bi, stride=st, pad=pad, dil=dil, relu=True), rounds=5, inner=2)
+                    extra += "  %s %.3f" % (tl, tms)
+                except Exception as e:  # noqa: BLE001
+                    extra += "  %s ERR" % tl
+            os.environ.pop("MEGA_IGEMM_TILE", None)
             ms = timeit(lambda: ops.conv2d_nhwc(x, w, sc, bi, stride=st, pad=pad, dil=dil, relu=True))
             fl = 2.0 * N * Ho * Wo * Cout * R * R * Cin
             by = (x.numel() + w.numel() + N * Ho * Wo * Cout) * x.element_size()
-            print("%-30s M=%7d N=%5d K=%6d  %8.3f ms  %7.1f TF/s  %7.1f GB/s  x%d" % (
-                name, N * Ho * Wo, Cout, R * R * Cin, ms, fl / ms / 1e9, by / ms / 1e6, cnt))
+            print("%-30s M=%7d N=%5d K=%6d  %8.3f ms  %7.1f TF/s  %7.1f GB/s  x%d%s" % (
+                name, N * Ho * Wo, Cout, R * R * Cin, ms, fl / ms / 1e9, by / ms / 1e6, cnt, extra))
             tot_ms += ms * cnt
             tot_fl += fl * cnt
             del x, w
