@@ -179,6 +179,7 @@ def main():
         elapsed = float(t.item())
     fps = K / elapsed
     log("timed region: %.3fs (%.2f frames/s)" % (elapsed, fps))
+    log("frame-stage batches so far: %s" % runner.graph_stats)
     ht = dict(runner.host_times)
     log("host ms/step: frame-stage enqueue %.3f, aggregation enqueue %.3f, waiting for results %.3f" % tuple(
         1e3 * ht[k] / max(ht["steps"], 1) for k in ("frame_enqueue", "aggregate_enqueue", "finish_wait")))

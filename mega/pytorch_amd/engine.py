@@ -82,6 +82,7 @@ class ClipEngine(object):
         self._rec_cache = {}              # frame id -> record (reuse_records)
         self._rec_pending = set()         # frame ids whose record is being computed by an enqueued batch
         self.frames_computed = 0
+        self.graph_stats = {"eager": 0, "captured": 0, "replayed": 0}
         self._streams = None
         # host-side seconds spent enqueuing / waiting, accumulated over run() calls (diagnostics for bench.py)
         self.host_times = {"frame_enqueue": 0.0, "aggregate_enqueue": 0.0, "finish_wait": 0.0, "steps": 0}
@@ -130,6 +131,7 @@ class ClipEngine(object):
         ent = self._fgraphs.get(key)
         if ent is None:
             self._fgraphs[key] = {}
+            self.graph_stats["eager"] += 1
             return m.frame_stage_async(imgs, want)
         if "graph" not in ent:
             ent["static_in"] = imgs.clone()
@@ -140,8 +142,10 @@ class ClipEngine(object):
             with torch.cuda.graph(g, pool=self._graph_pool):
                 ent["st"] = m.frame_stage_async(ent["static_in"], want)
             ent["graph"] = g
+            self.graph_stats["captured"] += 1
         ent["static_in"].copy_(imgs)
         ent["graph"].replay()
+        self.graph_stats["replayed"] += 1
         st = ent["st"]
         # the graph's outputs are overwritten by the next replay: hand out copies (6 MB per 16-frame batch)
         return {"props": st["props"].clone(), "scores": st["scores"].clone(), "cnt": st["cnt"].clone(),
@@ -244,6 +248,13 @@ class ClipEngine(object):
                         self._rec_pending.add(f)
                         todo.append((f, m.key_num, "l"))
                 flat = todo
+            elif self.use_graphs and clip.is_cuda and b[0] > 0 and 0 < b[1] - b[0] < self.steps_per_batch:
+                # a short last batch would be a NEW frame-stage shape: eager launches plus fresh allocator blocks
+                # (hipMalloc synchronises the device and stalls both streams, ~15 ms).  Pad it with repeats of its
+                # last step's jobs to the steady batch shape so that it replays the captured graph; the padded
+                # records are never consumed.
+                per = len(per_step[-1])
+                flat = flat + per_step[-1] * (self.steps_per_batch - (b[1] - b[0])) if per else flat
             self.frames_computed += len(flat)
             if not flat:
                 return per_step, {"none": True, "jobs": flat}, None

@@ -420,6 +420,7 @@ class MEGAFeatureExtractor(_Packed):
         self.out_channels = rep
         self.mem = None
         self.global_cache = None
+        self.cache_memory_kv = True      # keep the Wk / Wv projections of memory rows (False: re-project every step)
 
     # ---- kernel operands
     def _pack(self, dtype, device):
@@ -478,7 +479,7 @@ class MEGAFeatureExtractor(_Packed):
         n = self.mem_queue_list[i]["feats"][-1].shape[0]
         q = self.mem_queue_list[i]
         q["k"].append(k[:n])
-        q["vt"].append(vt[:, :n])
+        q["vt"].append(vt[:, :n].contiguous())      # contiguous pieces: the concatenation below is ONE batched copy
         self.mem[i]["k"] = torch.cat(list(q["k"]), dim=0)
         self.mem[i]["vt"] = torch.cat(list(q["vt"]), dim=1)
 
@@ -526,7 +527,7 @@ class MEGAFeatureExtractor(_Packed):
             feats_cur, k_loc, vt_loc = relation_attention_forward(
                 pk["local"][i], feats_cur.contiguous(), feats_ref.contiguous(), rois_cur.contiguous(),
                 rois_ref.contiguous(), residual=True, mem_kv=mem_kv, return_kv=True)
-            if self.memory_enable:
+            if self.memory_enable and self.cache_memory_kv:
                 self._remember_kv(i, k_loc, vt_loc)
             if i != self.stage - 1:
                 feats_cur = ops.linear(feats_cur, pk["fc_w"][i + 1], pk["fc_b"][i + 1], relu=True)
