@@ -199,23 +199,34 @@ def main():
             fam[k] = {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": round(v["launches"] / prof_steps, 1),
                       "tflops": round(v["flops"] / (v["ms"] * 1e9), 2) if v["ms"] > 0 else 0.0,
                       "gbps": round(v["bytes"] / (v["ms"] * 1e6), 1) if v["ms"] > 0 else 0.0}
-        dom = "igemm_bf16" if args.dtype == "bfloat16" else "igemm_f32"
+        # dominant kernel = the igemm instantiation (one rocprofv3 kernel symbol) with the largest share of GPU time
+        tag = "bf16" if args.dtype == "bfloat16" else "f32"
+        igemms = {k: v for k, v in summ.items() if k.startswith("igemm_" + tag)}
+        dom = max(igemms, key=lambda k: igemms[k]["ms"])
+        tile = dom.rsplit("_", 1)[1].split("x")
         peak = 2500.0 if args.dtype == "bfloat16" else 157.3
         d = summ[dom]
         ach = d["flops"] / (d["ms"] * 1e9)
+        fam_ms = sum(v["ms"] for v in igemms.values())
+        fam_fl = sum(v["flops"] for v in igemms.values())
         # HBM traffic per launch of the dominant variant, from the committed rocprofv3 PMC passes of this same
         # command (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction; tools/pmc_summary.py)
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc) and args.dtype == "bfloat16":
-            k = json.load(open(pmc))["kernels"].get("igemm_kernel<bf16, bf16, 128, 128>")
+        sym = "igemm_kernel<%s, %s, %s, %s>" % (tag if tag == "bf16" else "float", tag if tag == "bf16" else "float",
+                                                tile[0], tile[1])
+        if os.path.exists(pmc):
+            k = json.load(open(pmc))["kernels"].get(sym)
             if k:
                 traffic, traffic_src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/r01_pmc_summary.json"
-        roofline = {"bound": "mfma", "kernel": "igemm_kernel<%s> (implicit-GEMM conv / linear)" % args.dtype,
+        roofline = {"bound": "mfma", "kernel": sym + " (implicit-GEMM conv / linear)",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                     "flops_per_launch": round(d["flops"] / d["launches"], 0),
                     "share_of_gpu_time": round(d["ms"] / tot_ms, 3),
+                    "all_igemm_variants": {"achieved": round(fam_fl / (fam_ms * 1e9), 2),
+                                           "frac": round(fam_fl / (fam_ms * 1e9) / peak, 4),
+                                           "share_of_gpu_time": round(fam_ms / tot_ms, 3)},
                     "whole_path_frac": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / (peak * 1e12), 5)
                     if args.arch == "R-101" else None}
 

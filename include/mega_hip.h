@@ -44,12 +44,21 @@ extern "C" {
 int mega_conv2d_nhwc(const void* in, const void* w, const float* scale, const float* bias, const void* residual,
                      void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil,
                      int relu, int ldo, int ldr, int in_dtype, int out_dtype, void* stream);
+/* Which block tile (BM * 1000 + BN, i.e. which igemm_kernel<.., BM, BN> instantiation) mega_conv2d_nhwc launches for
+ * a GEMM of M = N*Ho*Wo rows, Cout columns, K = R*S*Cin: lets a profiler attribute time to the kernel symbol
+ * rocprofv3 reports.  No device work. */
+int mega_conv2d_nhwc_tile(int M, int Cout, int K);
 
 /* ResNet stem: 7x7 stride-2 pad-3 conv (3->64) + FrozenBN + ReLU  (resnet.py:347-366 BaseStem.forward,
  * without the max-pool).  in: NCHW f32 [N][3][H][W]; w_tap64: [147][64] f32 with tap = (c*7+r)*7+s;
  * out: NHWC [N][Ho][Wo][64], Ho = (H-1)/2+1. */
 int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, const float* scale, const float* bias, void* out,
                            int N, int H, int W, int out_dtype, void* stream);
+/* The same stem on the matrix cores (bf16 path): w_n160_bf16 = bf16 [64][160], row n = output channel, column
+ * k = (c*7+r)*7+s for k < 147 and zero for the 13 pad columns; out: NHWC bf16.  Image pixels and weights are rounded
+ * to bf16, accumulation is f32. */
+int mega_stem_conv_bn_relu_bf16(const float* in, const void* w_n160_bf16, const float* scale, const float* bias,
+                                void* out, int N, int H, int W, void* stream);
 
 /* F.max_pool2d(kernel 3, stride 2, padding 1) on NHWC (resnet.py:365). */
 int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);

@@ -16,6 +16,7 @@ _ERR = {1: "bad argument", 2: "kernel launch failure", 3: "workspace too small"}
 SIGNATURES = {
     "mega_conv2d_nhwc": (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_void_p]),
     "mega_stem_conv_bn_relu": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "mega_stem_conv_bn_relu_bf16": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "mega_maxpool3x3s2_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "mega_avgpool2x2_ceil_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "mega_roi_align_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] + [c_int] * 7 + [c_void_p]),
@@ -36,6 +37,7 @@ SIGNATURES = {
     "mega_relation_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                         c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                         c_int, c_void_p, c_size_t, c_void_p]),
+    "mega_conv2d_nhwc_tile": (c_int, [c_int] * 3),
     "mega_preprocess_frames": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
     "mega_dff_warp_scale": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "mega_resize_bilinear_u8": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p,

@@ -300,19 +300,22 @@ int launch(const ConvParams& p, hipStream_t st) {
 // blocks per CU wins every shape of the path except the very long-K 1024->1024 3x3 RPN conv, where 256x256 at one
 // block per CU is ~10 % faster; 256x128 never wins (one block of 4 waves per CU hides too little latency).  Small
 // grids shrink the tile to keep >= ~1.5 rounds of blocks over the 256 CUs.
+inline void choose_tile(int M, int Cout, int K, int& bm, int& bn) {
+  const char* force = getenv("MEGA_IGEMM_TILE");   // e.g. "256x128": experiments / tests only
+  if (force && sscanf(force, "%dx%d", &bm, &bn) == 2) return;
+  const long b256 = (long)cdiv(M, 256) * cdiv(Cout, 256);
+  const long b128 = (long)cdiv(M, 128) * cdiv(Cout, 128);
+  const long b12864 = (long)cdiv(M, 128) * cdiv(Cout, 64);
+  if (K >= 8192 && Cout >= 1024 && b256 >= 700) { bm = 256; bn = 256; }
+  else if (Cout > 64 && b128 >= 384) { bm = 128; bn = 128; }
+  else if (b12864 >= 384) { bm = 128; bn = 64; }
+  else { bm = 64; bn = 64; }
+}
+
 template <typename T, typename OT>
 int dispatch_tile(const ConvParams& p, hipStream_t st) {
-  const char* force = getenv("MEGA_IGEMM_TILE");   // e.g. "256x128": experiments / tests only
   int bm = 0, bn = 0;
-  if (!(force && sscanf(force, "%dx%d", &bm, &bn) == 2)) {
-    const long b256 = (long)cdiv(p.M, 256) * cdiv(p.Cout, 256);
-    const long b128 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 128);
-    const long b12864 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 64);
-    if (p.K >= 8192 && p.Cout >= 1024 && b256 >= 700) { bm = 256; bn = 256; }
-    else if (p.Cout > 64 && b128 >= 384) { bm = 128; bn = 128; }
-    else if (b12864 >= 384) { bm = 128; bn = 64; }
-    else { bm = 64; bn = 64; }
-  }
+  choose_tile(p.M, p.Cout, p.K, bm, bn);
   if (bm == 256 && bn == 256) return launch<T, OT, 256, 256>(p, st);
   if (bm == 256 && bn == 128) return launch<T, OT, 256, 128>(p, st);
   if (bm == 128 && bn == 128) return launch<T, OT, 128, 128>(p, st);
@@ -321,6 +324,12 @@ int dispatch_tile(const ConvParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int mega_conv2d_nhwc_tile(int M, int Cout, int K) {
+  int bm = 0, bn = 0;
+  choose_tile(M, Cout, K, bm, bn);
+  return bm * 1000 + bn;
+}
 
 extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scale, const float* bias,
                                 const void* residual, void* out, int N, int H, int W, int Cin, int Cout,

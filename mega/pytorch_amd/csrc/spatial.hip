@@ -281,7 +281,108 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------ stem conv on the matrix cores
+// bf16 path: the same 7x7/2 conv as a GEMM  out[pixel][n] = sum_k A[pixel][k] * W[n][k],  k = (c*7 + r)*7 + s padded
+// 147 -> 160 = 10 MFMA steps of 16.  A block owns an 8 x 32 tile of output pixels: its 3 x 21 x 69 input patch sits in
+// LDS as bf16, and a lane builds its A fragment (one pixel, 8 consecutive k) with eight 2-byte LDS reads whose
+// addresses differ between lanes only by the pixel's column (stride 4 B: conflict-free).  W (bf16 [64][160], packed
+// once on the host) is staged with a 336-B row stride (conflict-free ds_read_b128).  3 GF per frame: the kernel is
+// bound by reading the f32 image and writing the 64-channel map, not by the MFMAs.
+constexpr int SM_TY = 8, SM_TX = 32;
+constexpr int SM_PH = 2 * SM_TY + 5, SM_PW = 2 * SM_TX + 5, SM_PS = 72;   // patch rows / cols / row stride (elements)
+constexpr int SM_K = 160, SM_WS = 168;                                    // padded K, LDS weight row stride (elements)
+
+__host__ __device__ constexpr int stem_patch_off(int k) {   // LDS element offset of tap k relative to the pixel's origin
+  const int kk = k < 147 ? k : 146;                       // taps 147..159 meet zero weights: any valid address will do
+  return (kk / 49) * (SM_PH * SM_PS) + ((kk % 49) / 7) * SM_PS + (kk % 7);
+}
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ in, const bf16_t* __restrict__ w,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                        int N, int H, int W, int Ho, int Wo) {
+  __shared__ __attribute__((aligned(16))) unsigned short patch[3 * SM_PH * SM_PS];
+  __shared__ __attribute__((aligned(16))) unsigned short wl[64 * SM_WS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.z;
+  const int oy0 = blockIdx.y * SM_TY, ox0 = blockIdx.x * SM_TX;
+  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+  for (int e = tid; e < 3 * SM_PH * SM_PW; e += 256) {
+    const int c = e / (SM_PH * SM_PW);
+    const int rem = e - c * (SM_PH * SM_PW);
+    const int y = rem / SM_PW, x = rem - y * SM_PW;
+    const int iy = iy0 + y, ix = ix0 + x;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = in[((size_t)(n * 3 + c) * H + iy) * W + ix];
+    patch[(c * SM_PH + y) * SM_PS + x] = f32_to_bf16(v);
+  }
+  for (int e = tid; e < 64 * (SM_K / 8); e += 256) {
+    const int row = e / (SM_K / 8), v = e - row * (SM_K / 8);
+    *reinterpret_cast<uint4*>(&wl[row * SM_WS + v * 8]) = *reinterpret_cast<const uint4*>(w + row * SM_K + v * 8);
+  }
+  __syncthreads();
+
+  const int p = lane & 31, half = lane >> 5;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < SM_K / 16; ++ks) {
+    uint4 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned short* base = patch + (2 * (2 * wave + i)) * SM_PS + 2 * p;
+      unsigned v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = base[half ? stem_patch_off(ks * 16 + 8 + e) : stem_patch_off(ks * 16 + e)];
+      a[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      b[j] = *reinterpret_cast<const uint4*>(&wl[(j * 32 + p) * SM_WS + ks * 16 + half * 8]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]),
+                                                            __builtin_bit_cast(bf16x8_t, b[j]), acc[i][j], 0, 0, 0);
+  }
+  // lane owns channel (lane & 31) + 32 j and the pixels (r&3) + 8 (r>>2) + 4 half of output row 2*wave + i
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ch = j * 32 + p;
+    const float sc = scale[ch], bi = bias[ch];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = oy0 + 2 * wave + i;
+      if (oy >= Ho) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ox < Wo) out[(((size_t)n * Ho + oy) * Wo + ox) * 64 + ch] = f32_to_bf16(fmaxf(acc[i][j][r] * sc + bi, 0.f));
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int mega_stem_conv_bn_relu_bf16(const float* in, const void* w_n160_bf16, const float* scale,
+                                           const float* bias, void* out, int N, int H, int W, void* stream) {
+  mega_clear_error();
+  if (!in || !w_n160_bf16 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  dim3 grid(cdiv(Wo, SM_TX), cdiv(Ho, SM_TY), N);
+  hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)w_n160_bf16, scale,
+                     bias, (bf16_t*)out, N, H, W, Ho, Wo);
+  return mega_check_launch();
+}
 
 extern "C" int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, const float* scale, const float* bias,
                                       void* out, int N, int H, int W, int out_dtype, void* stream) {

@@ -176,11 +176,14 @@ class BaseStem(_Packed):
     def _pack(self, dtype, device):
         s, b = self.bn1.folded()
         w = self.conv1.weight.detach().float().permute(1, 2, 3, 0).reshape(147, 64).contiguous()
-        return {"w": w.to(device), "s": s.to(device), "b": b.to(device)}
+        pk = {"w": w.to(device), "s": s.to(device), "b": b.to(device), "w160": None}
+        if dtype == torch.bfloat16:
+            pk["w160"] = ops.pack_stem_weight_bf16(self.conv1.weight).to(device)
+        return pk
 
     def run(self, img_nchw_f32, dtype):
         pk = self._packed(dtype, img_nchw_f32.device)
-        y = ops.stem(img_nchw_f32, pk["w"], pk["s"], pk["b"], dtype)
+        y = ops.stem(img_nchw_f32, pk["w"], pk["s"], pk["b"], dtype, w_n160=pk["w160"])
         return ops.maxpool3x3s2(y)
 
 

@@ -108,7 +108,12 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
         assert residual.shape == out.shape and residual.dtype == x.dtype and residual.is_contiguous()
     for v in (scale, bias):
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
-    _tok = _pb("igemm_" + ("bf16" if x.dtype == torch.bfloat16 else "f32"), 2.0 * N * Ho * Wo * Cout * R * S * Cin, x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size())
+    _tok = None
+    if _PROF is not None:      # family = the kernel symbol rocprofv3 would report for this launch
+        t = lib.mega_conv2d_nhwc_tile(N * Ho * Wo, Cout, R * S * Cin)
+        _tok = _pb("igemm_%s_%dx%d" % ("bf16" if x.dtype == torch.bfloat16 else "f32", t // 1000, t % 1000),
+                   2.0 * N * Ho * Wo * Cout * R * S * Cin,
+                   x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size())
     rc = lib.mega_conv2d_nhwc(_ptr(x), _ptr(w), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin,
                               Cout, R, S, stride, pad, dil, int(relu), Cout, Cout, _dt(x), _DT[odt], _stream())
     _pe(_tok)
@@ -125,8 +130,9 @@ def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=Non
     return y.view(M, w.shape[0])
 
 
-def stem(x_nchw, w_tap64, scale, bias, out_dtype):
-    """x [N,3,H,W] f32 -> conv7x7 s2 + BN + ReLU -> NHWC [N,Ho,Wo,64]."""
+def stem(x_nchw, w_tap64, scale, bias, out_dtype, w_n160=None):
+    """x [N,3,H,W] f32 -> conv7x7 s2 + BN + ReLU -> NHWC [N,Ho,Wo,64].  f32: direct conv with w_tap64 [147,64] f32;
+    bf16: matrix-core kernel with w_n160 = bf16 [64,160] (see pack_stem_weight_bf16)."""
     _gpu(x_nchw, w_tap64, scale, bias)
     lib = _lib.load()
     N, C, H, W = x_nchw.shape
@@ -134,11 +140,24 @@ def stem(x_nchw, w_tap64, scale, bias, out_dtype):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = torch.empty((N, Ho, Wo, 64), dtype=out_dtype, device=x_nchw.device)
     _tok = _pb("stem", 2.0 * N * Ho * Wo * 64 * 147, x_nchw.numel() * 4 + out.numel() * out.element_size())
-    rc = lib.mega_stem_conv_bn_relu(_ptr(x_nchw), _ptr(w_tap64), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
-                                    _DT[out_dtype], _stream())
+    if out_dtype == torch.bfloat16 and w_n160 is not None:
+        _gpu(w_n160)
+        assert w_n160.dtype == torch.bfloat16 and tuple(w_n160.shape) == (64, 160) and w_n160.is_contiguous()
+        rc = lib.mega_stem_conv_bn_relu_bf16(_ptr(x_nchw), _ptr(w_n160), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
+                                             _stream())
+    else:
+        rc = lib.mega_stem_conv_bn_relu(_ptr(x_nchw), _ptr(w_tap64), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
+                                        _DT[out_dtype], _stream())
     _pe(_tok)
     _lib.check(rc, "mega_stem_conv_bn_relu")
     return out
+
+
+def pack_stem_weight_bf16(w_oihw):
+    """conv1.weight [64,3,7,7] -> bf16 [64,160]: column k = (c*7+r)*7+s, 13 zero pad columns."""
+    w = torch.zeros((64, 160), dtype=torch.float32, device=w_oihw.device)
+    w[:, :147] = w_oihw.detach().float().reshape(64, 147)
+    return w.to(torch.bfloat16).contiguous()
 
 
 def maxpool3x3s2(x):
@@ -328,7 +347,11 @@ def linear_transposed(w, x, ld):
     M = x.shape[0]
     assert x.shape[1] == K and ld >= M and w.dtype == x.dtype and w.is_contiguous() and x.is_contiguous()
     out = torch.zeros((Nout, ld), dtype=x.dtype, device=x.device)
-    _tok = _pb("igemm_" + ("bf16" if x.dtype == torch.bfloat16 else "f32"), 2.0 * Nout * M * K, (w.numel() + x.numel() + out.numel()) * x.element_size())
+    _tok = None
+    if _PROF is not None:
+        t = lib.mega_conv2d_nhwc_tile(Nout, M, K)
+        _tok = _pb("igemm_%s_%dx%d" % ("bf16" if x.dtype == torch.bfloat16 else "f32", t // 1000, t % 1000),
+                   2.0 * Nout * M * K, (w.numel() + x.numel() + out.numel()) * x.element_size())
     rc = lib.mega_conv2d_nhwc(_ptr(w), _ptr(x), None, None, None, _ptr(out), Nout, 1, 1, K, M, 1, 1, 1, 0, 1, 0, ld,
                               ld, _dt(x), _dt(x), _stream())
     _pe(_tok)

@@ -362,3 +362,31 @@ def test_conv_every_tile_shape(dev, tile, monkeypatch):
         got = out.float().cpu().permute(0, 3, 1, 2)
         err = _relerr(got, ref)
         assert err < (2e-2 if odt == torch.bfloat16 else 1e-4), "tile %s shape %s relerr %.3g" % (tile, (N, H, W, Cin, Cout, R), err)
+
+
+def test_stem_mfma_bf16(dev):
+    """matrix-core stem (bf16 pixels x bf16 weights, f32 accumulate) vs the f32 conv of the SAME bf16-rounded operands
+    (tight), vs the direct f32-math kernel (bf16-class), and on a size with partial tiles on both edges."""
+    ops = _ops()
+    from oracle import mega_oracle as mo
+    from mega.pytorch_amd import synth
+    sd = synth.make_state_dict(blocks=(1, 1, 1), seed=2)
+    g = torch.Generator().manual_seed(5)
+    p = "backbone.body.stem."
+    w = sd[p + "conv1.weight"]
+    scale = sd[p + "bn1.weight"] * sd[p + "bn1.running_var"].rsqrt()
+    bias = sd[p + "bn1.bias"] - sd[p + "bn1.running_mean"] * scale
+    w_tap = w.permute(1, 2, 3, 0).reshape(147, 64).contiguous()
+    w160 = ops.pack_stem_weight_bf16(w)
+    assert w160.shape == (64, 160) and not w160[:, 147:].any()
+    for (N, H, W) in [(2, 75, 101), (1, 600, 1000), (3, 33, 70)]:
+        x = torch.randn((N, 3, H, W), generator=g) * 60
+        got = ops.stem(x.to(dev), w_tap.to(dev), scale.to(dev), bias.to(dev), torch.bfloat16, w_n160=w160.to(dev))
+        got = got.float().cpu().permute(0, 3, 1, 2)
+        conv = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), stride=2, padding=3)
+        ref = F.relu(conv * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+        assert got.shape == ref.shape
+        # output is stored as bf16: half an ulp of the result is the floor
+        assert (got - ref).abs().max() <= 2 ** -8 * ref.abs().max() + 1e-6, (N, H, W, (got - ref).abs().max())
+        direct = ops.stem(x.to(dev), w_tap.to(dev), scale.to(dev), bias.to(dev), torch.bfloat16).float().cpu().permute(0, 3, 1, 2)
+        assert _relerr(got, direct) < 2e-2
