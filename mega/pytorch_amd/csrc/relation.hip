@@ -101,6 +101,75 @@ __global__ __launch_bounds__(256) void pos_logits_kernel(const float4* __restric
     out[((size_t)h * Nq + q) * ldp + k] = logf(fmaxf(acc[h], 0.f) + 1e-6f);
 }
 
+// Fast (bf16-mode) variant with the 64 -> 16 Wg contraction on the matrix cores.  A wave handles tiles of 16 (q, k)
+// pairs (one q, 16 consecutive k): v_mfma_f32_16x16x32_bf16 with A = the pairs' embedding (row = lane & 15,
+// k = 8 (lane >> 4) + e), B = Wg^T (col = head), two K-steps for the 64-d embedding.  The four lanes that share a pair
+// each build a quarter of its embedding (one delta's 8 sines or 8 cosines per K-step), so no value is computed twice
+// and the 1024 FMAs per pair of the VALU version disappear.  D: col = head, rows = 4 consecutive pairs -> 16-B stores.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __restrict__ rois_q,
+                                                              const float4* __restrict__ rois_k,
+                                                              const float* __restrict__ wgt,
+                                                              const float* __restrict__ bg,
+                                                              const float* __restrict__ dim_mat,
+                                                              float* __restrict__ out, int Nq, int Nk, int ldp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane & 15, g = lane >> 4;          // pair within the tile / k-group (A, B);  head = row (B, D)
+  const int q = blockIdx.y;
+  // B fragments: Wg^T[k][head] for k = 32 s + 8 g + e
+  bf16x8_t bw[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bw[s][e] = (__bf16)wgt[(32 * s + 8 * g + e) * 16 + row];
+  float rdim[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rdim[i] = 1.0f / dim_mat[i];
+  const float bias = bg[row];
+  const float4 bq = rois_q[q];
+  const float wq = bq.z - bq.x + 1.f, hq = bq.w - bq.y + 1.f;
+  const float cxq = 0.5f * (bq.x + bq.z), cyq = 0.5f * (bq.y + bq.w);
+  const bool use_cos = g & 1;
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    const int k0 = blockIdx.x * 256 + wave * 64 + t * 16;
+    if (k0 >= Nk) break;
+    const int k = min(k0 + row, Nk - 1);
+    const float4 bk = rois_k[k];
+    const float wk = bk.z - bk.x + 1.f, hk = bk.w - bk.y + 1.f;
+    const float cxk = 0.5f * (bk.x + bk.z), cyk = 0.5f * (bk.y + bk.w);
+    // K-step s covers deltas 2 s and 2 s + 1; this lane owns delta d = 2 s + (g >> 1)
+    float pm[2];
+    if (g >> 1) {
+      pm[0] = logf(fabsf((cyq - cyk) / hq) + 1e-3f);   // d = 1
+      pm[1] = logf(hq / hk);                           // d = 3
+    } else {
+      pm[0] = logf(fabsf((cxq - cxk) / wq) + 1e-3f);   // d = 0
+      pm[1] = logf(wq / wk);                           // d = 2
+    }
+    f32x4_t acc = {bias, bias, bias, bias};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float pv = pm[s] * 100.0f;
+      bf16x8_t a;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float sn, cs;
+        sincos_reduced(pv * rdim[i], &sn, &cs);
+        a[i] = (__bf16)(use_cos ? cs : sn);
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[s], acc, 0, 0, 0);
+    }
+    // D: head = lane & 15, pairs k0 + 4 g + r
+    float4 o;
+    o.x = logf(fmaxf(acc[0], 0.f) + 1e-6f); o.y = logf(fmaxf(acc[1], 0.f) + 1e-6f);
+    o.z = logf(fmaxf(acc[2], 0.f) + 1e-6f); o.w = logf(fmaxf(acc[3], 0.f) + 1e-6f);
+    float* dst = out + ((size_t)row * Nq + q) * ldp + k0 + 4 * g;
+    if (k0 + 4 * g + 3 < ldp) *reinterpret_cast<float4*>(dst) = o;    // ldp % 4 == 0: pad columns may be written
+  }
+}
+
 // ----------------------------------------------------------------------------------------------- attention
 template <typename T> struct AttnCfg;
 template <> struct AttnCfg<bf16_t> {
@@ -424,6 +493,9 @@ extern "C" int mega_position_logits(const float* rois_q, const float* rois_k, co
   dim3 grid(cdiv(Nk, 256), Nq);
   if (precise)
     hipLaunchKernelGGL((pos_logits_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
+                       (const float4*)rois_k, wg_t, bg, dim_mat, out, Nq, Nk, ldp);
+  else if (ldp % 4 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0)
+    hipLaunchKernelGGL(pos_logits_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
                        (const float4*)rois_k, wg_t, bg, dim_mat, out, Nq, Nk, ldp);
   else
     hipLaunchKernelGGL((pos_logits_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,

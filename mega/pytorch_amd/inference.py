@@ -79,11 +79,15 @@ def videos_for_rank(videos, rank, world):
 
 def compute_on_dataset(model, index, img_dir, device, videos=None, steps_per_batch=10, seed=0, timer=None,
                        source_kwargs=None, engine_kwargs=None):
-    """inference.py:17-47: -> {dataset index: BoxList on the host}."""
+    """inference.py:17-47: -> {dataset index: BoxList on the host}.  The engine runs with reuse_records=True unless
+    engine_kwargs says otherwise: every frame of a video goes through the frame stage once and serves both its
+    local-window and its global-pool role (bit-identical detections on the GPU, ~half the backbone work)."""
     model.eval()
     results = {}
     videos = index.videos if videos is None else videos
-    eng = _engine.ClipEngine(model, steps_per_batch=steps_per_batch, **(engine_kwargs or {}))
+    ek = dict(reuse_records=True)
+    ek.update(engine_kwargs or {})
+    eng = _engine.ClipEngine(model, steps_per_batch=steps_per_batch, **ek)
     gsize = model.cfg.MODEL.VID.MEGA.GLOBAL.SIZE
     for vi, v in enumerate(videos):
         src = feed.FrameSource(os.path.join(img_dir, "%s.JPEG"), v["pattern"], v["seg_len"], device,

@@ -78,7 +78,7 @@ def test_inference_writes_reference_format_predictions(monkeypatch, tmp_path):
     cfg, model = _model()
     out = str(tmp_path / "out")
     preds = inference.inference(cfg, model, img_dir, idx, output_folder=out, steps_per_batch=3,
-                                engine_kwargs={"overlap": False, "graphs": False}, source_kwargs={"workers": 2})
+                                engine_kwargs={"overlap": False, "graphs": False, "reuse_records": False}, source_kwargs={"workers": 2})
     assert len(preds) == 12
     # same detections as the engine on the pre-resized resident clip of each video
     _, model2 = _model()
@@ -117,7 +117,7 @@ def _worker(rank, world, port, root, outdir):
     cfg, model = _model()
     preds = inference.inference(cfg, model, os.path.join(root, "Data"), os.path.join(root, "index.txt"),
                                 output_folder=outdir, steps_per_batch=3,
-                                engine_kwargs={"overlap": False, "graphs": False}, source_kwargs={"workers": 1})
+                                engine_kwargs={"overlap": False, "graphs": False, "reuse_records": False}, source_kwargs={"workers": 1})
     assert (preds is None) == (rank != 0)
     dist.barrier()
     dist.destroy_process_group()
@@ -135,7 +135,7 @@ def test_video_sharded_inference_world2(monkeypatch, tmp_path):
     cpu_ops.install(monkeypatch)
     cfg, model = _model()
     single = inference.inference(cfg, model, os.path.join(root, "Data"), os.path.join(root, "index.txt"),
-                                 steps_per_batch=3, engine_kwargs={"overlap": False, "graphs": False})
+                                 steps_per_batch=3, engine_kwargs={"overlap": False, "graphs": False, "reuse_records": False})
     both = inference.load_predictions(os.path.join(out2, "predictions.pth"))
     assert len(both) == len(single) == 12
     for a, b in zip(both, single):

@@ -269,10 +269,13 @@ def test_position_logits(dev):
     assert (got.exp() - ref.exp()).abs().max() < 2e-5
     big = ref > -8
     assert (got[big] - ref[big]).abs().max() < 5e-2
-    # fast mode (bf16 path): Cody-Waite reduction + hardware sin/cos
+    # fast mode (bf16 path): Cody-Waite reduction + hardware sin/cos, embedding and Wg rounded to bf16 for the
+    # matrix-core contraction (64 products of ~2^-8 relative error each): bf16-class tolerance on the softmax weight
     fast = ops.position_logits(bq.to(dev), bk.to(dev), w.view(16, 64).t().contiguous().to(dev), bias.to(dev),
                                mo.dim_mat_values().to(dev), precise=False).cpu()[:, :, :bk.shape[0]]
-    assert (fast.exp() - ref.exp()).abs().max() < 1e-4
+    err = (fast.exp() - ref.exp()).abs()
+    assert err.max() < 6e-3 and err.mean() < 1e-3, (err.max(), err.mean())
+    assert torch.isfinite(fast).all()
 
 
 def test_preprocess(dev):
