@@ -124,6 +124,11 @@ def cpu_baseline(arch, sd, H, W, budget_s):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): everything else any library writes to fd 1 -- RCCL prints a
+    # version banner there at exit -- is sent to stderr.
+    json_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,9 +138,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("MEGA_FORCE_SHARDED") == "1":   # the latter: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
         group = dist.group.WORLD
     from mega.pytorch_amd import engine as eng, ops
@@ -251,8 +259,8 @@ def main():
                        "key_proposals_last_frame": int(model.records[model.key_frame_location]["boxes"].shape[0])},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_families": fam,
         }
-        print(json.dumps(line))
-    if world > 1:
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if world > 1 or os.environ.get("MEGA_FORCE_SHARDED") == "1":
         dist.destroy_process_group()
 
 

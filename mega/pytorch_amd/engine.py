@@ -72,6 +72,8 @@ class ClipEngine(object):
             self.rank, self.world = dist.get_rank(dist_group), dist.get_world_size(dist_group)
         else:
             self.dist, self.rank, self.world = None, 0, 1
+        import os as _os      # diagnostics: take the sharded (all-gather) branch even with one rank
+        self.force_sharded = dist_group is not None and _os.environ.get("MEGA_FORCE_SHARDED") == "1"
         self.mean = tuple(model.cfg.INPUT.PIXEL_MEAN)
         self.to_bgr = bool(model.cfg.INPUT.TO_BGR255)
         self.overlap = overlap
@@ -155,7 +157,7 @@ class ClipEngine(object):
         """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
         records_resolve()."""
         m = self.model
-        if self.world == 1:
+        if self.world == 1 and not self.force_sharded:
             return {"st": self._frame_stage(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs])}
         # ---- sharded: contiguous slices of the (padded) job list per rank, fixed-size records, one all-gather each
         n = len(jobs)
