@@ -49,6 +49,16 @@ int mega_conv2d_nhwc(const void* in, const void* w, const float* scale, const fl
  * rocprofv3 reports.  No device work. */
 int mega_conv2d_nhwc_tile(int M, int Cout, int K);
 
+/* mega_conv2d_nhwc with a caller-owned workspace of mega_conv2d_nhwc_workspace_bytes(M, Cout, K) bytes (M = N*Ho*Wo,
+ * K = R*S*Cin; 0 for most layers).  With it, layers with K >= 32768 (the box head's first FC, K = 100352) run
+ * split-K: two K ranges per output tile write f32 partial sums into the workspace and a second kernel adds them in a
+ * fixed order and applies scale / bias / residual / activation.  The split depends on K only, never on M, so a
+ * row's result does not depend on the batch it is computed in.  mega_conv2d_nhwc (no workspace) never splits. */
+size_t mega_conv2d_nhwc_workspace_bytes(int M, int Cout, int K);
+int mega_conv2d_nhwc_ws(const void* in, const void* w, const float* scale, const float* bias, const void* residual,
+                        void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil,
+                        int relu, int ldo, int ldr, int in_dtype, int out_dtype, void* ws, size_t ws_bytes, void* stream);
+
 /* ResNet stem: 7x7 stride-2 pad-3 conv (3->64) + FrozenBN + ReLU  (resnet.py:347-366 BaseStem.forward,
  * without the max-pool).  in: NCHW f32 [N][3][H][W]; w_tap64: [147][64] f32 with tap = (c*7+r)*7+s;
  * out: NHWC [N][Ho][Wo][64], Ho = (H-1)/2+1. */

@@ -15,6 +15,8 @@ _ERR = {1: "bad argument", 2: "kernel launch failure", 3: "workspace too small"}
 # name -> (restype, argtypes).  Must list every symbol declared in include/mega_hip.h.
 SIGNATURES = {
     "mega_conv2d_nhwc": (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_void_p]),
+    "mega_conv2d_nhwc_ws": (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_void_p, c_size_t, c_void_p]),
+    "mega_conv2d_nhwc_workspace_bytes": (c_size_t, [c_int] * 3),
     "mega_stem_conv_bn_relu": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "mega_stem_conv_bn_relu_bf16": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "mega_maxpool3x3s2_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),

@@ -39,6 +39,8 @@ struct ConvParams {
   int ldo, ldr;
   int relu;
   unsigned in_bytes, w_bytes;
+  int ksplit;        // > 1: blockIdx.z owns a contiguous range of K-tiles and writes raw f32 partial sums
+  float* partial;    // [ksplit][M][Cout] f32 when ksplit > 1
 };
 
 template <typename T> struct Mma;
@@ -124,8 +126,14 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
     b_off[j] = b_ok[j] ? ((unsigned)n * (unsigned)p.K + vec * VE) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
   }
 
-  int kr = 0, ks = 0, kc = 0;  // (r, s, c0) of the tile about to be loaded
-  int kk = 0;                  // k offset of that tile
+  // split-K: this block's K-tile range (the whole K when ksplit == 1)
+  const int nkt_all = p.K / KE;
+  const int kt_per = (nkt_all + p.ksplit - 1) / p.ksplit;
+  const int kt0 = (int)blockIdx.z * kt_per;
+  const int nkt = min(kt_per, nkt_all - kt0);
+  int kk = kt0 * KE;           // k offset of the tile about to be loaded
+  int kc = kk % p.Cin;         // and its (r, s, c0)
+  int ks = (kk / p.Cin) % p.S, kr = (kk / p.Cin) / p.S;
 
   auto load_tile = [&](uint4 (&areg)[AV], uint4 (&breg)[BV]) {
     const int dh = kr * p.dil, dw = ks * p.dil;
@@ -191,7 +199,6 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
 
   // ---- main loop: global loads run TWO K-tiles ahead of the MFMAs (two register sets, two LDS buffers,
   //      one barrier per K-tile); the store of tile t+1 waits only for the older register set.
-  const int nkt = p.K / KE;
   uint4 ra[AV], rb[BV], sa[AV], sb[BV];
   //      The steady-state body has NO conditionals (hipcc merges wait counts conservatively at control-flow
   //      joins: one conditional load collapses the counted vmcnt into vmcnt(0)).  Tiles past the end of K are
@@ -235,8 +242,8 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-    sc[j] = (p.scale && n < p.Cout) ? p.scale[n] : 1.f;
-    bi[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+    sc[j] = (p.ksplit == 1 && p.scale && n < p.Cout) ? p.scale[n] : 1.f;
+    bi[j] = (p.ksplit == 1 && p.bias && n < p.Cout) ? p.bias[n] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -249,6 +256,22 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
       for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][j][r] * sc[j] + bi[j];
     }
     __syncthreads();
+    if (p.ksplit > 1) {     // raw partial sums (sc = 1, bi = 0 were forced above); splitk_finalize_kernel finishes
+      float* part = p.partial + (size_t)blockIdx.z * p.M * p.Cout;
+      for (int e = tid; e < 64 * (BN / 4); e += NTHREADS) {
+        const int row = e / (BN / 4), cv = e - row * (BN / 4);
+        const int m = m0 + (row >> 5) * WTM + i * 32 + (row & 31), n = n0 + cv * 4;
+        if (m >= p.M || n >= p.Cout) continue;
+        const float4 f = *reinterpret_cast<const float4*>(cs + row * CST + cv * 4);
+        if (n + 4 <= p.Cout && p.Cout % 4 == 0) {
+          *reinterpret_cast<float4*>(part + (size_t)m * p.Cout + n) = f;
+        } else {
+          const float v[4] = {f.x, f.y, f.z, f.w};
+          for (int t = 0; t < 4 && n + t < p.Cout; ++t) part[(size_t)m * p.Cout + n + t] = v[t];
+        }
+      }
+      continue;
+    }
     for (int e = tid; e < 64 * VPR; e += NTHREADS) {
       const int row = e / VPR, cv = e - row * VPR;
       const int m = m0 + (row >> 5) * WTM + i * 32 + (row & 31), n = n0 + cv * OVE;
@@ -292,7 +315,31 @@ int launch(const ConvParams& p, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)igemm_kernel<T, OT, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, OT, BM, BN>), dim3(ntm * ntn), dim3(NTHREADS), smem, st, p);
+  hipLaunchKernelGGL((igemm_kernel<T, OT, BM, BN>), dim3(ntm * ntn, 1, p.ksplit), dim3(NTHREADS), smem, st, p);
+  return mega_check_launch();
+}
+
+// out[m][n] = act((sum_z partial[z][m][n]) * scale[n] + bias[n] + res[m][n]); fixed summation order -> deterministic
+template <typename T, typename OT>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(ConvParams p) {
+  const size_t total = (size_t)p.M * p.Cout;
+  const float neg_slope = p.relu == 1 ? 0.f : (p.relu == 2 ? 0.1f : 1.f);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / p.Cout), n = (int)(i - (size_t)m * p.Cout);
+    float v = 0.f;
+    for (int z = 0; z < p.ksplit; ++z) v += p.partial[(size_t)z * total + i];
+    v = v * (p.scale ? p.scale[n] : 1.f) + (p.bias ? p.bias[n] : 0.f);
+    if (p.res) v += Elem<T>::ld((const T*)p.res + (size_t)m * p.ldr + n);
+    v = v > 0.f ? v : v * neg_slope;
+    Elem<OT>::st((OT*)p.out + (size_t)m * p.ldo + n, v);
+  }
+}
+
+template <typename T, typename OT>
+int launch_finalize(const ConvParams& p, hipStream_t st) {
+  const size_t total = (size_t)p.M * p.Cout;
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL((splitk_finalize_kernel<T, OT>), dim3(blocks), dim3(256), 0, st, p);
   return mega_check_launch();
 }
 
@@ -300,12 +347,17 @@ int launch(const ConvParams& p, hipStream_t st) {
 // blocks per CU wins every shape of the path except the very long-K 1024->1024 3x3 RPN conv, where 256x256 at one
 // block per CU is ~10 % faster; 256x128 never wins (one block of 4 waves per CU hides too little latency).  Small
 // grids shrink the tile to keep >= ~1.5 rounds of blocks over the 256 CUs.
-inline void choose_tile(int M, int Cout, int K, int& bm, int& bn) {
+// Split-K depends on K ALONE (never on M): a row of a layer is then summed in the same order whatever batch it is part
+// of, which keeps results batch-invariant (tests: reference call convention == batched engine, bit for bit).  Only
+// the box head's first FC (K = 100352 on R-101) qualifies: two halves of 784 K-tiles double the resident blocks.
+inline int choose_ksplit(int K) { return K >= 32768 ? 2 : 1; }
+
+inline void choose_tile(int M, int Cout, int K, int z, int& bm, int& bn) {
   const char* force = getenv("MEGA_IGEMM_TILE");   // e.g. "256x128": experiments / tests only
   if (force && sscanf(force, "%dx%d", &bm, &bn) == 2) return;
-  const long b256 = (long)cdiv(M, 256) * cdiv(Cout, 256);
-  const long b128 = (long)cdiv(M, 128) * cdiv(Cout, 128);
-  const long b12864 = (long)cdiv(M, 128) * cdiv(Cout, 64);
+  const long b256 = (long)cdiv(M, 256) * cdiv(Cout, 256) * z;
+  const long b128 = (long)cdiv(M, 128) * cdiv(Cout, 128) * z;
+  const long b12864 = (long)cdiv(M, 128) * cdiv(Cout, 64) * z;
   if (K >= 8192 && Cout >= 1024 && b256 >= 700) { bm = 256; bn = 256; }
   else if (Cout > 64 && b128 >= 384) { bm = 128; bn = 128; }
   else if (b12864 >= 384) { bm = 128; bn = 64; }
@@ -314,27 +366,34 @@ inline void choose_tile(int M, int Cout, int K, int& bm, int& bn) {
 
 template <typename T, typename OT>
 int dispatch_tile(const ConvParams& p, hipStream_t st) {
-  int bm = 0, bn = 0;
-  choose_tile(p.M, p.Cout, p.K, bm, bn);
-  if (bm == 256 && bn == 256) return launch<T, OT, 256, 256>(p, st);
-  if (bm == 256 && bn == 128) return launch<T, OT, 256, 128>(p, st);
-  if (bm == 128 && bn == 128) return launch<T, OT, 128, 128>(p, st);
-  if (bm == 128 && bn == 64) return launch<T, OT, 128, 64>(p, st);
-  return launch<T, OT, 64, 64>(p, st);
+  int bm = 0, bn = 0, rc;
+  choose_tile(p.M, p.Cout, p.K, p.ksplit, bm, bn);
+  if (bm == 256 && bn == 256) rc = launch<T, OT, 256, 256>(p, st);
+  else if (bm == 256 && bn == 128) rc = launch<T, OT, 256, 128>(p, st);
+  else if (bm == 128 && bn == 128) rc = launch<T, OT, 128, 128>(p, st);
+  else if (bm == 128 && bn == 64) rc = launch<T, OT, 128, 64>(p, st);
+  else rc = launch<T, OT, 64, 64>(p, st);
+  if (rc == MEGA_OK && p.ksplit > 1) rc = launch_finalize<T, OT>(p, st);
+  return rc;
 }
 
 }  // namespace
 
 extern "C" int mega_conv2d_nhwc_tile(int M, int Cout, int K) {
   int bm = 0, bn = 0;
-  choose_tile(M, Cout, K, bm, bn);
+  choose_tile(M, Cout, K, choose_ksplit(K), bm, bn);
   return bm * 1000 + bn;
 }
 
-extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scale, const float* bias,
-                                const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
-                                int R, int S, int stride, int pad, int dil, int relu, int ldo, int ldr,
-                                int in_dtype, int out_dtype, void* stream) {
+extern "C" size_t mega_conv2d_nhwc_workspace_bytes(int M, int Cout, int K) {
+  const int z = choose_ksplit(K);
+  return z > 1 ? (size_t)z * M * Cout * sizeof(float) : 0;
+}
+
+extern "C" int mega_conv2d_nhwc_ws(const void* in, const void* w, const float* scale, const float* bias,
+                                   const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
+                                   int R, int S, int stride, int pad, int dil, int relu, int ldo, int ldr,
+                                   int in_dtype, int out_dtype, void* ws, size_t ws_bytes, void* stream) {
   mega_clear_error();
   if (!in || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
       dil <= 0 || pad < 0)
@@ -351,6 +410,16 @@ extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scal
   p.ldo = ldo > 0 ? ldo : Cout;
   p.ldr = ldr > 0 ? ldr : Cout;
   p.relu = relu;
+  p.ksplit = 1;
+  p.partial = nullptr;
+  if (ws) {   // with a workspace the K range of long-K layers is split (mega_conv2d_nhwc_workspace_bytes)
+    const int z = choose_ksplit(p.K);
+    if (z > 1) {
+      if (ws_bytes < (size_t)z * p.M * Cout * sizeof(float)) return MEGA_ERR_ARG;
+      p.ksplit = z;
+      p.partial = (float*)ws;
+    }
+  }
   {
     const size_t esz = in_dtype == MEGA_BF16 ? 2 : 4;
     const size_t ib = (size_t)N * H * W * Cin * esz, wb = (size_t)Cout * p.K * esz;
@@ -370,4 +439,12 @@ extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scal
     return dispatch_tile<float, float>(p, st);
   }
   return MEGA_ERR_ARG;
+}
+
+extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scale, const float* bias,
+                                const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
+                                int R, int S, int stride, int pad, int dil, int relu, int ldo, int ldr,
+                                int in_dtype, int out_dtype, void* stream) {
+  return mega_conv2d_nhwc_ws(in, w, scale, bias, residual, out, N, H, W, Cin, Cout, R, S, stride, pad, dil, relu, ldo,
+                             ldr, in_dtype, out_dtype, nullptr, 0, stream);
 }

@@ -114,8 +114,11 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
         _tok = _pb("igemm_%s_%dx%d" % ("bf16" if x.dtype == torch.bfloat16 else "f32", t // 1000, t % 1000),
                    2.0 * N * Ho * Wo * Cout * R * S * Cin,
                    x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size())
-    rc = lib.mega_conv2d_nhwc(_ptr(x), _ptr(w), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin,
-                              Cout, R, S, stride, pad, dil, int(relu), Cout, Cout, _dt(x), _DT[odt], _stream())
+    nb = lib.mega_conv2d_nhwc_workspace_bytes(N * Ho * Wo, Cout, R * S * Cin)     # > 0: long-K layer, split-K
+    ws = _ws(nb, x.device) if nb else None
+    rc = lib.mega_conv2d_nhwc_ws(_ptr(x), _ptr(w), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin,
+                                 Cout, R, S, stride, pad, dil, int(relu), Cout, Cout, _dt(x), _DT[odt], _ptr(ws), nb,
+                                 _stream())
     _pe(_tok)
     _lib.check(rc, "mega_conv2d_nhwc")
     return out

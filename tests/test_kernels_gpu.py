@@ -393,3 +393,23 @@ def test_stem_mfma_bf16(dev):
         assert (got - ref).abs().max() <= 2 ** -8 * ref.abs().max() + 1e-6, (N, H, W, (got - ref).abs().max())
         direct = ops.stem(x.to(dev), w_tap.to(dev), scale.to(dev), bias.to(dev), torch.bfloat16).float().cpu().permute(0, 3, 1, 2)
         assert _relerr(got, direct) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_split_k(dev, dtype):
+    """K >= 32768 (the box head's first FC) runs split-K through the workspace entry point: value parity, fused
+    bias / ReLU in the finalize kernel, and batch invariance (a row gives the same bits in a batch of 37 or 300)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    M, N, K = 300, 200, 32768 + 1024
+    x = (torch.randn((M, K), generator=g) * 0.5).to(dtype)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn((N,), generator=g) * 0.1
+    ref = F.relu(x.float() @ w.float().t() + b)
+    got = ops.linear(x.to(dev), w.to(dev), b.to(dev), relu=True)
+    assert _relerr(got.float().cpu(), ref) < (2e-5 if dtype == torch.float32 else 2e-2)
+    part = ops.linear(x[:37].contiguous().to(dev), w.to(dev), b.to(dev), relu=True)
+    assert torch.equal(part, got[:37])
+    from mega.pytorch_amd import _lib
+    lib = _lib.load()
+    assert lib.mega_conv2d_nhwc_workspace_bytes(M, N, K) == 2 * M * N * 4 and lib.mega_conv2d_nhwc_workspace_bytes(M, N, 4096) == 0
