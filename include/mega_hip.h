@@ -145,6 +145,16 @@ int mega_relation_attention(const void* q, int ldq, const void* k, int ldk, cons
 /* The key range of one call is split over mega_relation_attention_splits() block groups (flash-decoding style:
  * partial max / sum / output per split, merged by a second kernel) when ws holds at least
  * mega_relation_attention_workspace_bytes(); with ws == NULL the call runs unsplit. */
+/* bf16-mode pair of the two calls above with the logits kept in bf16 and in the attention kernel's own tile order:
+ * out_bf16 / pos_tiled_bf16 = [16][ceil(Nk/32)][Nq][32] bf16 (16 * ceil(Nk/32) * Nq * 64 bytes, 16-byte aligned), the
+ * 32 keys of a tile stored as (h2, rq, e) with key = 8 rq + 4 h2 + e.  Half the bytes of the f32 form, written by the
+ * matrix-core position kernel and read by the attention kernel in fully coalesced 2 KiB blocks one tile pair ahead. */
+int mega_position_logits_tiled(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
+                               const float* dim_mat, void* out_bf16, int Nq, int Nk, void* stream);
+int mega_relation_attention_tiled_pos(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
+                                      const void* pos_tiled_bf16, const void* resid, int ldr, const float* bias_v,
+                                      void* out, int ldo, int Nq, int Nk, int groups, float scale, void* ws,
+                                      size_t ws_bytes, void* stream);
 int mega_relation_attention_splits(int Nq, int Nk, int groups);
 size_t mega_relation_attention_workspace_bytes(int Nq, int Nk, int groups);
 

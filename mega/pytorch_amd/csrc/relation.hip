@@ -113,7 +113,11 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
                                                               const float* __restrict__ wgt,
                                                               const float* __restrict__ bg,
                                                               const float* __restrict__ dim_mat,
-                                                              float* __restrict__ out, int Nq, int Nk, int ldp) {
+                                                              float* __restrict__ out, bf16_t* __restrict__ out_t,
+                                                              int Nq, int Nk, int ldp) {
+  // out_t != null: logits as bf16 in the attention kernel's own order, [16][ceil(Nk/32)][Nq][32] where the 32 keys of
+  // a tile are stored (h2, rq, e) with key = 8 rq + 4 h2 + e -- the 16 keys one attention lane consumes per tile are
+  // 32 contiguous bytes and a wave's read is one contiguous 2 KiB block.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 15, g = lane >> 4;          // pair within the tile / k-group (A, B);  head = row (B, D)
   const int q = blockIdx.y;
@@ -165,8 +169,17 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
     float4 o;
     o.x = logf(fmaxf(acc[0], 0.f) + 1e-6f); o.y = logf(fmaxf(acc[1], 0.f) + 1e-6f);
     o.z = logf(fmaxf(acc[2], 0.f) + 1e-6f); o.w = logf(fmaxf(acc[3], 0.f) + 1e-6f);
-    float* dst = out + ((size_t)row * Nq + q) * ldp + k0 + 4 * g;
-    if (k0 + 4 * g + 3 < ldp) *reinterpret_cast<float4*>(dst) = o;    // ldp % 4 == 0: pad columns may be written
+    if (out_t) {
+      const int kf = k0 + 4 * g, kt = kf >> 5, kk = kf & 31;
+      bf16_t* dst = out_t + (((size_t)row * ((Nk + 31) >> 5) + kt) * Nq + q) * 32 + ((kk >> 2) & 1) * 16 + (kk >> 3) * 4;
+      uint2 pk;
+      pk.x = (unsigned)f32_to_bf16(o.x) | ((unsigned)f32_to_bf16(o.y) << 16);
+      pk.y = (unsigned)f32_to_bf16(o.z) | ((unsigned)f32_to_bf16(o.w) << 16);
+      *reinterpret_cast<uint2*>(dst) = pk;
+    } else {
+      float* dst = out + ((size_t)row * Nq + q) * ldp + k0 + 4 * g;
+      if (k0 + 4 * g + 3 < ldp) *reinterpret_cast<float4*>(dst) = o;    // ldp % 4 == 0: pad columns may be written
+    }
   }
 }
 
@@ -212,6 +225,7 @@ struct AttnParams {
   const void* K; int ldk;     // [Nk][ldk]
   const void* Vt; int ldv;    // [G*64][ldv]  row h*64+dv, column = key (V already projected by Wv)
   const float* pos; int ldp;  // [G][Nq][ldp] additive logits or null
+  const bf16_t* pos_t;        // or: bf16 logits in tile order [G][ceil(Nk/32)][Nq][32] (see pos_logits_mfma_kernel)
   const void* resid; int ldr; // [Nq][ldr] residual (feats_cur) or null
   const float* bias_v;        // [G*64] or null
   void* out; int ldo;         // [Nq][ldo]
@@ -222,7 +236,7 @@ struct AttnParams {
   float* part_ml;             // [nsplit][2][G][Nq]   running max / sum of each partial
 };
 
-template <typename T>
+template <typename T, bool POS_TILED>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   using C = AttnCfg<T>;
   constexpr int VE = 16 / (int)sizeof(T);
@@ -305,8 +319,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
   const float* pos_row = p.pos ? p.pos + ((size_t)head * p.Nq + q_ld) * p.ldp : nullptr;
+  // tiled bf16 logits: this lane's 16 keys of tile kt are 32 contiguous bytes; fetched one tile pair ahead
+  const int ktiles = (p.Nk + 31) >> 5;
+  auto load_pos = [&](int kt, uint4 (&pr)[2]) {
+    if (POS_TILED) {
+      const int kc = min(kt, ktiles - 1);
+      const uint4* src = reinterpret_cast<const uint4*>(p.pos_t + (((size_t)head * ktiles + kc) * p.Nq + q_ld) * 32 + h2 * 16);
+      pr[0] = src[0];
+      pr[1] = src[1];
+    }
+  };
 
-  auto compute = [&](int cur, int k0) {
+  auto compute = [&](int cur, int k0, const uint4 (&pr)[2]) {
     // ---- S^T[key][q] = sum_d K[key][d] * Q[q][d]
     f32x16_t st;
 #pragma unroll
@@ -323,9 +347,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     float s[16];
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
-      float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pos_row) pw = *reinterpret_cast<const float4*>(pos_row + k0 + 8 * rq + 4 * h2);
-      const float pe[4] = {pw.x, pw.y, pw.z, pw.w};
+      float pe[4] = {0.f, 0.f, 0.f, 0.f};
+      if (POS_TILED) {
+        const unsigned short* pb = reinterpret_cast<const unsigned short*>(&pr[0]);   // element 4 rq + e
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pe[e] = bf16_to_f32(pb[4 * rq + e]);
+      } else if (pos_row) {
+        const float4 pw = *reinterpret_cast<const float4*>(pos_row + k0 + 8 * rq + 4 * h2);
+        pe[0] = pw.x; pe[1] = pw.y; pe[2] = pw.z; pe[3] = pw.w;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int key = k0 + 8 * rq + 4 * h2 + e;
@@ -396,22 +426,27 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   const int t0 = split * p.tiles_per_split;
   const int n = min(ntiles, t0 + p.tiles_per_split) - t0;
   uint4 ka[NLD], va[NLD], kb2[NLD], vb2[NLD];
+  uint4 pA[2] = {}, pB[2] = {};          // position logits of the next even / odd tile (POS_TILED)
   // (unconditional steady-state body, see igemm.hip: tiles past this split's range are loaded but never used)
   load_tiles(t0 * 32, ka, va);
+  load_pos(t0, pA);
   store_tiles(0, ka, va);
   load_tiles((t0 + 1) * 32, ka, va);
+  load_pos(t0 + 1, pB);
   __syncthreads();
   for (int i = 0; i + 1 < n; i += 2) {   // invariant: LDS buffer 0 holds tile t0+i, ka/va hold tile t0+i+1
     load_tiles((t0 + i + 2) * 32, kb2, vb2);
-    compute(0, (t0 + i) * 32);
+    compute(0, (t0 + i) * 32, pA);
+    load_pos(t0 + i + 2, pA);
     store_tiles(1, ka, va);
     __syncthreads();
     load_tiles((t0 + i + 3) * 32, ka, va);
-    compute(1, (t0 + i + 1) * 32);
+    compute(1, (t0 + i + 1) * 32, pB);
+    load_pos(t0 + i + 3, pB);
     store_tiles(0, kb2, vb2);
     __syncthreads();
   }
-  if (n & 1) compute(0, (t0 + n - 1) * 32);
+  if (n & 1) compute(0, (t0 + n - 1) * 32, pA);
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   if (p.nsplit > 1) {
@@ -496,10 +531,23 @@ extern "C" int mega_position_logits(const float* rois_q, const float* rois_k, co
                        (const float4*)rois_k, wg_t, bg, dim_mat, out, Nq, Nk, ldp);
   else if (ldp % 4 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0)
     hipLaunchKernelGGL(pos_logits_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
-                       (const float4*)rois_k, wg_t, bg, dim_mat, out, Nq, Nk, ldp);
+                       (const float4*)rois_k, wg_t, bg, dim_mat, out, (bf16_t*)nullptr, Nq, Nk, ldp);
   else
     hipLaunchKernelGGL((pos_logits_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
                        (const float4*)rois_k, wg_t, bg, dim_mat, out, Nq, Nk, ldp);
+  return mega_check_launch();
+}
+
+extern "C" int mega_position_logits_tiled(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
+                                          const float* dim_mat, void* out_bf16, int Nq, int Nk, void* stream) {
+  mega_clear_error();
+  if (Nq == 0 || Nk == 0) return MEGA_OK;
+  if (!rois_q || !rois_k || !wg_t || !bg || !dim_mat || !out_bf16 || Nq < 0 || Nk < 0 ||
+      (reinterpret_cast<size_t>(out_bf16) & 15))
+    return MEGA_ERR_ARG;
+  dim3 grid(cdiv(Nk, 256), Nq);
+  hipLaunchKernelGGL(pos_logits_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
+                     (const float4*)rois_k, wg_t, bg, dim_mat, (float*)nullptr, (bf16_t*)out_bf16, Nq, Nk, 0);
   return mega_check_launch();
 }
 
@@ -522,17 +570,19 @@ extern "C" size_t mega_relation_attention_workspace_bytes(int Nq, int Nk, int gr
 }
 
 // Multi-head relation attention core (groups heads x 64).  See header comment for the formula.
-extern "C" int mega_relation_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
-                                       const float* pos, int ldp, const void* resid, int ldr, const float* bias_v,
-                                       void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype,
-                                       void* ws, size_t ws_bytes, void* stream) {
+static int relation_attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
+                                   const float* pos, int ldp, const void* pos_tiled, const void* resid, int ldr,
+                                   const float* bias_v, void* out, int ldo, int Nq, int Nk, int groups, float scale,
+                                   int dtype, void* ws, size_t ws_bytes, void* stream) {
   mega_clear_error();
   if (Nq == 0) return MEGA_OK;
   if (!q || !k || !vt || !out || Nq < 0 || Nk <= 0 || groups <= 0) return MEGA_ERR_ARG;
   const int ve = dtype == MEGA_BF16 ? 8 : 4;
   if (ldq % ve || ldk % ve || ldv % ve || (pos && (ldp % 32 || ldp < Nk))) return MEGA_ERR_ARG;
   if (ldv < ((Nk + ve - 1) / ve) * ve) return MEGA_ERR_ARG;
+  if (pos_tiled && (pos || dtype != MEGA_BF16 || (reinterpret_cast<size_t>(pos_tiled) & 15))) return MEGA_ERR_ARG;
   AttnParams p;
+  p.pos_t = (const bf16_t*)pos_tiled;
   p.Q = q; p.ldq = ldq; p.K = k; p.ldk = ldk; p.Vt = vt; p.ldv = ldv; p.pos = pos; p.ldp = ldp;
   p.resid = resid; p.ldr = ldr; p.bias_v = bias_v; p.out = out; p.ldo = ldo; p.Nq = Nq; p.Nk = Nk; p.G = groups;
   p.scale = scale;
@@ -548,8 +598,9 @@ extern "C" int mega_relation_attention(const void* q, int ldq, const void* k, in
                          : nullptr;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(Nq, 128), groups, nsplit);
-  if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(256), 0, st, p);
-  else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_kernel<float>), grid, dim3(256), 0, st, p);
+  if (dtype == MEGA_BF16 && pos_tiled) hipLaunchKernelGGL((attn_kernel<bf16_t, true>), grid, dim3(256), 0, st, p);
+  else if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, false>), grid, dim3(256), 0, st, p);
+  else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_kernel<float, false>), grid, dim3(256), 0, st, p);
   else return MEGA_ERR_ARG;
   if (nsplit > 1) {
     const size_t total = (size_t)Nq * groups * 64;
@@ -558,4 +609,20 @@ extern "C" int mega_relation_attention(const void* q, int ldq, const void* k, in
     else hipLaunchKernelGGL((attn_combine_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
   }
   return mega_check_launch();
+}
+
+extern "C" int mega_relation_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
+                                       const float* pos, int ldp, const void* resid, int ldr, const float* bias_v,
+                                       void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype,
+                                       void* ws, size_t ws_bytes, void* stream) {
+  return relation_attention_impl(q, ldq, k, ldk, vt, ldv, pos, ldp, nullptr, resid, ldr, bias_v, out, ldo, Nq, Nk,
+                                 groups, scale, dtype, ws, ws_bytes, stream);
+}
+
+extern "C" int mega_relation_attention_tiled_pos(const void* q, int ldq, const void* k, int ldk, const void* vt,
+                                                 int ldv, const void* pos_tiled_bf16, const void* resid, int ldr,
+                                                 const float* bias_v, void* out, int ldo, int Nq, int Nk, int groups,
+                                                 float scale, void* ws, size_t ws_bytes, void* stream) {
+  return relation_attention_impl(q, ldq, k, ldk, vt, ldv, nullptr, 0, pos_tiled_bf16, resid, ldr, bias_v, out, ldo, Nq,
+                                 Nk, groups, scale, MEGA_BF16, ws, ws_bytes, stream);
 }

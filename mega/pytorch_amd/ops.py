@@ -272,11 +272,23 @@ def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh,
 
 
 # ------------------------------------------------------------------------------------------------ relation module
-def position_logits(rois_q, rois_k, wg_t, bg, dim_mat, precise=True):
-    """-> [16, Nq, ldp] f32 with ldp = roundup(Nk, 32).  precise=False: fast sin/cos (bf16 mode)."""
+def position_logits(rois_q, rois_k, wg_t, bg, dim_mat, precise=True, tiled=False):
+    """-> [16, Nq, ldp] f32 with ldp = roundup(Nk, 32).  precise=False: fast sin/cos (bf16 mode).
+    tiled=True (bf16 mode only): -> bf16 [16, ceil(Nk/32), Nq, 32] in the attention kernel's tile order (half the
+    bytes; relation_attention recognises it by its dtype)."""
     _gpu(rois_q, rois_k, wg_t, bg, dim_mat)
     lib = _lib.load()
     Nq, Nk = rois_q.shape[0], rois_k.shape[0]
+    if tiled:
+        assert not precise
+        kt = (Nk + 31) // 32
+        out = torch.empty((16, kt, Nq, 32), dtype=torch.bfloat16, device=rois_q.device)
+        _tok = _pb("pos_logits", 2.0 * Nq * Nk * 1024, out.numel() * 2.0)
+        rc = lib.mega_position_logits_tiled(_ptr(rois_q.contiguous()), _ptr(rois_k.contiguous()), _ptr(wg_t), _ptr(bg),
+                                            _ptr(dim_mat), _ptr(out), Nq, Nk, _stream())
+        _pe(_tok)
+        _lib.check(rc, "mega_position_logits_tiled")
+        return out
     ldp = (Nk + 31) // 32 * 32
     out = torch.empty((16, Nq, ldp), dtype=torch.float32, device=rois_q.device)
     _tok = _pb("pos_logits", 2.0 * Nq * Nk * 1024, 16.0 * Nq * ldp * 4)
@@ -296,7 +308,16 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     out = torch.empty((Nq, groups * 64), dtype=q.dtype, device=q.device)
     nb = lib.mega_relation_attention_workspace_bytes(Nq, Nk, groups)
     ws = _ws(nb, q.device) if nb else None
-    _tok = _pb("attention_" + ("bf16" if q.dtype == torch.bfloat16 else "f32"), 4.0 * Nq * Nk * 64 * groups, (q.numel() + k.numel() + vt.numel() + out.numel()) * q.element_size() + (0 if pos is None else pos.numel() * 4))
+    _tok = _pb("attention_" + ("bf16" if q.dtype == torch.bfloat16 else "f32"), 4.0 * Nq * Nk * 64 * groups, (q.numel() + k.numel() + vt.numel() + out.numel()) * q.element_size() + (0 if pos is None else pos.numel() * pos.element_size()))
+    if pos is not None and pos.dtype == torch.bfloat16:       # tile-ordered bf16 logits (position_logits(tiled=True))
+        assert q.dtype == torch.bfloat16 and pos.is_contiguous() and tuple(pos.shape) == (groups, (Nk + 31) // 32, Nq, 32)
+        rc = lib.mega_relation_attention_tiled_pos(_ptr(q), q.shape[1], _ptr(k), k.shape[1], _ptr(vt), vt.shape[1],
+                                                   _ptr(pos), _ptr(resid), 0 if resid is None else resid.shape[1],
+                                                   _ptr(bias_v), _ptr(out), groups * 64, Nq, Nk, groups,
+                                                   1.0 / math.sqrt(64.0), _ptr(ws), nb, _stream())
+        _pe(_tok)
+        _lib.check(rc, "mega_relation_attention_tiled_pos")
+        return out
     rc = lib.mega_relation_attention(_ptr(q), q.shape[1], _ptr(k), k.shape[1], _ptr(vt), vt.shape[1], _ptr(pos),
                                      0 if pos is None else pos.shape[2], _ptr(resid),
                                      0 if resid is None else resid.shape[1], _ptr(bias_v), _ptr(out), groups * 64,

@@ -65,6 +65,7 @@ def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=Tru
     q = ops.linear(x, w.wq, w.bq)
     pos = None
     if w.with_pos:
-        pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=(x.dtype == torch.float32))
+        fast = x.dtype != torch.float32      # bf16 mode: matrix-core kernel, bf16 logits in the attention's tile order
+        pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
     out = ops.relation_attention(q, k_all, vt_all, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
     return (out, k, vt) if return_kv else out

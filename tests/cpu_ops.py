@@ -94,7 +94,7 @@ def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh,
     return ob, os_, ol, torch.tensor([n], dtype=torch.int32)
 
 
-def position_logits(rois_q, rois_k, wg_t, bg, dim_mat, precise=True):
+def position_logits(rois_q, rois_k, wg_t, bg, dim_mat, precise=True, tiled=False):   # the twin always returns f32 rows
     pe = mo.cal_position_embedding(rois_q, rois_k)
     w = wg_t.t().contiguous().view(16, 64, 1, 1)
     out = (F.relu(F.conv2d(pe, w, bg)) + 1e-6).log()[0]

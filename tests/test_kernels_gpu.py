@@ -413,3 +413,63 @@ def test_linear_split_k(dev, dtype):
     from mega.pytorch_amd import _lib
     lib = _lib.load()
     assert lib.mega_conv2d_nhwc_workspace_bytes(M, N, K) == 2 * M * N * 4 and lib.mega_conv2d_nhwc_workspace_bytes(M, N, 4096) == 0
+
+
+def _untile_pos(t, Nk):
+    """bf16 [16, KT, Nq, 32] in (h2, rq, e) tile order -> f32 [16, Nq, Nk]."""
+    G, KT, Nq, _ = t.shape
+    x = t.float().view(G, KT, Nq, 2, 4, 4).permute(0, 2, 1, 4, 3, 5)      # [G, Nq, KT, rq, h2, e]: key = 8rq + 4h2 + e
+    return x.reshape(G, Nq, KT * 32)[:, :, :Nk]
+
+
+def _tile_pos(p, Nk):
+    """f32 [16, Nq, >=Nk] -> bf16 [16, KT, Nq, 32] tile order (pad keys = 0)."""
+    G, Nq = p.shape[0], p.shape[1]
+    KT = (Nk + 31) // 32
+    full = torch.zeros((G, Nq, KT * 32))
+    full[:, :, :Nk] = p[:, :, :Nk]
+    x = full.view(G, Nq, KT, 4, 2, 4).permute(0, 2, 1, 4, 3, 5)           # [G, KT, Nq, h2, rq, e]
+    return x.reshape(G, KT, Nq, 32).to(torch.bfloat16).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(37, 70), (300, 750), (5, 33), (64, 16)])
+def test_position_logits_tiled_bf16(dev, shape):
+    """bf16 tile-ordered logits (what the bf16-mode attention consumes) == the f32-row fast kernel, bf16-rounded."""
+    ops = _ops()
+    from oracle import mega_oracle as mo
+    from mega.pytorch_amd import synth
+    Nq, Nk = shape
+    sd = synth.make_state_dict(blocks=(1, 1, 1), seed=4)
+    g = torch.Generator().manual_seed(Nq + Nk)
+    c = torch.rand((Nq + Nk, 2), generator=g) * torch.tensor([900., 500.])
+    wh = torch.rand((Nq + Nk, 2), generator=g) * 250 + 2
+    b = torch.cat([c - wh / 2, c + wh / 2], dim=1)
+    bq, bk = b[:Nq], b[Nq:]
+    w, bias = sd[mo.FE + "l_Wgs.0.weight"], sd[mo.FE + "l_Wgs.0.bias"]
+    args = (bq.to(dev), bk.to(dev), w.view(16, 64).t().contiguous().to(dev), bias.to(dev), mo.dim_mat_values().to(dev))
+    rows = ops.position_logits(*args, precise=False).cpu()[:, :, :Nk]
+    tiled = ops.position_logits(*args, precise=False, tiled=True).cpu()
+    assert tiled.dtype == torch.bfloat16 and tuple(tiled.shape) == (16, (Nk + 31) // 32, Nq, 32)
+    got = _untile_pos(tiled, Nk)
+    assert torch.equal(got, rows.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("shape", [(300, 750), (675, 1111), (33, 70), (129, 64)])
+def test_relation_attention_tiled_pos(dev, shape):
+    """bf16 attention with tile-ordered bf16 logits == the same kernel fed the same (bf16-rounded) logits as f32 rows,
+    bit for bit: only the fetch path differs."""
+    ops = _ops()
+    Nq, Nk = shape
+    g = torch.Generator().manual_seed(Nq * 3 + Nk)
+    q = (torch.randn((Nq, 1024), generator=g) * 0.3).to(torch.bfloat16)
+    k = (torch.randn((Nk, 1024), generator=g) * 0.3).to(torch.bfloat16)
+    ld = (Nk + 31) // 32 * 32
+    vt = torch.zeros((1024, ld), dtype=torch.bfloat16)
+    vt[:, :Nk] = torch.randn((1024, Nk), generator=g).to(torch.bfloat16)
+    pos = (torch.randn((16, Nq, ld), generator=g) * 2 - 3).to(torch.bfloat16).float()
+    resid = torch.randn((Nq, 1024), generator=g).to(torch.bfloat16)
+    bv = torch.randn((1024,), generator=g) * 0.1
+    a = ops.relation_attention(q.to(dev), k.to(dev), vt.to(dev), Nk, pos=pos.to(dev), resid=resid.to(dev), bias_v=bv.to(dev))
+    b = ops.relation_attention(q.to(dev), k.to(dev), vt.to(dev), Nk, pos=_tile_pos(pos, Nk).to(dev), resid=resid.to(dev),
+                               bias_v=bv.to(dev))
+    assert torch.equal(a, b)
