@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true", help="launch the frame stage kernel by kernel (no hipGraph)")
     ap.add_argument("--reuse-records", action="store_true",
                     help="compute each frame's record once per video (engine option; NOT the headline configuration)")
+    ap.add_argument("--static-aggregation", action="store_true",
+                    help="experimental: steady-state aggregation steps replayed from one hipGraph (engine option)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     return ap.parse_args()
 
@@ -157,7 +159,8 @@ def main():
     clip = make_clip(T, args.height, args.width, device)
     gfor = eng.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
     runner = eng.ClipEngine(model, steps_per_batch=args.steps_per_batch, dist_group=group, overlap=not args.no_overlap,
-                            graphs=not args.no_graphs, reuse_records=args.reuse_records)
+                            graphs=not args.no_graphs, reuse_records=args.reuse_records,
+                            static_aggregation=args.static_aggregation)
 
     def barrier():
         torch.cuda.synchronize()
@@ -187,7 +190,7 @@ def main():
         elapsed = float(t.item())
     fps = K / elapsed
     log("timed region: %.3fs (%.2f frames/s)" % (elapsed, fps))
-    log("frame-stage batches so far: %s" % runner.graph_stats)
+    log("frame-stage batches so far: %s; static aggregation steps: %d" % (runner.graph_stats, runner.static_steps))
     ht = dict(runner.host_times)
     log("host ms/step: frame-stage enqueue %.3f, aggregation enqueue %.3f, waiting for results %.3f" % tuple(
         1e3 * ht[k] / max(ht["steps"], 1) for k in ("frame_enqueue", "aggregate_enqueue", "finish_wait")))
@@ -254,6 +257,7 @@ def main():
                                    % (args.arch, args.width, args.height, "" if world == 1 else " sharded = configs[3]"),
                        "steps_per_batch": args.steps_per_batch, "parallelism": "frame-sharded x%d" % world,
                        "frame_record_reuse": bool(args.reuse_records),
+                       "static_aggregation": bool(args.static_aggregation),
                        "frames_through_frame_stage_per_step": round((runner_frames_after - fc_before) / K, 2),
                        "avg_detections": round(ndet, 1),
                        "key_proposals_last_frame": int(model.records[model.key_frame_location]["boxes"].shape[0])},

@@ -424,6 +424,7 @@ class MEGAFeatureExtractor(_Packed):
         self.mem = None
         self.global_cache = None
         self.cache_memory_kv = True      # keep the Wk / Wv projections of memory rows (False: re-project every step)
+        self.static_pools = None         # set by engine.StaticAggregation while it owns the pools
 
     # ---- kernel operands
     def _pack(self, dtype, device):
@@ -472,14 +473,15 @@ class MEGAFeatureExtractor(_Packed):
     def update_memory(self, i, cache):
         n = self.base_num if i == 0 else self.advanced_num
         self.mem_queue_list[i]["rois"].append(cache["rois_ref"][:n])
-        self.mem_queue_list[i]["feats"].append(cache["feats_ref"][:n])
-        self.mem[i] = {"rois": torch.cat(list(self.mem_queue_list[i]["rois"]), dim=0),
-                       "feats": torch.cat(list(self.mem_queue_list[i]["feats"]), dim=0)}
+        self.mem[i] = {"rois": torch.cat(list(self.mem_queue_list[i]["rois"]), dim=0)}
+        if not self.cache_memory_kv:     # raw features are only needed when their projections are not kept
+            self.mem_queue_list[i]["feats"].append(cache["feats_ref"][:n])
+            self.mem[i]["feats"] = torch.cat(list(self.mem_queue_list[i]["feats"]), dim=0)
 
     def _remember_kv(self, i, k, vt):
         """The rows update_memory(i, .) pushed this step are the first rows of this step's `ref`: keep their key /
         value projections (k [Nr,1024], vt [1024,ld] of the whole ref) with them -- next steps read them as memory."""
-        n = self.mem_queue_list[i]["feats"][-1].shape[0]
+        n = self.mem_queue_list[i]["rois"][-1].shape[0]
         q = self.mem_queue_list[i]
         q["k"].append(k[:n])
         q["vt"].append(vt[:, :n].contiguous())      # contiguous pieces: the concatenation below is ONE batched copy
@@ -514,10 +516,14 @@ class MEGAFeatureExtractor(_Packed):
         for _ in range(self.stage - 2):
             cache.append({"rois_cur": rois_cur01, "rois_ref": rois_dis})
         cache.append({"rois_cur": rois_key, "rois_ref": rois_dis})
+        sp = self.static_pools       # engine.StaticAggregation: pools as fixed-address tensors (hipGraph-able step)
         for i in range(self.stage):
-            memory = self.mem[i] if self.mem[i] else None                 # read BEFORE the push (:914-917)
-            if self.memory_enable:
-                self.update_memory(i, cache[i])
+            if sp is not None:
+                memory = sp.read_memory(i)
+            else:
+                memory = self.mem[i] if self.mem[i] else None             # read BEFORE the push (:914-917)
+                if self.memory_enable:
+                    self.update_memory(i, cache[i])
             rois_cur, rois_ref = cache[i]["rois_cur"], cache[i]["rois_ref"]
             feats_cur, feats_ref = cache[i]["feats_cur"], cache[i]["feats_ref"]
             mem_kv = None
@@ -530,7 +536,10 @@ class MEGAFeatureExtractor(_Packed):
             feats_cur, k_loc, vt_loc = relation_attention_forward(
                 pk["local"][i], feats_cur.contiguous(), feats_ref.contiguous(), rois_cur.contiguous(),
                 rois_ref.contiguous(), residual=True, mem_kv=mem_kv, return_kv=True)
-            if self.memory_enable and self.cache_memory_kv:
+            if sp is not None:          # the push comes after the read and after every use of the old rows
+                n = self.base_num if i == 0 else self.advanced_num
+                sp.push_memory(i, cache[i]["rois_ref"][:n], k_loc[:n], vt_loc[:, :n])
+            elif self.memory_enable and self.cache_memory_kv:
                 self._remember_kv(i, k_loc, vt_loc)
             if i != self.stage - 1:
                 feats_cur = ops.linear(feats_cur, pk["fc_w"][i + 1], pk["fc_b"][i + 1], relu=True)

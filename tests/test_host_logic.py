@@ -100,7 +100,9 @@ def test_detector_state_machine_matches_oracle(monkeypatch):
         assert (det.get_field("scores") - ws).abs().max() < 1e-5
     # memory / global pools have the sizes the reference would have
     fe = model.roi_heads.box.feature_extractor
-    assert len(fe.mem_queue_list[0]["feats"]) == nkey and fe.mem[1]["feats"].shape[0] == nkey * 15
+    # (the rows' Wk / Wv projections are kept instead of the raw features: same row counts)
+    assert len(fe.mem_queue_list[0]["rois"]) == nkey and fe.mem[1]["k"].shape[0] == nkey * 15
+    assert fe.mem[0]["vt"].shape == (1024, nkey * 75) and fe.mem[2]["rois"].shape == (nkey * 15, 4)
     assert fe.global_cache[0]["feats"].shape[0] == 10 * 75
 
 
@@ -272,3 +274,44 @@ def test_engine_record_reuse_gives_same_detections(monkeypatch):
         assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels"))
         assert (a.bbox - b.bbox).abs().max() < 1e-3 and (a.get_field("scores") - b.get_field("scores")).abs().max() < 1e-5
     assert computed[0] == 13 + 10 + 2 * (nkey - 1) and computed[1] <= T and computed[1] < computed[0]
+
+
+def test_static_aggregation_equals_eager(monkeypatch):
+    """ClipEngine(static_aggregation=True): once the window, memory and global pools are full, the aggregation step
+    runs on fixed-address shift-append pools (the hipGraph-able form) -- same detections as the deque-based eager
+    path, including leaving and re-entering steady state and a second video."""
+    from mega.pytorch_amd import engine
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    cfg = _small_cfg()
+    cfg.merge_from_list(["MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 7, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 3,
+                         "MODEL.VID.MEGA.MIN_OFFSET", -3, "MODEL.VID.MEGA.MAX_OFFSET", 3, "MODEL.VID.MEGA.GLOBAL.SIZE", 3,
+                         "MODEL.RPN.POST_NMS_TOP_N_TEST", 40, "MODEL.VID.RPN.REF_POST_NMS_TOP_N", 10])
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    T, nkey = 26, 20
+    frames = synth.preprocess_cpu(synth.make_clip(T, 96, 128, seed=2))
+    outs, engines = [], []
+    for static in (False, True):
+        model = modeling.build_detection_model(cfg)
+        model.load_state_dict(sd)
+        eng = engine.ClipEngine(model, steps_per_batch=3, overlap=False, graphs=False, static_aggregation=static)
+        a = eng.run(frames, T, last=12)
+        if static:                       # force a round trip static -> eager -> static in the middle of the video
+            assert eng._static.active
+            eng._static.leave()
+        a += eng.run(frames, T, first=12, last=15)
+        if static:                       # ... and a stretch of plain eager steps on the written-back deques
+            eng._static.leave()
+            keep, eng._static = eng._static, None
+            a += eng.run(frames, T, first=15, last=17)
+            eng._static = keep
+        else:
+            a += eng.run(frames, T, first=15, last=17)
+        a += eng.run(frames, T, first=17, last=nkey)
+        a += eng.run(frames[:12], 12, last=4)          # a second video re-initialises everything
+        outs.append(a)
+        engines.append(eng)
+    assert engines[1].static_steps >= 8, engines[1].static_steps
+    for a, b in zip(*outs):
+        assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels"))
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
