@@ -19,6 +19,7 @@ from oracle import pil_resize  # noqa: E402
 
 VIDEOS = [("val/vid_a", 7), ("val/vid_b", 5)]
 H0, W0, MIN_S, MAX_S = 60, 100, 96, 160
+GSIZE = 3
 
 
 def _make_dataset(root):
@@ -44,6 +45,9 @@ def _model():
     cfg = config.get_cfg("R-50")
     cfg.MODEL.DEVICE = "cpu"
     cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = MIN_S, MAX_S
+    # a short window keeps the cold start of each tiny video cheap (3 local + 3 global frames instead of 13 + 10)
+    cfg.merge_from_list(["MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 5, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 2,
+                         "MODEL.VID.MEGA.MIN_OFFSET", -2, "MODEL.VID.MEGA.MAX_OFFSET", 2, "MODEL.VID.MEGA.GLOBAL.SIZE", GSIZE])
     m = modeling.build_detection_model(cfg)
     m.load_state_dict(synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5))
     return cfg, m
@@ -86,7 +90,7 @@ def test_inference_writes_reference_format_predictions(monkeypatch, tmp_path):
     for name, L in VIDEOS:
         clip = torch.from_numpy(np.stack([pil_resize.resize_bilinear_u8(f, MIN_S, MAX_S) for f in clips[name]]))
         ref = engine.ClipEngine(model2, steps_per_batch=2, overlap=False, graphs=False).run(
-            clip, L, engine.global_schedule(L, 10, seed=start))
+            clip, L, engine.global_schedule(L, GSIZE, seed=start))
         for i, r in enumerate(ref):
             p = preds[start + i]
             assert p.size == (MAX_S, MIN_S) and torch.equal(p.bbox, r.bbox)
