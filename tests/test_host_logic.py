@@ -315,3 +315,32 @@ def test_static_aggregation_equals_eager(monkeypatch):
     for a, b in zip(*outs):
         assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels"))
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+
+
+def test_fgfa_window_override_matches_oracle(monkeypatch):
+    """BASELINE config 5 changes the FGFA window through config overrides (21 frames there; 5 here to stay cheap):
+    ALL_FRAME_INTERVAL / KEY_FRAME_LOCATION / offsets are honoured by GeneralizedRCNNFGFA exactly as by the oracle."""
+    import mega.pytorch_amd.fgfa  # noqa: F401
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    cfg = config.get_cfg("R-50", "fgfa")
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.merge_from_list(["MODEL.VID.FGFA.ALL_FRAME_INTERVAL", 5, "MODEL.VID.FGFA.KEY_FRAME_LOCATION", 2,
+                         "MODEL.VID.FGFA.MIN_OFFSET", -2, "MODEL.VID.FGFA.MAX_OFFSET", 2])
+    sd = synth.make_fgfa_state_dict(seed=3)
+    model = modeling.build_detection_model(cfg)
+    model.load_state_dict(sd)
+    T = 6
+    frames = synth.preprocess_cpu(synth.make_clip(T, 96, 128, seed=7))
+    orc = mo.FgfaOracle(sd, mo.OracleCfg(blocks=(3, 4, 6), reduce_channel=True, nms_strict_gt=True),
+                        all_frame_interval=5, key_frame_location=2)
+    for idx in range(3):
+        nxt = min(T - 1, idx + 2)
+        images = {"cur": frames[idx], "ref": [frames[nxt]], "frame_category": 0 if idx == 0 else 1, "seg_len": T,
+                  "ref_init": [frames[i] for i in range(1, 3)]}
+        with torch.no_grad():
+            det = model(images)[0]
+            wb, ws, wl = orc.forward_frame(frames[idx:idx + 1], 0 if idx == 0 else 1, ref=frames[nxt][None], seg_len=T,
+                                           frame_loader=lambda i: frames[i][None])
+        assert len(det) == wb.shape[0] and torch.equal(det.get_field("labels"), wl)
+        assert (det.bbox - wb).abs().max() < 5e-3 and (det.get_field("scores") - ws).abs().max() < 1e-5
