@@ -84,6 +84,7 @@ class ClipEngine(object):
         self._fgraphs = {}
         self._graph_pool = None
         self.reuse_records = reuse_records
+        self.frames_per_launch = steps_per_batch + 2      # reuse_records: fixed frame-stage launch size
         # experimental, opt-in: steady-state aggregation steps on fixed-address pools, replayed from one hipGraph
         self._static = StaticAggregation(model, use_graph=graphs) if static_aggregation else None
         self.static_steps = 0
@@ -246,54 +247,79 @@ class ClipEngine(object):
         if first == 0:
             self._rec_cache, self._rec_pending = {}, set()
 
+        # reuse_records: frames go through the frame stage in launches of EXACTLY frames_per_launch frames, taken in
+        # the order in which the schedule first needs them (what a step-batch does not need yet is computed ahead of
+        # time): one frame-stage shape for the whole video, i.e. one hipGraph, instead of a new shape per batch.
+        plan, plan_pos = [], {}
+        if self.reuse_records:
+            for i in range(first, last):
+                for f, _, _ in self.jobs_for_step(i, T, gfor):
+                    if f not in plan_pos and f not in self._rec_cache and f not in self._rec_pending:
+                        plan_pos[f] = len(plan)
+                        plan.append(f)
+        cursor = [0]
+
+        def launch(flat):
+            """one frame-stage launch (+ async copy of its proposal counts) -> handle"""
+            h = self.records_async(clip, flat)
+            h["jobs"] = flat
+            if use_streams:   # proposal counts -> pinned host memory, async
+                c = self._cnt_of(h)
+                h["cnt_host"] = torch.empty(c.shape, dtype=c.dtype).pin_memory()
+                h["cnt_host"].copy_(c, non_blocking=True)
+            return h
+
         def frame_stage(b):
             per_step = [self.jobs_for_step(i, T, gfor) for i in range(b[0], b[1])]
             flat = [j for js in per_step for j in js]
+            launches = []
             if self.reuse_records:      # every frame once per video, always with the key-role row count
-                todo = []
-                for f, _, _ in flat:
-                    if f not in self._rec_cache and f not in self._rec_pending:
-                        self._rec_pending.add(f)
-                        todo.append((f, m.key_num, "l"))
-                flat = todo
-            elif self.use_graphs and clip.is_cuda and b[0] > 0 and 0 < b[1] - b[0] < self.steps_per_batch:
-                # a short last batch would be a NEW frame-stage shape: eager launches plus fresh allocator blocks
-                # (hipMalloc synchronises the device and stalls both streams, ~15 ms).  Pad it with repeats of its
-                # last step's jobs to the steady batch shape so that it replays the captured graph; the padded
-                # records are never consumed.
-                per = len(per_step[-1])
-                flat = flat + per_step[-1] * (self.steps_per_batch - (b[1] - b[0])) if per else flat
-            self.frames_computed += len(flat)
-            if not flat:
-                return per_step, {"none": True, "jobs": flat}, None
+                need = [f for f, _, _ in flat if f not in self._rec_cache and f not in self._rec_pending]
+                if need:
+                    C = self.frames_per_launch
+                    hi = max(plan_pos[f] for f in need) + 1
+                    n = -(-(hi - cursor[0]) // C) * C
+                    take = plan[cursor[0]:cursor[0] + n]
+                    cursor[0] += len(take)
+                    self._rec_pending.update(take)
+                    take = take + [take[-1]] * (n - len(take))      # end of the plan: repeat (result ignored)
+                    launches = [[(f, m.key_num, "l") for f in take[o:o + C]] for o in range(0, n, C)]
+            else:
+                if self.use_graphs and clip.is_cuda and b[0] > 0 and 0 < b[1] - b[0] < self.steps_per_batch and per_step[-1]:
+                    # a short last batch would be a NEW frame-stage shape: eager launches plus fresh allocator blocks
+                    # (hipMalloc synchronises the device and stalls both streams, ~15 ms).  Pad it with repeats of
+                    # its last step's jobs to the steady batch shape so that it replays the captured graph; the
+                    # padded records are never consumed.
+                    flat = flat + per_step[-1] * (self.steps_per_batch - (b[1] - b[0]))
+                launches = [flat] if flat else []
+            self.frames_computed += sum(len(x) for x in launches)
+            if not launches:
+                return per_step, [], None
             with _On(sF):
-                h = self.records_async(clip, flat)
-                h["jobs"] = flat
+                hs = [launch(x) for x in launches]
                 ev = None
-                if use_streams:   # proposal counts -> pinned host memory, async; the event covers the copy
-                    c = self._cnt_of(h)
-                    h["cnt_host"] = torch.empty(c.shape, dtype=c.dtype).pin_memory()
-                    h["cnt_host"].copy_(c, non_blocking=True)
-                    ev = torch.cuda.Event()
+                if use_streams:
+                    ev = torch.cuda.Event()       # covers the launches and their count copies
                     ev.record(sF)
-            return per_step, h, ev
+            return per_step, hs, ev
 
-        def aggregate(b, per_step, h, ev):
+        def aggregate(b, per_step, hs, ev):
             with _On(sB):
-                counts = None
                 if use_streams and ev is not None:
                     sB.wait_event(ev)
                     ev.synchronize()                  # host waits for THIS frame-stage batch only, not the stream
-                    counts = h["cnt_host"].tolist()
-                recs = [] if h.get("none") else self.records_resolve(h, counts)
+                recs = []
+                for h in hs:
+                    r = self.records_resolve(h, h["cnt_host"].tolist() if use_streams else None)
+                    if self.reuse_records:
+                        for (f, _, _), x in zip(h["jobs"], r):
+                            self._rec_cache[f] = x
+                            self._rec_pending.discard(f)
+                    recs += r
                 if use_streams:
                     for r in recs:                    # produced on sF, consumed on sB
                         for t in r.values():
                             t.record_stream(sB)
-                if self.reuse_records:
-                    for (f, _, _), r in zip(h["jobs"], recs):
-                        self._rec_cache[f] = r
-                        self._rec_pending.discard(f)
                 pending, o = [], 0
                 for i, js in zip(range(b[0], b[1]), per_step):
                     if self.reuse_records:
