@@ -88,3 +88,42 @@ def test_load_c2_pickle_and_pth_round_trip(tmp_path):
         checkpoint.load_checkpoint(cfg, modeling.build_detection_model(cfg), str(tmp_path / "bad.pth"))
     with pytest.raises(ValueError):
         checkpoint.load_file(cfg, "catalog://ImageNetPretrained/MSRA/R-50")
+
+
+def _complex_model():
+    """the nested model + flat state_dict of the reference's own loader test (tests/checkpoint.py:19-36)."""
+    from collections import OrderedDict
+    from torch import nn
+    m = nn.Module()
+    m.block1 = nn.Module()
+    m.block1.layer1 = nn.Linear(2, 3)
+    m.layer2 = nn.Linear(3, 2)
+    m.res = nn.Module()
+    m.res.layer2 = nn.Linear(3, 2)
+    g = torch.Generator().manual_seed(0)
+    sd = OrderedDict()
+    sd["layer1.weight"] = torch.rand(3, 2, generator=g)
+    sd["layer1.bias"] = torch.rand(3, generator=g)
+    sd["layer2.weight"] = torch.rand(2, 3, generator=g)
+    sd["layer2.bias"] = torch.rand(2, generator=g)
+    sd["res.layer2.weight"] = torch.rand(2, 3, generator=g)
+    sd["res.layer2.bias"] = torch.rand(2, generator=g)
+    return m, sd
+
+
+@pytest.mark.parametrize("data_parallel", [False, True])
+def test_reference_complex_model_case(data_parallel):
+    """tests/checkpoint.py:103-114 test_complex_model_loaded: keys that differ by a prefix, 'layer2' vs 'res.layer2'
+    resolved by the longest suffix, with and without a DataParallel wrapper on the model side."""
+    from torch import nn
+    model, sd = _complex_model()
+    if data_parallel:
+        model = nn.DataParallel(model)
+    checkpoint.load_state_dict(model, sd)
+    for loaded, stored in zip(model.state_dict().values(), sd.values()):
+        assert loaded.equal(stored)
+    # and the loaded side wrapped instead (checkpoint saved from a DataParallel model)
+    model2, _ = _complex_model()
+    checkpoint.load_state_dict(model2, {"module." + k: v for k, v in sd.items()})
+    for loaded, stored in zip(model2.state_dict().values(), sd.values()):
+        assert loaded.equal(stored)
