@@ -45,6 +45,9 @@ def get_cfg(arch="R-101", method="mega"):
     the advanced stage / vid_R_{50,101}_C4_RDN_base_1x.yaml without)."""
     r50 = arch in ("R-50", "R-50-C4")
     cfg = _mega_cfg(r50)
+    if method != "mega":      # what only the MEGA yamls set goes back to config/defaults.py:409,:447
+        cfg.MODEL.VID.ROI_BOX_HEAD.ATTENTION.STAGE = 2
+        cfg.MODEL.VID.MEGA.GLOBAL.RES_STAGE = 1
     if method == "fgfa":
         cfg.MODEL.META_ARCHITECTURE = "GeneralizedRCNNFGFA"
         cfg.MODEL.VID.METHOD = "fgfa"

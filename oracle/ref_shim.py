@@ -200,12 +200,26 @@ def install():
     _INSTALLED = True
 
 
+_PRISTINE_CFG = None
+
+
 def make_cfg(config_file="configs/MEGA/vid_R_101_C4_MEGA_1x.yaml", opts=()):
     """cfg exactly as tools/test_net.py:75-79 builds it (BASE_RCNN_1gpu.yaml -> file -> opts)."""
     install()
     from mega_core.config import cfg as global_cfg
     cfg = global_cfg  # the reference reads the GLOBAL cfg inside some constructors
     cfg.defrost()
+    # the global tree is merged IN PLACE: start every call from the pristine defaults, or values of a config merged
+    # earlier in this process would leak into this one (e.g. METHOD "dff" into configs/vid_R_50_C4_1x.yaml)
+    global _PRISTINE_CFG
+    if _PRISTINE_CFG is None:
+        _PRISTINE_CFG = copy.deepcopy(cfg)
+    else:
+        fresh = copy.deepcopy(_PRISTINE_CFG)
+        for k in list(cfg.keys()):
+            del cfg[k]
+        for k, v in fresh.items():
+            cfg[k] = v
     cfg.merge_from_file(os.path.join(REF_ROOT, "configs", "BASE_RCNN_1gpu.yaml"))
     cfg.merge_from_file(os.path.join(REF_ROOT, config_file))
     cfg.merge_from_list(["MODEL.DEVICE", "cpu"] + list(opts))

@@ -374,6 +374,48 @@ def golden_checkpoint():
         json.dump(out, f, indent=0, sort_keys=True)
 
 
+def golden_configs():
+    """ref_configs.json: for every reference config file this package mirrors, the values the REFERENCE's yacs tree
+    holds (defaults.py merged with the yaml) for exactly the keys mega.pytorch_amd.config.get_cfg defines."""
+    import json
+    from mega.pytorch_amd import config as myconfig
+    cases = {"mega_R-101": ("configs/MEGA/vid_R_101_C4_MEGA_1x.yaml", "R-101", "mega"),
+             "mega_R-50": ("configs/MEGA/vid_R_50_C4_MEGA_1x.yaml", "R-50", "mega"),
+             "rdn_R-101": ("configs/RDN/vid_R_101_C4_RDN_1x.yaml", "R-101", "rdn"),
+             "rdn_base_R-101": ("configs/RDN/vid_R_101_C4_RDN_base_1x.yaml", "R-101", "rdn_base"),
+             "rdn_base_R-50": ("configs/RDN/vid_R_50_C4_RDN_base_1x.yaml", "R-50", "rdn_base"),
+             "fgfa_R-101": ("configs/FGFA/vid_R_101_C4_FGFA_1x.yaml", "R-101", "fgfa"),
+             "fgfa_R-50": ("configs/FGFA/vid_R_50_C4_FGFA_1x.yaml", "R-50", "fgfa"),
+             "dff_R-101": ("configs/DFF/vid_R_101_C4_DFF_1x.yaml", "R-101", "dff"),
+             "dff_R-50": ("configs/DFF/vid_R_50_C4_DFF_1x.yaml", "R-50", "dff"),
+             "base_R-101": ("configs/vid_R_101_C4_1x.yaml", "R-101", "base"),
+             "base_R-50": ("configs/vid_R_50_C4_1x.yaml", "R-50", "base")}
+
+    def flat(node, prefix=""):
+        out = {}
+        for k, v in node.items():
+            if isinstance(v, dict):
+                out.update(flat(v, prefix + k + "."))
+            else:
+                out[prefix + k] = v
+        return out
+    out = {}
+    for name, (yaml_path, arch, method) in cases.items():
+        ref = ref_shim.make_cfg(yaml_path)
+        vals = {}
+        for key in flat(myconfig.get_cfg(arch, method)):
+            node = ref
+            try:
+                for part in key.split("."):
+                    node = node[part] if isinstance(node, dict) else getattr(node, part)
+            except (KeyError, AttributeError):
+                continue            # a key this package adds (NMS_STRICT_GT): not in the reference
+            vals[key] = list(node) if isinstance(node, (tuple, list)) else node
+        out[name] = {"arch": arch, "method": method, "yaml": yaml_path, "values": vals}
+    with open(os.path.join(HERE, "ref_configs.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
 def golden_feed():
     """ref_feed.npz: the reference's test-time transform chain (data/transforms/build.py:26-45 with the default
     INPUT.* of config/defaults.py) on VID-like frame sizes (Resize.get_size) and on one seeded frame (full chain).
@@ -455,3 +497,4 @@ if __name__ == "__main__":
     golden_rdn()
     golden_dff()
     golden_checkpoint()
+    golden_configs()

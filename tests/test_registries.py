@@ -102,3 +102,32 @@ def test_detectors_build_from_their_configs(method, name):
                                                                   "seg_len": 1, "is_key_frame": True}, targets=[None])
     with pytest.raises(AssertionError):
         modeling.DETECTION_META_ARCHITECTURES.register(name, object)      # utils/registry.py:4-6: names are unique
+
+
+def _flat(node, prefix=""):
+    out = {}
+    for k, v in node.items():
+        if isinstance(v, dict):
+            out.update(_flat(v, prefix + k + "."))
+        else:
+            out[prefix + k] = v
+    return out
+
+
+def test_config_values_equal_the_reference_configs():
+    """tests/test_configs.py loads every yaml; here: for the 11 config files this package mirrors, every key of
+    config.get_cfg(arch, method) that exists in the reference holds the value the reference's defaults + yaml give
+    (tests/golden/ref_configs.json, dumped from the reference's own yacs tree)."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_configs.json")))
+    assert len(gold) == 11
+    for name, case in gold.items():
+        mine = _flat(config.get_cfg(case["arch"], case["method"]))
+        assert len(case["values"]) >= 60, name
+        for key, want in case["values"].items():
+            got = mine[key]
+            got = list(got) if isinstance(got, (tuple, list)) else got
+            if key == "MODEL.DEVICE":
+                continue
+            assert got == want, "%s: %s = %r, reference has %r" % (name, key, got, want)
