@@ -60,21 +60,27 @@ class VIDTestIndex(object):
         return len(self.image_set_index)
 
 
-def videos_for_rank(videos, rank, world):
-    """Whole videos per rank, contiguous chunks balanced by frame count (VIDTestDistributedSampler's policy:
-    a video never straddles two ranks)."""
+def videos_for_rank(videos, rank, world, num_frames=None):
+    """VIDTestDistributedSampler (data/samplers/distributed.py:83-95): the frame range of rank r starts at the first
+    VIDEO START at or after r * ceil(N / world) and ends at the first video start at or after (r + 1) * ceil(N / world)
+    (N = frames in the dataset) -- a video never straddles two ranks; a rank whose range holds no video start gets
+    nothing.  (Where the reference's find_zero runs off the end of its list and returns None, the end of the dataset is
+    meant and used here.)"""
     if world == 1:
         return list(videos)
-    total = sum(v["seg_len"] for v in videos)
-    out, acc, r = [], 0, 0
-    for v in videos:
-        # a video goes to the rank whose share its midpoint falls into
-        mid = acc + v["seg_len"] / 2.0
-        r = min(world - 1, int(mid * world / total))
-        if r == rank:
-            out.append(v)
-        acc += v["seg_len"]
-    return out
+    n = sum(v["seg_len"] for v in videos) if num_frames is None else num_frames
+    per = -(-n // world)
+    starts = [v["start"] for v in videos]
+
+    def find_zero(offset):
+        if offset >= n:
+            return n
+        for s in starts:
+            if s >= offset:
+                return s
+        return n
+    lo, hi = find_zero(rank * per), find_zero((rank + 1) * per)
+    return [v for v in videos if lo <= v["start"] < hi]
 
 
 def compute_on_dataset(model, index, img_dir, device, videos=None, steps_per_batch=10, seed=0, timer=None,

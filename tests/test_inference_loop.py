@@ -144,3 +144,45 @@ def test_video_sharded_inference_world2(monkeypatch, tmp_path):
     assert len(both) == len(single) == 12
     for a, b in zip(both, single):
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("labels"), b.get_field("labels"))
+
+
+def test_video_partition_equals_reference_sampler():
+    """videos_for_rank == the frame ranges mega_core.data.samplers.VIDTestDistributedSampler hands out (executed from
+    the reference tree when it is present: the build container), on random video-length lists and world sizes."""
+    import ref_shim
+    if not ref_shim.available():
+        pytest.skip("needs /root/reference")
+    ref_shim.install()
+    from mega_core.data.samplers.distributed import VIDTestDistributedSampler
+
+    class _DS(object):
+        def __init__(self, lens):
+            self.start_index, n = [], 0
+            for l in lens:
+                self.start_index.append(n)
+                n += l
+            self.n = n
+
+        def __len__(self):
+            return self.n
+    rng = np.random.RandomState(0)
+    for trial in range(40):
+        lens = rng.randint(1, 60, size=rng.randint(1, 14)).tolist()
+        ds = _DS(lens)
+        videos = [{"start": s, "seg_len": l, "pattern": str(i)} for i, (s, l) in enumerate(zip(ds.start_index, lens))]
+        for world in (2, 3, 4, 8):
+            covered = []
+            for rank in range(world):
+                smp = VIDTestDistributedSampler(ds, num_replicas=world, rank=rank)
+                if smp.start is None:
+                    # the reference's find_zero fell off its list (offset inside the LAST video) and returned None;
+                    # its slice [None:end] would then hand this rank the whole dataset again.  Here: nothing.
+                    # (an end of None slices to the end of the dataset, which is what is meant: compared below)
+                    assert inference.videos_for_rank(videos, rank, world) == []
+                    continue
+                want = list(iter(smp))
+                mine = inference.videos_for_rank(videos, rank, world)
+                got = [i for v in mine for i in range(v["start"], v["start"] + v["seg_len"])]
+                assert got == want, (lens, world, rank)
+                covered += got
+            assert len(covered) == len(set(covered))
