@@ -33,7 +33,23 @@ def agg(path, name):
     return d
 
 
+def counter_table(argv):
+    """python tools/pmc_summary.py --counter NAME pmc_counter_collection.csv out.csv : mean of one counter per kernel
+    (e.g. SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE collected in their own passes; MFMA-busy % = ratio of the two)."""
+    name, path, out = argv
+    d = agg(path, name)
+    rows = sorted(((k, n, v / n, t / n / 1e3) for k, (n, v, t) in d.items()), key=lambda r: -r[1] * r[3])
+    with open(out, "w") as fh:
+        fh.write("kernel,launches,%s_per_launch,avg_us\n" % name)
+        for k, n, v, t in rows:
+            fh.write('"%s",%d,%.1f,%.2f\n' % (k, n, v, t))
+    for k, n, v, t in rows[:8]:
+        print("%-64s x%-5d %s %14.0f  %8.1f us" % (k[:64], n, name, v, t))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--counter":
+        return counter_table(sys.argv[2:5])
     f = agg(sys.argv[1], "FETCH_SIZE")
     w = agg(sys.argv[2], "WRITE_SIZE")
     prefix = sys.argv[3]

@@ -11,6 +11,8 @@ timeout 600 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; echo
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
 timeout 400 python bench.py > $out/bench_n1.json 2> $out/bench_n1.err; tail -3 $out/bench_n1.err; cut -c1-260 $out/bench_n1.json
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python bench.py --steps 48 --warmup 40 --no-cpu-baseline --no-roofline > $out/bench_under_rocprof.json 2> $out/prof.err; ls $out/prof | head -3
-for c in FETCH_SIZE WRITE_SIZE; do
+# (MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, again one counter per pass; reduce with
+#  `python tools/pmc_summary.py --counter NAME <csv> profiles/<tag>_<NAME>.csv`)
+for c in FETCH_SIZE WRITE_SIZE ${EXTRA_PMC:-}; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python bench.py --steps 8 --warmup 26 --no-cpu-baseline --no-roofline --no-graphs --no-overlap > $out/pmc_$c.json 2> $out/pmc_$c.err; ls -la $out/pmc_$c | tail -2
 done
