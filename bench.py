@@ -7,10 +7,17 @@
 A "step" is one steady-state key frame: one new local frame + one new global-pool frame through
 backbone/RPN/res5/ROIAlign/fc0 (preprocessing included, uint8 frames resident in HBM), then the relation
 aggregation (7 attention calls), predictor and post-processing NMS -- the reference's per-key-frame work,
-nothing skipped.  Warm-up covers the cold start (frame 0: 13 local + 10 global frames) and fills the window,
-the global pool and the 25-frame memory when W >= 25.  N>1: the frame stage of each batch of steps is sharded
-over the ranks and the fixed-size frame records are exchanged with one RCCL all-gather ("strong" scaling:
-the clip is the same for every N).
+nothing skipped.
+
+What is timed is ALWAYS the steady state of SURVEY.md 8d (mirrors mega_core/engine/inference.py:24-42), whatever
+--warmup says: an internal pre-roll runs the cold start (frame 0: 13 local + 10 global frames) and then key frames
+until (i) the local window, the global pool and the 25-entry memory deques of all three stages are full and (ii) the
+steady frame-stage / aggregation hipGraphs have been captured AND replayed; --warmup only lengthens it.  The timed
+region is then R blocks of EXACTLY --steps key frames, each block bracketed by barrier + synchronize on both sides
+(R chosen so that the blocks cover >= ~1 s); `value` / `ms_per_step` are the MEDIAN block (all block times are in
+`config.timed_blocks_ms`).  The engine's graph statistics must not change inside the timed region (asserted).
+N>1: the frame stage of each batch of steps is sharded over the ranks and the fixed-size frame records are
+exchanged with one RCCL all-gather ("strong" scaling: the clip is the same for every N).
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract fields it carries
   roofline     -- the dominant kernel family (implicit-GEMM conv/linear on MFMA): algorithmic FLOPs of its launches
@@ -63,9 +70,11 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true", help="launch the frame stage kernel by kernel (no hipGraph)")
     ap.add_argument("--reuse-records", action="store_true",
                     help="compute each frame's record once per video (engine option; NOT the headline configuration)")
-    ap.add_argument("--static-aggregation", action="store_true",
-                    help="experimental: steady-state aggregation steps replayed from one hipGraph (engine option)")
-    ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    ap.add_argument("--no-static-aggregation", action="store_true",
+                    help="step the aggregation eagerly (~80 launches per key frame) instead of replaying one hipGraph")
+    ap.add_argument("--cpu-frames", type=int, default=3, help="steady key frames timed by the CPU baseline (memory full)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed blocks cover at least this long")
+    ap.add_argument("--max-blocks", type=int, default=60)
     return ap.parse_args()
 
 
@@ -90,9 +99,10 @@ def make_clip(T, H, W, device, unique=16):
     return base.index_select(0, idx).contiguous()
 
 
-def cpu_baseline(arch, sd, H, W, budget_s):
-    """oracle (kind 'port') on the host cores: cold start + a few steady frames, bounded by budget_s."""
-    import numpy as np
+def cpu_baseline(arch, sd, H, W, n_timed):
+    """oracle (kind 'port') on the host cores.  The oracle is stepped through the cold start and key frames 1..25
+    UNTIMED so that its 25-entry memory deques are full (the regime `value` is measured in), then `n_timed` steady
+    key frames are timed."""
     from oracle import mega_oracle as mo
     from mega.pytorch_amd import synth
     cores = min(host_cores(), 64)
@@ -100,29 +110,30 @@ def cpu_baseline(arch, sd, H, W, budget_s):
     log("cpu baseline on %d threads (affinity %d, cpu_count %s)" % (cores, host_cores(), os.cpu_count()))
     r50 = arch.startswith("R-50")
     ocfg = mo.OracleCfg(blocks=(3, 4, 6) if r50 else (3, 4, 23), reduce_channel=r50, global_res_stage=0 if r50 else 1)
-    T = 40
+    fill = ocfg.all_frame_interval + 1            # key frames 0..25: every memory deque holds 25 entries afterwards
+    T = fill + n_timed + 13
     frames = synth.preprocess_cpu(synth.make_clip(8, H, W, seed=0))
     frames = frames[torch.arange(T) % frames.shape[0]]
     _, gfor = mo.global_frame_schedule(T, ocfg.global_size, seed=0)
     orc = mo.MegaOracle({k: v.cpu() for k, v in sd.items()}, ocfg)
     times = []
-    t_all = time.perf_counter()
     with torch.no_grad():
-        for idx in range(T):
+        for idx in range(fill + n_timed):
             t0 = time.perf_counter()
             orc.forward_frame(frames[idx:idx + 1], 0 if idx == 0 else 1, ref_l=frames[min(T - 1, idx + 12)][None],
                               ref_g=[frames[g][None] for g in gfor(idx)], seg_len=T,
                               frame_loader=lambda i: frames[i][None])
             times.append(time.perf_counter() - t0)
-            log("cpu baseline frame %d: %.2fs" % (idx, times[-1]))
-            if idx >= 1 and time.perf_counter() - t_all > budget_s:
-                break
-    steady = times[1:]
+            if idx < 2 or idx >= fill - 1 or idx % 8 == 0:
+                log("cpu baseline frame %d: %.2fs (memory %d/25)" % (idx, times[-1], len(orc.mem_queue[0]["rois"])))
+    mem = [len(q["rois"]) for q in orc.mem_queue]
+    steady = times[fill:]
     fps = len(steady) / sum(steady)
-    return {"value": round(fps, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(fps, 4), "unit": "frames/s", "cores": cores, "kind": "port", "memory_frames": min(mem),
             "sample": "oracle/mega_oracle.py (torch-CPU fp32 restatement of the reference path), same weights and "
-                      "frame size, %d steady key frames after a %.1f s cold-start frame (memory pool still filling: "
-                      "%d of 25 frames)" % (len(steady), times[0], len(steady))}
+                      "frame size: %d steady key frames timed (%.2f s each) AFTER an untimed fill of %d key frames "
+                      "(cold start %.1f s + %.1f s) that leaves all memory deques full (%s of 25)"
+                      % (len(steady), sum(steady) / len(steady), fill, times[0], sum(times[1:fill]), min(mem))}
 
 
 def main():
@@ -153,14 +164,23 @@ def main():
     log("building model")
     cfg, model, sd = build_model(args.arch, args.dtype, device)
     log("model ready")
-    K, Wm = args.steps, max(args.warmup, 1)
+    K = args.steps
+    spb = args.steps_per_batch
+    afi = cfg.MODEL.VID.MEGA.ALL_FRAME_INTERVAL
+    # pre-roll (untimed): cold start + enough key frames to fill the 25-entry memory deques (frames >= 37)
+    # and to see the steady frame-stage batch shape three times (eager -> captured -> replayed); --warmup can only
+    # lengthen it.  Rounded so that the timed region starts on a batch boundary.
+    pre = max(args.warmup, afi + 12 + 1, 3 * spb + 1)
+    pre = 1 + -(-(pre - 1) // spb) * spb
+    extra_cap = 6 * spb                           # further pre-roll batches if the engine is not yet in steady state
+    max_blocks = max(1, min(args.max_blocks, -(-1200 // K)))
     prof_steps = 0 if args.no_roofline else 8
-    T = 1 + Wm + K + prof_steps + 13
+    T = pre + extra_cap + K * max_blocks + prof_steps + 1 + K + 13
     clip = make_clip(T, args.height, args.width, device)
     gfor = eng.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
-    runner = eng.ClipEngine(model, steps_per_batch=args.steps_per_batch, dist_group=group, overlap=not args.no_overlap,
+    runner = eng.ClipEngine(model, steps_per_batch=spb, dist_group=group, overlap=not args.no_overlap,
                             graphs=not args.no_graphs, reuse_records=args.reuse_records,
-                            static_aggregation=args.static_aggregation)
+                            static_aggregation=not args.no_static_aggregation)
 
     def barrier():
         torch.cuda.synchronize()
@@ -168,32 +188,76 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up: cold start (key frame 0) + W - 1 steady frames
-    log("clip ready (%d frames); warm-up" % T)
+    def engine_state():
+        fe = model.roi_heads.box.feature_extractor
+        st = runner.steady_state()
+        st["graph_stats"] = dict(runner.graph_stats)
+        st["static_graph_replays"] = runner.static_replays()
+        return st
+
+    # ---- pre-roll
+    log("clip ready (%d frames); pre-roll: cold start + %d key frames" % (T, pre - 1))
     runner.run(clip, T, gfor, first=0, last=1)
     barrier()
     log("cold start done")
-    runner.run(clip, T, gfor, first=1, last=Wm)
+    runner.run(clip, T, gfor, first=1, last=pre)
     barrier()
-    log("warm-up done; timing %d steps" % K)
+    pos = pre
+    while not runner.steady_state()["steady"] and pos < pre + extra_cap:
+        runner.run(clip, T, gfor, first=pos, last=pos + spb)
+        barrier()
+        pos += spb
+    st0 = engine_state()
+    log("pre-roll done at key frame %d: %s" % (pos, st0))
+    if not st0["steady"]:
+        log("WARNING: engine did not reach the steady state in the pre-roll (%s)" % (st0,))
     for k in runner.host_times:
         runner.host_times[k] = 0
     fc_before = runner.frames_computed
-    t0 = time.perf_counter()
-    dets = runner.run(clip, T, gfor, first=Wm, last=Wm + K)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    runner_frames_after = runner.frames_computed
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+
+    # ---- timed region: blocks of EXACTLY K key frames, each bracketed by barrier + synchronize
+    def timed_block(first):
+        barrier()
+        t0 = time.perf_counter()
+        d = runner.run(clip, T, gfor, first=first, last=first + K)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, d
+
+    blocks = []
+    dt, dets = timed_block(pos)
+    blocks.append(dt)
+    pos += K
+    nblk = max(1, min(max_blocks, int(-(-args.min_seconds // dt))))
+    if world > 1:      # every rank must run the same number of blocks
+        t = torch.tensor([nblk], dtype=torch.int64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        nblk = min(max_blocks, int(t.item()))
+    for _ in range(nblk - 1):
+        dt, dets = timed_block(pos)
+        blocks.append(dt)
+        pos += K
+    st1 = engine_state()
+    runner_frames_after = runner.frames_computed
+    srt = sorted(blocks)
+    elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     fps = K / elapsed
-    log("timed region: %.3fs (%.2f frames/s)" % (elapsed, fps))
-    log("frame-stage batches so far: %s; static aggregation steps: %d" % (runner.graph_stats, runner.static_steps))
+    log("timed region: %d blocks of %d steps, median %.4fs (%.2f frames/s), min %.4f max %.4f, total %.2fs" % (
+        len(blocks), K, elapsed, fps, srt[0], srt[-1], sum(blocks)))
+    captures_in_region = (st1["graph_stats"]["captured"] - st0["graph_stats"]["captured"]
+                          + st1["graph_stats"]["eager"] - st0["graph_stats"]["eager"])
+    log("engine state after the timed region: %s" % (st1,))
+    if not args.no_graphs:
+        assert captures_in_region == 0, "a frame-stage batch ran eagerly / was captured inside the timed region: %s -> %s" % (st0, st1)
+    assert st1["pools_full"], "pools not full in the timed region: %s" % (st1,)
     ht = dict(runner.host_times)
     log("host ms/step: frame-stage enqueue %.3f, aggregation enqueue %.3f, waiting for results %.3f" % tuple(
         1e3 * ht[k] / max(ht["steps"], 1) for k in ("frame_enqueue", "aggregate_enqueue", "finish_wait")))
+    Wm = pos - K * len(blocks)       # key frames processed before the first timed block
 
     roofline = None
     fam = {}
@@ -201,8 +265,9 @@ def main():
         p = ops.Profiler()
         ops.set_profiler(p)
         runner.use_graphs = False
+        runner.use_static = False  # the instrumented pass launches kernel by kernel: no hipGraph replays
         runner.overlap = False     # per-kernel event pairs are only meaningful without cross-stream concurrency
-        runner.run(clip, T, gfor, first=Wm + K, last=Wm + K + prof_steps)
+        runner.run(clip, T, gfor, first=pos, last=pos + prof_steps)
         summ = p.summary()
         ops.set_profiler(None)
         tot_ms = sum(v["ms"] for v in summ.values())
@@ -223,13 +288,16 @@ def main():
         # HBM traffic per launch of the dominant variant, from the committed rocprofv3 PMC passes of this same
         # command (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction; tools/pmc_summary.py)
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         sym = "igemm_kernel<%s, %s, %s, %s>" % (tag if tag == "bf16" else "float", tag if tag == "bf16" else "float",
                                                 tile[0], tile[1])
-        if os.path.exists(pmc):
-            k = json.load(open(pmc))["kernels"].get(sym)
-            if k:
-                traffic, traffic_src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/r01_pmc_summary.json"
+        for rnd in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
+            if os.path.exists(pmc):
+                ks = json.load(open(pmc))["kernels"]
+                k = next((v for name, v in ks.items() if name.replace(" ", "").startswith(sym.replace(" ", "")[:-1])), None)
+                if k:
+                    traffic, traffic_src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/%s_pmc_summary.json" % rnd
+                    break
         roofline = {"bound": "mfma", "kernel": sym + " (implicit-GEMM conv / linear)",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
@@ -246,6 +314,7 @@ def main():
     whole_clip = None
     try:
         runner.use_graphs, runner.overlap = not args.no_graphs, not args.no_overlap   # (the instrumented pass turned them off)
+        runner.use_static = True
         barrier()
         t0 = time.perf_counter()
         runner.run(clip, T, gfor, first=0, last=1 + K)
@@ -262,13 +331,13 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.arch, sd, args.height, args.width, args.cpu_seconds)
+        cpu = cpu_baseline(args.arch, sd, args.height, args.width, args.cpu_frames)
 
     if rank == 0:
         ndet = sum(len(d) for d in dets) / max(len(dets), 1)
         line = {
             "metric": "frames/sec MEGA %s inference, %dx%d VID clip" % (args.arch, args.width, args.height),
-            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": "MEGA %s-C4, %dx%d frames, 25 local + 10 global frames + 25-frame memory, "
@@ -276,8 +345,14 @@ def main():
                                    % (args.arch, args.width, args.height, "" if world == 1 else " sharded = configs[3]"),
                        "steps_per_batch": args.steps_per_batch, "parallelism": "frame-sharded x%d" % world,
                        "frame_record_reuse": bool(args.reuse_records),
-                       "static_aggregation": bool(args.static_aggregation),
-                       "frames_through_frame_stage_per_step": round((runner_frames_after - fc_before) / K, 2),
+                       "static_aggregation": not args.no_static_aggregation,
+                       "pre_roll_key_frames": Wm, "pools_full": bool(st0["pools_full"] and st1["pools_full"]),
+                       "graph_captures_in_timed_region": captures_in_region,
+                       "engine_state_before": st0, "engine_state_after": st1,
+                       "timed_blocks": len(blocks), "timed_blocks_ms": [round(1e3 * b, 2) for b in blocks],
+                       "value_is": "median block (each block = exactly --steps key frames between barrier+synchronize)",
+                       "clip": "16 unique synthetic frames repeated (timing does not depend on frame content)",
+                       "frames_through_frame_stage_per_step": round((runner_frames_after - fc_before) / (K * len(blocks)), 2),
                        "avg_detections": round(ndet, 1),
                        "key_proposals_last_frame": int(model.records[model.key_frame_location]["boxes"].shape[0]),
                        "whole_clip_incl_cold_start": whole_clip},

@@ -56,7 +56,7 @@ class _On(object):
 
 class ClipEngine(object):
     def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True, graphs=True, reuse_records=False,
-                 static_aggregation=False):
+                 static_aggregation=False, keep_logits=False):
         """steps_per_batch: key-frame steps whose frame jobs are computed in one frame-stage batch
         (steady state: 2 frames per step).  dist_group: torch.distributed group to shard the frame stage over
         (None = single process).  overlap: use the two-stream pipeline (see module docstring).
@@ -87,6 +87,9 @@ class ClipEngine(object):
         self.frames_per_launch = steps_per_batch + 2      # reuse_records: fixed frame-stage launch size
         # experimental, opt-in: steady-state aggregation steps on fixed-address pools, replayed from one hipGraph
         self._static = StaticAggregation(model, use_graph=graphs) if static_aggregation else None
+        self.use_static = True            # False: step eagerly even when a StaticAggregation exists (instrumented passes)
+        self.keep_logits = keep_logits    # tests: logits_log[i] = predictor class logits of the i-th key frame stepped
+        self.logits_log = []
         self.static_steps = 0
         self._rec_cache = {}              # frame id -> record (reuse_records)
         self._rec_pending = set()         # frame ids whose record is being computed by an enqueued batch
@@ -95,6 +98,32 @@ class ClipEngine(object):
         self._streams = None
         # host-side seconds spent enqueuing / waiting, accumulated over run() calls (diagnostics for bench.py)
         self.host_times = {"frame_enqueue": 0.0, "aggregate_enqueue": 0.0, "finish_wait": 0.0, "steps": 0}
+
+    # ------------------------------------------------------------------ state report (bench.py, tests)
+    def static_replays(self):
+        return 0 if self._static is None else self._static.replays
+
+    def steady_state(self):
+        """{"pools_full", "graphs_warm", "steady"}: pools_full = the local window, the global pool and the memory
+        deques of every stage hold their maximum number of entries (SURVEY.md 8d steady state); graphs_warm = the
+        steady frame-stage batch shape (and the aggregation step, with static aggregation) has been captured and
+        replayed at least once, i.e. no eager batch / capture is still ahead."""
+        m = self.model
+        fe = m.roi_heads.box.feature_extractor
+        if self._static is not None and self._static.active:
+            full = True                   # StaticAggregation.ready() only admits full pools
+        else:
+            full = hasattr(m, "records") and len(m.records) == m.all_frame_interval
+            if full and getattr(m, "global_enable", False):
+                full = len(fe.global_queue_list[0]["feats"]) == fe.global_size
+            if full and getattr(m, "memory_enable", False):
+                full = all(len(q["rois"]) == fe.all_frame_interval for q in fe.mem_queue_list)
+        warm = True
+        if self.use_graphs:
+            warm = self.graph_stats["replayed"] >= 1
+            if self._static is not None and self.use_static:
+                warm = warm and self._static.replays >= 1
+        return {"pools_full": bool(full), "graphs_warm": bool(warm), "steady": bool(full and warm)}
 
     # ------------------------------------------------------------------ schedule
     def jobs_for_step(self, idx, T, gfor):
@@ -338,13 +367,19 @@ class ClipEngine(object):
                         for x in loc[1:]:
                             m.records.append(x)
                         pending.append((i, m.step(None, glob, (W, H), defer=True)))
-                    elif self._static is not None and self._static.ready(loc[0], glob):
+                        if self.keep_logits:
+                            self.logits_log.append(m.last_logits.float().clone())
+                    elif self._static is not None and self.use_static and self._static.ready(loc[0], glob):
                         pending.append((i, self._static.step(loc[0], glob, (W, H))))
                         self.static_steps += 1
+                        if self.keep_logits:
+                            self.logits_log.append(self._static.last_logits.float().clone())
                     else:
                         if self._static is not None:
                             self._static.leave()
                         pending.append((i, m.step(loc[0], glob, (W, H), defer=True)))
+                        if self.keep_logits:
+                            self.logits_log.append(m.last_logits.float().clone())
                 if use_streams:   # detection counts of the whole batch -> pinned host memory, async + event
                     dc = torch.cat([pd[3] for _, pd in pending])
                     host = torch.empty(dc.shape, dtype=dc.dtype).pin_memory()
@@ -522,6 +557,7 @@ class StaticAggregation(object):
         kl = m.key_frame_location
         x = fe.aggregate(self.hist_feats[kl], self.hist_boxes[kl], rois, rois_dis, x_ref, self.dis_index)
         logits, deltas = m.roi_heads.box.predictor(x)
+        self.last_logits = logits         # (a graph output buffer once captured: read it right after the replay)
         kb = BoxListLike(self.hist_boxes[kl], im_size)
         return m.roi_heads.box.post_processor.run((logits, deltas), kb)
 

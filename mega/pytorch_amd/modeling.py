@@ -791,6 +791,7 @@ class GeneralizedRCNNMEGA(nn.Module):
         rois, rois_dis, x_ref, dis_index = self._window()
         x = fe.aggregate(key["feats"], key["boxes"], rois, rois_dis, x_ref, dis_index)
         logits, deltas = self.roi_heads.box.predictor(x)
+        self.last_logits = logits
         kb = BoxList(key["boxes"], im_size, "xyxy")
         kb.add_field("objectness", key["scores"])
         pp = self.roi_heads.box.post_processor

@@ -32,6 +32,9 @@ import ref_shim  # noqa: E402
 from mega.pytorch_amd import synth  # noqa: E402
 
 E2E = dict(H=160, W=256, T=30, nkey=4, seed_w=1, seed_clip=3, global_seed=0)
+# long clip: 44 key frames -> the 25-entry memory deques of all three stages and the 10-entry global deque WRAP
+# (roi_box_feature_extractors.py:657-688, read-before-push :914-917): the regime bench.py times
+E2E_LONG = dict(H=160, W=256, T=64, nkey=44, seed_w=1, seed_clip=6, global_seed=2)
 FGFA = dict(H=128, W=192, T=14, nkey=3, seed_w=2, seed_clip=4)
 RDN = dict(H=128, W=192, T=24, nkey=3, seed_w=2, seed_clip=4)
 
@@ -239,6 +242,59 @@ def golden_e2e():
     for k, v in c.items():
         out["cfg_" + k] = np.int64(v)
     np.savez_compressed(os.path.join(HERE, "ref_e2e_r50.npz"), **out)
+
+
+def golden_e2e_long():
+    """ref_e2e_long_r50.npz: the unmodified reference stepped through 44 key frames of a 64-frame clip (R-50 MEGA
+    config, 25 local / 10 global / 25 memory): every key frame's detections, predictor logits and the first rows of
+    the box-head output; plus the state sizes the reference itself holds at each step (memory / global deque lengths)
+    so that a test can assert that the fixture really covers eviction."""
+    c = E2E_LONG
+    cfg = ref_shim.make_cfg("configs/MEGA/vid_R_50_C4_MEGA_1x.yaml")
+    model = ref_shim.build_model(cfg)
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, stage=3, global_res_stage=0, seed=c["seed_w"])
+    model.load_state_dict(sd, strict=True)
+    frames = synth.preprocess_cpu(synth.make_clip(c["T"], c["H"], c["W"], seed=c["seed_clip"]))
+    rng = np.random.RandomState(c["global_seed"])
+    shuffled = np.arange(c["T"]); rng.shuffle(shuffled)
+    gs = cfg.MODEL.VID.MEGA.GLOBAL.SIZE
+    import mega_core.modeling.detector.generalized_rcnn_mega as gm
+
+    class _FakeImg(object):
+        def __init__(self, i): self.i = i
+        def convert(self, m): return self
+
+    class _FakeImage(object):
+        @staticmethod
+        def open(path): return _FakeImg(int(path))
+    gm.Image = _FakeImage
+    trace = {}
+    fe = model.roi_heads.box.feature_extractor
+    model.roi_heads.box.predictor.register_forward_hook(
+        lambda m, i, o: trace.update(x=i[0].detach().clone(), logits=o[0].detach().clone()))
+    out = {"mem_len": [], "glob_len": [], "nprop": [], "mem_rows": []}
+    for idx in range(c["nkey"]):
+        gl = [int(shuffled[(idx + gs - i - 1) % c["T"]]) for i in range(gs if idx == 0 else 1)]
+        images = {"cur": frames[idx], "ref_l": [frames[min(c["T"] - 1, idx + 12)]], "ref_g": [frames[g] for g in gl],
+                  "frame_category": 0 if idx == 0 else 1, "seg_len": c["T"], "pattern": "%d", "img_dir": "%s",
+                  "transforms": lambda im: frames[im.i]}
+        with torch.no_grad():
+            det = model(images)[0]
+        out["boxes%d" % idx] = det.bbox.numpy()
+        out["scores%d" % idx] = det.get_field("scores").numpy()
+        out["labels%d" % idx] = det.get_field("labels").numpy()
+        out["x%d" % idx] = trace["x"].numpy()[:16]
+        out["logits%d" % idx] = trace["logits"].numpy()
+        out["mem_len"].append([len(q["rois"]) for q in fe.mem_queue_list])
+        out["mem_rows"].append([int(fe.mem[i]["rois"].shape[0]) for i in range(len(fe.mem))])
+        out["glob_len"].append(len(fe.global_queue_list[0]["feats"]))
+        out["nprop"].append(trace["logits"].shape[0])
+        print("long frame", idx, "dets", det.bbox.shape[0], "props", trace["logits"].shape[0], "mem", out["mem_len"][-1])
+    for k in ("mem_len", "glob_len", "nprop", "mem_rows"):
+        out[k] = np.asarray(out[k], dtype=np.int64)
+    for k, v in c.items():
+        out["cfg_" + k] = np.int64(v)
+    np.savez_compressed(os.path.join(HERE, "ref_e2e_long_r50.npz"), **out)
 
 
 def golden_base():
@@ -488,9 +544,14 @@ if __name__ == "__main__":
     if not ref_shim.available():
         sys.exit("needs /root/reference")
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                      # e.g. `python tests/golden/make_golden.py golden_e2e_long`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     golden_from_reference_tests()
     golden_ops()
     golden_e2e()
+    golden_e2e_long()
     golden_fgfa()
     golden_base()
     golden_feed()

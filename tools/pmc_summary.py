@@ -15,10 +15,14 @@ import sys
 
 
 def short(k):
-    if "igemm_kernel" in k:
-        return k[k.index("igemm_kernel"):k.index(">(") + 1].replace("unsigned short", "bf16")
-    k = k.split("(")[0]
-    return k.replace("void ", "").replace("(anonymous namespace)::", "")[-80:]
+    """rocprofv3 kernel name -> short family name.  The anonymous-namespace prefix is stripped BEFORE the argument
+    list is cut off (every kernel of this library lives in `(anonymous namespace)`: cutting at the first "(" used to
+    collapse all of them into one empty name).  The split-K first FC of the box head is its own template
+    instantiation (igemm.hip), hence its own row."""
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "").replace("unsigned short", "bf16")
+    k = k.replace("__hip_bfloat16", "bf16")
+    name = k.split("(")[0].strip()
+    return name[-96:]
 
 
 def agg(path, name):
