@@ -1,0 +1,383 @@
+// Implicit-GEMM convolution / linear layer, bf16, for the big layers of the MEGA frame stage: 256-wide tiles,
+// 8 waves, operands staged HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPR round trip, no ds_write),
+// 8 half-tile slots in flight-order ring, counted vmcnt, raw s_barrier, two wave groups running half a phase apart so
+// that one group's MFMA segment always runs beside the other group's LDS-read / DMA-issue segment.
+//
+// Same contraction, layouts and epilogue as igemm.hip (see its header for the reference layers this replaces:
+// mega_core/modeling/backbone/resnet.py:324-344, rpn/rpn.py:99-106, roi_box_feature_extractors.py:894,:907).
+// Same MFMA instruction (v_mfma_f32_32x32x16_bf16) and the same ascending-K order per output element as the
+// igemm.hip tiles, so a row's result does not depend on which kernel / tile computed it (batch invariance).
+//
+// Geometry.  Block tile BM x 256 (BM = 256, or 192 with MF1 = 1), K-tile 64 bf16 = one 128-byte line per row.
+//   half-tiles: A0 = rows 0..127, A1 = rows 128..BM-1, B0 = cols 0..127, B1 = cols 128..255 (16 KiB each);
+//   wave (wr, wc) of a 2 x 4 grid owns, in every (Ai, Bj) quadrant of the tile, a 64(32) x 32 piece:
+//     rows i*128 + wr*64 + [0,64)   (A1 with MF1 = 1: 128 + wr*32 + [0,32)),   cols j*128 + wc*32 + [0,32).
+//   A K-tile is processed in 4 phases (A0,B0) (A0,B1) (A1,B1) (A1,B0); each half-tile is read from LDS exactly once
+//   per K-tile (phases 0,0,1,2), the fragments stay in registers for the second quadrant that uses them.
+// LDS (128 KiB): [parity 2][A0 | A1 | B0 | B1][128 rows][128 B].  A row's eight 16-byte chunks are stored XOR-swizzled
+//   (physical chunk = logical chunk ^ ((row >> 1) & 7)): every 16-lane group of a ds_read_b128 then touches 16
+//   different bank quads.  The DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address;
+//   the eight lanes of a row still read one whole 128-byte line.
+// Pipeline.  Half-tiles are issued in the order of use A0(t) B0(t) B1(t) A1(t) A0(t+1) ..., one per phase, six
+//   half-tiles ahead of the phase that issues (1.5 K-tiles: > 2000 cycles).  A slot is re-filled two or three phases
+//   after its last ds_read.  Every phase = [load segment: ds_reads of this phase, DMA issue, counted vmcnt] barrier
+//   [MFMA segment] barrier; wave group 1 (waves 4-7, one per SIMD like group 0) runs one barrier behind group 0.
+//   RAW: the wait that retires a half-tile sits before the barrier that ends the phase BEFORE the one that reads it
+//   (for both groups); WAR: see the schedule table in DESIGN.md section 3.
+#include "common.h"
+#include "igemm_params.h"
+
+namespace {
+
+constexpr int NT8 = 512;
+constexpr int ROWB = 128;              // bytes per LDS row = one K-tile of one row
+constexpr int HALF = 128 * ROWB;       // one half-tile slot (16 KiB)
+constexpr int PBUF = 4 * HALF;         // the four half-tiles of one K-tile parity
+constexpr int O_A0 = 0, O_A1 = HALF, O_B0 = 2 * HALF, O_B1 = 3 * HALF;
+constexpr int LDS8 = 2 * PBUF;         // 128 KiB
+constexpr unsigned OOB = 0x80000000u;  // >= num_records of every operand (operands are < 2 GiB): the DMA writes zeros
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+
+// scalar (wave-uniform) position of a K-tile inside the (r, s, c) loop of the implicit GEMM
+struct KPos {
+  int kc, ks, kr, dh, dw;
+  unsigned uni;                        // ((dh * W + dw) * Cin + kc) * 2 bytes
+};
+
+template <typename OT, int MF1>
+__global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
+  constexpr int BM = 128 + 64 * MF1;
+  constexpr int BN = 256;
+  constexpr int WROWS1 = 32 * MF1;     // rows a wave owns in A1
+  constexpr int CA1 = MF1;             // DMA instructions per wave for A1 (A0, B0, B1: 2 each)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- XCD-aware block -> tile map (bijective for any grid size): the blocks of one XCD walk N first, so they share
+  //      A row panels in that XCD's L2
+  const int ntn = (p.Cout + BN - 1) / BN;
+  int lid;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tile_m = lid / ntn, tile_n = lid - tile_m * ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+  // ---- staging descriptors: thread (prow, pch) fetches, for each half-tile, the pieces (row prow + 64 u, physical
+  //      chunk pch), u = 0, 1; the logical chunk it reads from memory is pch ^ swizzle(row)  (64 u does not change it)
+  const int prow = tid >> 3, pch = tid & 7;
+  const unsigned lcb = (unsigned)((pch ^ ((prow >> 1) & 7)) * 16);
+  int a_hi0[4], a_wi0[4];
+  unsigned a_off[4];
+  {
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (MF1 == 1 && r == 3) { a_hi0[r] = -(1 << 20); a_wi0[r] = 0; a_off[r] = 0; continue; }
+      const int m = m0 + (r >> 1) * 128 + prow + 64 * (r & 1);
+      const bool ok = m < p.M;
+      const int mm = ok ? m : 0;
+      const int nimg = mm / HoWo;
+      const int rem = mm - nimg * HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      a_hi0[r] = ok ? ho * p.stride - p.pad : -(1 << 20);      // a row past M never passes the range test below
+      a_wi0[r] = wo * p.stride - p.pad;
+      a_off[r] = ((unsigned)(nimg * p.H * p.W) + (unsigned)(a_hi0[r] * p.W + a_wi0[r])) * (unsigned)(p.Cin * 2) + lcb;
+    }
+  }
+  unsigned b_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + (r >> 1) * 128 + prow + 64 * (r & 1);
+    b_off[r] = n < p.Cout ? (unsigned)n * (unsigned)(p.K * 2) + lcb : OOB;
+  }
+
+  // ---- K range of this block (split-K: blockIdx.z owns a contiguous range of K-tiles)
+  const int nkt_all = p.K >> 6;
+  const int kt_per = (nkt_all + p.ksplit - 1) / p.ksplit;
+  const int kt0 = (int)blockIdx.z * kt_per;
+  const int nkt = min(kt_per, nkt_all - kt0);
+  auto kpos_init = [&](KPos& s) {
+    const int kk = kt0 * 64;
+    s.kc = kk % p.Cin;
+    s.ks = (kk / p.Cin) % p.S;
+    s.kr = (kk / p.Cin) / p.S;
+    s.dh = s.kr * p.dil;
+    s.dw = s.ks * p.dil;
+    s.uni = (unsigned)(((s.dh * p.W + s.dw) * p.Cin + s.kc) * 2);
+  };
+  auto kpos_next = [&](KPos& s) {
+    s.kc += 64;
+    if (s.kc >= p.Cin) {
+      s.kc = 0;
+      s.dw += p.dil;
+      if (++s.ks == p.S) { s.ks = 0; s.dw = 0; ++s.kr; s.dh += p.dil; }
+    }
+    s.uni = (unsigned)(((s.dh * p.W + s.dw) * p.Cin + s.kc) * 2);
+  };
+  KPos pa0, pa1;                       // K position of the next A0 / A1 half-tile to be issued
+  kpos_init(pa0);
+  kpos_init(pa1);
+  int ta0 = 0, ta1 = 0, tb0 = 0, tb1 = 0;   // tile index (relative to kt0) of the next A0 / A1 / B0 / B1 issue
+
+  unsigned char* const wbase = smem + wave * 1024;
+  auto issue_A = [&](int i, int par, const KPos& s, bool live) {
+#pragma unroll
+    for (int u = 0; u < (i == 1 ? CA1 : 2); ++u) {
+      const int r = i * 2 + u;
+      const int hi = a_hi0[r] + s.dh, wi = a_wi0[r] + s.dw;
+      const bool ok = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const unsigned off = ok ? a_off[r] + s.uni : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(wbase + par * PBUF + (i ? O_A1 : O_A0) + u * 8192), 16,
+                                               off, 0, 0, 0);
+    }
+  };
+  auto issue_B = [&](int j, int par, int tile, bool live) {
+    const unsigned kb = (unsigned)((kt0 + tile) * 128);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned off = live ? b_off[j * 2 + u] + kb : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wbase + par * PBUF + (j ? O_B1 : O_B0) + u * 8192), 16,
+                                               off, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses (bytes inside a half-tile slot): row (lane & 31) of the wave's piece, K step ks:
+  //      logical chunk 2 ks + (lane >> 5), swizzled by the row
+  const int l31 = lane & 31;
+  unsigned a_rd[4], a1_rd[4], b_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const unsigned ch = (unsigned)(((ks * 2 + (lane >> 5)) ^ ((l31 >> 1) & 7)) * 16);
+    a_rd[ks] = (unsigned)((wr * 64 + l31) * ROWB) + ch;
+    a1_rd[ks] = (unsigned)((wr * WROWS1 + l31) * ROWB) + ch;
+    b_rd[ks] = (unsigned)((wc * 32 + l31) * ROWB) + ch;
+  }
+
+  f32x16_t acc[2][2][2];               // [A half i][M fragment f][B half j]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][f][j][r] = 0.f;
+
+  uint4 af[2][4], b0f[4], b1f[4];
+  auto ld = [&](unsigned off) { return *reinterpret_cast<const uint4*>(smem + off); };
+
+#define MEGA_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define MEGA_BAR()                    \
+  do {                                \
+    asm volatile("" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();     \
+    asm volatile("" ::: "memory");   \
+  } while (0)
+  constexpr int VMW = 6 + CA1;         // loads that may stay in flight at the end of a load segment (see header)
+
+  // ---- prologue: six half-tiles
+  issue_A(0, 0, pa0, ta0 < nkt); kpos_next(pa0); ++ta0;
+  issue_B(0, 0, tb0, tb0 < nkt); ++tb0;
+  issue_B(1, 0, tb1, tb1 < nkt); ++tb1;
+  issue_A(1, 0, pa1, ta1 < nkt); kpos_next(pa1); ++ta1;
+  issue_A(0, 1, pa0, ta0 < nkt); kpos_next(pa0); ++ta0;
+  issue_B(0, 1, tb0, tb0 < nkt); ++tb0;
+  MEGA_WAIT_VM(VMW);
+  MEGA_BAR();
+  if (wr == 1) MEGA_BAR();             // group 1 runs one barrier behind group 0
+
+  const int nkt2 = (nkt + 1) & ~1;     // an odd tail tile is computed on all-zero operands (its DMAs are out of range)
+  for (int t = 0; t < nkt2; t += 2) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const unsigned base = (unsigned)(par * PBUF);
+      // ================= phase 0: (A0, B0)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        af[0][ks] = ld(base + O_A0 + a_rd[ks]);
+        af[1][ks] = ld(base + O_A0 + 32 * ROWB + a_rd[ks]);
+        b0f[ks] = ld(base + O_B0 + b_rd[ks]);
+      }
+      issue_B(1, par ^ 1, tb1, tb1 < nkt); ++tb1;
+      MEGA_WAIT_VM(VMW);
+      MEGA_BAR();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        mma(acc[0][0][0], af[0][ks], b0f[ks]);
+        mma(acc[0][1][0], af[1][ks], b0f[ks]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      MEGA_BAR();
+      // ================= phase 1: (A0, B1)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) b1f[ks] = ld(base + O_B1 + b_rd[ks]);
+      issue_A(1, par ^ 1, pa1, ta1 < nkt); kpos_next(pa1); ++ta1;
+      MEGA_WAIT_VM(VMW);
+      MEGA_BAR();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        mma(acc[0][0][1], af[0][ks], b1f[ks]);
+        mma(acc[0][1][1], af[1][ks], b1f[ks]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      MEGA_BAR();
+      // ================= phase 2: (A1, B1)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        af[0][ks] = ld(base + O_A1 + a1_rd[ks]);
+        if (MF1 == 2) af[1][ks] = ld(base + O_A1 + 32 * ROWB + a1_rd[ks]);
+      }
+      issue_A(0, par, pa0, ta0 < nkt); kpos_next(pa0); ++ta0;
+      MEGA_BAR();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        mma(acc[1][0][1], af[0][ks], b1f[ks]);
+        if (MF1 == 2) mma(acc[1][1][1], af[1][ks], b1f[ks]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      MEGA_BAR();
+      // ================= phase 3: (A1, B0)  -- both operands are still in registers
+      issue_B(0, par, tb0, tb0 < nkt); ++tb0;
+      MEGA_WAIT_VM(VMW);
+      MEGA_BAR();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        mma(acc[1][0][0], af[0][ks], b0f[ks]);
+        if (MF1 == 2) mma(acc[1][1][0], af[1][ks], b0f[ks]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      MEGA_BAR();
+    }
+  }
+  if (wr == 0) MEGA_BAR();             // group 0 waits for group 1's last MFMA segment
+  MEGA_WAIT_VM(0);                     // the out-of-range tail DMAs also write (zeros) into the LDS re-used below
+  MEGA_BAR();
+
+  // ---- epilogue: accumulators (lane owns column lane & 31, rows (r&3) + 8 (r>>2) + 4 (lane>>5) of a 32 x 32
+  //      fragment) are scaled / biased and staged through LDS as f32, one 64-row slab per (A half, M fragment) --
+  //      the two wave rows' 32-row fragments, all 256 columns -- then written as whole 16-byte vectors along n with
+  //      residual add and activation: same scheme as igemm.hip.
+  constexpr int CST = BN + 4;
+  static_assert(64 * CST * 4 <= LDS8, "staging slab must fit");
+  float* cs = reinterpret_cast<float*>(smem);
+  OT* __restrict__ out = (OT*)p.out;
+  const bf16_t* __restrict__ res = (const bf16_t*)p.res;
+  constexpr int OVE = 16 / (int)sizeof(OT);
+  constexpr int VPR = BN / OVE;
+  const float neg_slope = p.relu == 1 ? 0.f : (p.relu == 2 ? 0.1f : 1.f);
+  auto act = [&](float x) { return x > 0.f ? x : x * neg_slope; };
+  const bool vec_ok = (p.ldo % OVE == 0) && (!res || (sizeof(OT) == 2 && p.ldr % OVE == 0));
+  float sc[2], bi[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + j * 128 + wc * 32 + l31;
+    sc[j] = (p.ksplit == 1 && p.scale && n < p.Cout) ? p.scale[n] : 1.f;
+    bi[j] = (p.ksplit == 1 && p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int f = 0; f < (i == 1 ? MF1 : 2); ++f) {
+      if (i + f > 0) __syncthreads();                  // the previous slab has been read out
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nl = j * 128 + wc * 32 + l31;
+        const int rb = wr * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][f][j][r] * sc[j] + bi[j];
+      }
+      __syncthreads();
+      const int wrows = i == 1 ? WROWS1 : 64;          // rows per wave row inside this A half
+      if (p.ksplit > 1) {                              // raw partial sums; splitk_finalize_kernel (igemm.hip) finishes
+        float* part = p.partial + (size_t)blockIdx.z * p.M * p.Cout;
+        for (int e = tid; e < 64 * (BN / 4); e += NT8) {
+          const int row = e / (BN / 4), cv = e - row * (BN / 4);
+          const int m = m0 + i * 128 + (row >> 5) * wrows + f * 32 + (row & 31), n = n0 + cv * 4;
+          if (m >= p.M || n >= p.Cout) continue;
+          const float4 v = *reinterpret_cast<const float4*>(cs + row * CST + cv * 4);
+          if (n + 4 <= p.Cout && p.Cout % 4 == 0) {
+            *reinterpret_cast<float4*>(part + (size_t)m * p.Cout + n) = v;
+          } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            for (int t = 0; t < 4 && n + t < p.Cout; ++t) part[(size_t)m * p.Cout + n + t] = vv[t];
+          }
+        }
+        continue;
+      }
+      for (int e = tid; e < 64 * VPR; e += NT8) {
+        const int row = e / VPR, cv = e - row * VPR;
+        const int m = m0 + i * 128 + (row >> 5) * wrows + f * 32 + (row & 31), n = n0 + cv * OVE;
+        if (m >= p.M || n >= p.Cout) continue;
+        float v[OVE];
+#pragma unroll
+        for (int t = 0; t < OVE; t += 4) {
+          const float4 q4 = *reinterpret_cast<const float4*>(cs + row * CST + cv * OVE + t);
+          v[t] = q4.x; v[t + 1] = q4.y; v[t + 2] = q4.z; v[t + 3] = q4.w;
+        }
+        if (vec_ok && n + OVE <= p.Cout) {
+          if (res) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
+            const bf16_t* re = reinterpret_cast<const bf16_t*>(&rr);
+#pragma unroll
+            for (int t = 0; t < OVE; ++t) v[t] += bf16_to_f32(re[t]);
+          }
+          uint4 o;
+          OT* oe = reinterpret_cast<OT*>(&o);
+#pragma unroll
+          for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, act(v[t]));
+          *reinterpret_cast<uint4*>(out + (size_t)m * p.ldo + n) = o;
+        } else {
+          for (int t = 0; t < OVE && n + t < p.Cout; ++t) {
+            float x = v[t];
+            if (res) x += bf16_to_f32(res[(size_t)m * p.ldr + n + t]);
+            Elem<OT>::st(out + (size_t)m * p.ldo + n + t, act(x));
+          }
+        }
+      }
+    }
+  }
+#undef MEGA_WAIT_VM
+#undef MEGA_BAR
+}
+
+template <typename OT, int MF1>
+int launch8(const ConvParams& p, hipStream_t st) {
+  constexpr int BM = 128 + 64 * MF1;
+  const int ntm = cdiv(p.M, BM), ntn = cdiv(p.Cout, 256);
+  // set on every launch (a per-process flag would miss the second device of a multi-GPU process)
+  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+  hipLaunchKernelGGL((igemm8_kernel<OT, MF1>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8, st, p);
+  return mega_check_launch();
+}
+
+}  // namespace
+
+int mega_igemm8_supports(const ConvParams& p) {
+  return p.Cin % 64 == 0 && p.in_bytes < 0x7FF00000u && p.w_bytes < 0x7FF00000u && (p.K >> 6) >= 2;
+}
+
+int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st) {
+  if (bm == 256) return out_f32 ? launch8<float, 2>(p, st) : launch8<bf16_t, 2>(p, st);
+  if (bm == 192) return out_f32 ? launch8<float, 1>(p, st) : launch8<bf16_t, 1>(p, st);
+  return MEGA_ERR_ARG;
+}

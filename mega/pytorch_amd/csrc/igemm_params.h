@@ -1,0 +1,25 @@
+// Launch parameters shared by the implicit-GEMM kernels (igemm.hip: register-staged 2-barrier tiles;
+// igemm8.hip: LDS-DMA 8-phase 256-wide tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct ConvParams {
+  const void* in;
+  const void* w;
+  const float* scale;
+  const float* bias;
+  const void* res;
+  void* out;
+  int N, H, W, Cin, Cout, R, S, stride, pad, dil, Ho, Wo;
+  int M, K;
+  int ldo, ldr;
+  int relu;          // 0 none, 1 ReLU, 2 LeakyReLU(0.1)
+  unsigned in_bytes, w_bytes;
+  int ksplit;        // > 1: blockIdx.z owns a contiguous range of K-tiles and writes raw f32 partial sums
+  float* partial;    // [ksplit][M][Cout] f32 when ksplit > 1
+};
+
+// igemm8.hip: bf16 operands, 8 waves, 256 (BM8 rows) x 256 tile; returns MEGA_OK / MEGA_ERR_*.  out_f32: 0 bf16, 1 f32.
+int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st);
+// 1 when the shape is one igemm8 can take (bf16, Cin % 64 == 0, operands < 2 GiB, ...)
+int mega_igemm8_supports(const ConvParams& p);

@@ -90,6 +90,7 @@ class ClipEngine(object):
         self.use_static = True            # False: step eagerly even when a StaticAggregation exists (instrumented passes)
         self.keep_logits = keep_logits    # tests: logits_log[i] = predictor class logits of the i-th key frame stepped
         self.logits_log = []
+        self.key_boxes_log = []           # and the key frame's proposal boxes (rows of logits_log[i])
         self.static_steps = 0
         self._rec_cache = {}              # frame id -> record (reuse_records)
         self._rec_pending = set()         # frame ids whose record is being computed by an enqueued batch
@@ -369,17 +370,20 @@ class ClipEngine(object):
                         pending.append((i, m.step(None, glob, (W, H), defer=True)))
                         if self.keep_logits:
                             self.logits_log.append(m.last_logits.float().clone())
+                            self.key_boxes_log.append(m.records[m.key_frame_location]["boxes"].clone())
                     elif self._static is not None and self.use_static and self._static.ready(loc[0], glob):
                         pending.append((i, self._static.step(loc[0], glob, (W, H))))
                         self.static_steps += 1
                         if self.keep_logits:
                             self.logits_log.append(self._static.last_logits.float().clone())
+                            self.key_boxes_log.append(self._static.hist_boxes[m.key_frame_location].clone())
                     else:
                         if self._static is not None:
                             self._static.leave()
                         pending.append((i, m.step(loc[0], glob, (W, H), defer=True)))
                         if self.keep_logits:
                             self.logits_log.append(m.last_logits.float().clone())
+                            self.key_boxes_log.append(m.records[m.key_frame_location]["boxes"].clone())
                 if use_streams:   # detection counts of the whole batch -> pinned host memory, async + event
                     dc = torch.cat([pd[3] for _, pd in pending])
                     host = torch.empty(dc.shape, dtype=dc.dtype).pin_memory()

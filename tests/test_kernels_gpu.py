@@ -473,3 +473,94 @@ def test_relation_attention_tiled_pos(dev, shape):
     b = ops.relation_attention(q.to(dev), k.to(dev), vt.to(dev), Nk, pos=_tile_pos(pos, Nk).to(dev), resid=resid.to(dev),
                                bias_v=bv.to(dev))
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ hot shapes
+# The exact shapes of the benchmarked configuration (MEGA R-101, 600x1000, 20-frame frame-stage batches):
+# SURVEY.md Appendix A attention call list, the first FC of the box head, the RPN conv through its natural dispatch.
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(675, 3750, True), (1875, 750, False), (300, 750, True)])
+def test_relation_attention_hot_shapes(dev, dtype, shape):
+    """local stage 0 (675 x 3750 with the position term: 1875 window rows + 1875 memory rows), the global stage over
+    the whole window (1875 x 750) and the last local stage (300 x 750) against the literal reference formula."""
+    from oracle import mega_oracle as mo
+    from mega.pytorch_amd import synth
+    from mega.pytorch_amd.relation import RelationWeights, relation_attention_forward
+    Nq, Nk, use_pos = shape
+    torch.set_num_threads(16)
+    sd = synth.make_state_dict(blocks=(1, 1, 1), seed=4)
+    g = torch.Generator().manual_seed(Nq + Nk)
+    x = torch.randn((Nq, 1024), generator=g).to(dtype)
+    r = torch.randn((Nk, 1024), generator=g).to(dtype)
+
+    def boxes(n):
+        c = torch.rand((n, 2), generator=g) * torch.tensor([900., 500.])
+        wh = torch.rand((n, 2), generator=g) * 250 + 2
+        return torch.cat([c - wh / 2, c + wh / 2], dim=1)
+    bq, bk = boxes(Nq), boxes(Nk)
+    ver = "local" if use_pos else "global"
+    with torch.no_grad():
+        pe = mo.cal_position_embedding(bq, bk) if use_pos else None
+        ref = x.float() + mo.attention_module_multi_head(sd, mo.FE, ver, 0, x.float(), r.float(), pe)
+    del pe
+    wts = RelationWeights(sd, mo.FE, "l_" if use_pos else "g_", 0, dtype, dev, with_pos=use_pos)
+    out = relation_attention_forward(wts, x.to(dev), r.to(dev), bq.to(dev) if use_pos else None,
+                                     bk.to(dev) if use_pos else None, residual=True)
+    err = _relerr(out.float().cpu(), ref)
+    assert err < (2e-4 if dtype == torch.float32 else 3e-2), "attention %s %s relerr %.3g" % (shape, dtype, err)
+    # the engine's form of the same call: the second half of the keys arrives as cached memory projections
+    if use_pos and Nk == 3750:
+        h = Nk // 2
+        _, k1, vt1 = relation_attention_forward(wts, x[:8].to(dev), r[h:].to(dev), bq[:8].to(dev), bk[h:].to(dev),
+                                                residual=True, return_kv=True)
+        out2 = relation_attention_forward(wts, x.to(dev), r[:h].to(dev), bq.to(dev), bk.to(dev), residual=True,
+                                          mem_kv=(k1, vt1[:, :Nk - h].contiguous()))
+        err2 = _relerr(out2.float().cpu(), ref)
+        assert err2 < (2e-4 if dtype == torch.float32 else 3e-2), "attention with cached memory K/V: relerr %.3g" % err2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_first_fc_hot_shape(dev, dtype):
+    """l_fcs[0] at its real size: K = 100352 (2048 x 7 x 7), 1024 outputs, M = 375 rows (one 300-row local frame + one
+    75-row global frame), through the split-K path its natural dispatch takes."""
+    ops = _ops()
+    torch.set_num_threads(16)
+    g = torch.Generator().manual_seed(21)
+    M, K, N = 375, 100352, 1024
+    x = torch.randn((M, K), generator=g).to(dtype)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn((N,), generator=g) * 0.1
+    ref = F.relu(F.linear(x.float(), w.float(), b))
+    out = ops.linear(x.to(dev), w.to(dev), b.to(dev), relu=True)
+    err = _relerr(out.float().cpu(), ref)
+    assert err < (1e-4 if dtype == torch.float32 else 2e-2), "fc0 %s relerr %.3g" % (dtype, err)
+    # batch invariance: the same rows inside a bigger batch give the same bits
+    x2 = torch.cat([x, x.flip(0)], dim=0)
+    out2 = ops.linear(x2.to(dev), w.to(dev), b.to(dev), relu=True)
+    assert torch.equal(out2[:M], out)
+
+
+def test_rpn_conv_natural_dispatch_hot_shape(dev):
+    """The RPN 3x3 conv (1024 -> 1024, K = 9216) on a 20-frame batch of 38x63 maps (M = 47880), through the tile its
+    natural dispatch picks, bf16: (i) two whole frames against torch-CPU fp32 on the same bf16-rounded operands,
+    (ii) all 20 frames bit-identical to the same frames computed in batches of 1 (batch invariance across tiles)."""
+    ops = _ops()
+    lib = __import__("mega.pytorch_amd._lib", fromlist=["load"]).load()
+    torch.set_num_threads(16)
+    g = torch.Generator().manual_seed(33)
+    Nf, H, W, C = 20, 38, 63, 1024
+    x = (torch.randn((Nf, H, W, C), generator=g)).to(torch.bfloat16)
+    w = (torch.randn((C, 3, 3, C), generator=g) / math.sqrt(9 * C)).to(torch.bfloat16)
+    b = torch.randn((C,), generator=g) * 0.1
+    tile = lib.mega_conv2d_nhwc_tile(Nf * H * W, C, 9 * C)
+    print("RPN conv natural tile: %dx%d" % (tile // 1000, tile % 1000))
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    out = ops.conv2d_nhwc(xd, wd, None, bd, pad=1, relu=True)
+    for f in (0, Nf - 1):
+        ref = F.relu(F.conv2d(x[f:f + 1].float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, padding=1))
+        err = _relerr(out[f:f + 1].float().cpu().permute(0, 3, 1, 2), ref)
+        assert err < 2e-2, "frame %d relerr %.3g" % (f, err)
+    for f in (0, 7, Nf - 1):
+        one = ops.conv2d_nhwc(xd[f:f + 1].contiguous(), wd, None, bd, pad=1, relu=True)
+        assert torch.equal(one[0], out[f]), "frame %d differs between batch-of-1 and batch-of-%d dispatch" % (f, Nf)
