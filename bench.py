@@ -277,9 +277,10 @@ def main():
                       "gbps": round(v["bytes"] / (v["ms"] * 1e6), 1) if v["ms"] > 0 else 0.0}
         # dominant kernel = the igemm instantiation (one rocprofv3 kernel symbol) with the largest share of GPU time
         tag = "bf16" if args.dtype == "bfloat16" else "f32"
-        igemms = {k: v for k, v in summ.items() if k.startswith("igemm_" + tag)}
+        igemms = {k: v for k, v in summ.items() if k.startswith(("igemm_" + tag, "igemm8_" + tag))}
         dom = max(igemms, key=lambda k: igemms[k]["ms"])
         tile = dom.rsplit("_", 1)[1].split("x")
+        is8 = dom.startswith("igemm8_")
         peak = 2500.0 if args.dtype == "bfloat16" else 157.3
         d = summ[dom]
         ach = d["flops"] / (d["ms"] * 1e9)
@@ -288,8 +289,11 @@ def main():
         # HBM traffic per launch of the dominant variant, from the committed rocprofv3 PMC passes of this same
         # command (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction; tools/pmc_summary.py)
         traffic, traffic_src = None, None
-        sym = "igemm_kernel<%s, %s, %s, %s>" % (tag if tag == "bf16" else "float", tag if tag == "bf16" else "float",
-                                                tile[0], tile[1])
+        if is8:       # igemm8_kernel<OT, MF1>: MF1 = 2 (256-row tile) or 1 (192-row tile)
+            sym = "igemm8_kernel<bf16, %d>" % (2 if tile[0] == "256" else 1)
+        else:
+            sym = "igemm_kernel<%s, %s, %s, %s>" % (tag if tag == "bf16" else "float", tag if tag == "bf16" else "float",
+                                                    tile[0], tile[1])
         for rnd in ("r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
             if os.path.exists(pmc):
@@ -298,7 +302,8 @@ def main():
                 if k:
                     traffic, traffic_src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/%s_pmc_summary.json" % rnd
                     break
-        roofline = {"bound": "mfma", "kernel": sym + " (implicit-GEMM conv / linear)",
+        roofline = {"bound": "mfma", "kernel": sym + " (implicit-GEMM conv / linear%s)" % (
+                        ", %sx256 tile" % tile[0] if is8 else ""),
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                     "flops_per_launch": round(d["flops"] / d["launches"], 0),

@@ -48,6 +48,11 @@ int mega_conv2d_nhwc(const void* in, const void* w, const float* scale, const fl
  * a GEMM of M = N*Ho*Wo rows, Cout columns, K = R*S*Cin: lets a profiler attribute time to the kernel symbol
  * rocprofv3 reports.  No device work. */
 int mega_conv2d_nhwc_tile(int M, int Cout, int K);
+/* Same, for a given operand dtype (MEGA_F32 / MEGA_BF16): kind * 1000000 + BM * 1000 + BN with kind 0 =
+ * igemm_kernel<.., BM, BN> (register-staged tiles) and kind 8 = igemm8_kernel (bf16 only: LDS-DMA staging, 8 waves,
+ * BM x 256 tiles, BM = 256 or 192).  Every kernel accumulates an output element over K in the same order with the
+ * same MFMA instruction, so the choice never changes a result bit. */
+int mega_conv2d_nhwc_plan(int M, int Cout, int K, int in_dtype);
 
 /* mega_conv2d_nhwc with a caller-owned workspace of mega_conv2d_nhwc_workspace_bytes(M, Cout, K) bytes (M = N*Ho*Wo,
  * K = R*S*Cin; 0 for most layers).  With it, layers with K >= 32768 (the box head's first FC, K = 100352) run

@@ -44,6 +44,7 @@ SIGNATURES = {
                                         c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                         c_int, c_void_p, c_size_t, c_void_p]),
     "mega_conv2d_nhwc_tile": (c_int, [c_int] * 3),
+    "mega_conv2d_nhwc_plan": (c_int, [c_int] * 4),
     "mega_preprocess_frames": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
     "mega_dff_warp_scale": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "mega_resize_bilinear_u8": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p,

@@ -15,6 +15,7 @@ LIB = os.path.join(HERE, "libmega_hip.so")
 STAMP = os.path.join(HERE, "csrc", ".build_stamp")
 SOURCES = {
     "igemm.hip": [],
+    "igemm8.hip": [],
     "spatial.hip": [],
     "boxes.hip": ["-ffp-contract=off"],
     "relation.hip": [],

@@ -20,28 +20,13 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "igemm_params.h"
 
 namespace {
 
 constexpr int KTB = 128;          // bytes of K per LDS row per K-tile
 constexpr int LDS_STRIDE = 144;   // bytes, 128 + 16 pad
 constexpr int NTHREADS = 256;
-
-struct ConvParams {
-  const void* in;
-  const void* w;
-  const float* scale;
-  const float* bias;
-  const void* res;
-  void* out;
-  int N, H, W, Cin, Cout, R, S, stride, pad, dil, Ho, Wo;
-  int M, K;
-  int ldo, ldr;
-  int relu;
-  unsigned in_bytes, w_bytes;
-  int ksplit;        // > 1: blockIdx.z owns a contiguous range of K-tiles and writes raw f32 partial sums
-  float* partial;    // [ksplit][M][Cout] f32 when ksplit > 1
-};
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -310,11 +295,8 @@ template <typename T, typename OT, int BM, int BN>
 int launch(const ConvParams& p, hipStream_t st) {
   const int ntm = cdiv(p.M, BM), ntn = cdiv(p.Cout, BN);
   const size_t smem = 2 * (BM + BN) * LDS_STRIDE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)igemm_kernel<T, OT, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  // set on every launch: a per-process flag would miss the second device of a multi-GPU process (cheap host call)
+  (void)hipFuncSetAttribute((const void*)igemm_kernel<T, OT, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL((igemm_kernel<T, OT, BM, BN>), dim3(ntm * ntn, 1, p.ksplit), dim3(NTHREADS), smem, st, p);
   return mega_check_launch();
 }
@@ -352,12 +334,26 @@ int launch_finalize(const ConvParams& p, hipStream_t st) {
 // the box head's first FC (K = 100352 on R-101) qualifies: two halves of 784 K-tiles double the resident blocks.
 inline int choose_ksplit(int K) { return K >= 32768 ? 2 : 1; }
 
-inline void choose_tile(int M, int Cout, int K, int z, int& bm, int& bn) {
-  const char* force = getenv("MEGA_IGEMM_TILE");   // e.g. "256x128": experiments / tests only
+// kind 0: igemm_kernel<.., bm, bn> (this file);  kind 8: igemm8_kernel (igemm8.hip: LDS-DMA, 8 waves, bm x 256), bf16 only.
+// MEGA_IGEMM_TILE forces a choice (experiments / tests): "128x64" or "8:256" / "8:192".
+inline void choose_tile(int M, int Cout, int K, int z, bool bf16, int& kind, int& bm, int& bn) {
+  kind = 0;
+  const char* force = getenv("MEGA_IGEMM_TILE");
+  if (force && sscanf(force, "8:%d", &bm) == 1) { kind = 8; bn = 256; return; }
   if (force && sscanf(force, "%dx%d", &bm, &bn) == 2) return;
   const long b256 = (long)cdiv(M, 256) * cdiv(Cout, 256) * z;
   const long b128 = (long)cdiv(M, 128) * cdiv(Cout, 128) * z;
   const long b12864 = (long)cdiv(M, 128) * cdiv(Cout, 64) * z;
+  static const int use8 = getenv("MEGA_IGEMM8") ? atoi(getenv("MEGA_IGEMM8")) : 1;
+  if (bf16 && use8 && Cout >= 256 && K >= 128) {
+    // igemm8 runs one block per CU: pick the row count that wastes the fewest CU-rounds (cost ~ rounds x rows)
+    const long t256 = (long)cdiv(M, 256) * cdiv(Cout, 256) * z, t192 = (long)cdiv(M, 192) * cdiv(Cout, 256) * z;
+    const long c256 = cdiv((int)t256, 256) * 256L * 8, c192 = cdiv((int)t192, 256) * 192L * 9;   // 192: ~12 % slower per row
+    if (t256 >= 128 || t192 >= 128) {
+      kind = 8; bn = 256; bm = c192 < c256 ? 192 : 256;
+      return;
+    }
+  }
   if (K >= 8192 && Cout >= 1024 && b256 >= 700) { bm = 256; bn = 256; }
   else if (Cout > 64 && b128 >= 384) { bm = 128; bn = 128; }
   else if (b12864 >= 384) { bm = 128; bn = 64; }
@@ -366,9 +362,14 @@ inline void choose_tile(int M, int Cout, int K, int z, int& bm, int& bn) {
 
 template <typename T, typename OT>
 int dispatch_tile(const ConvParams& p, hipStream_t st) {
-  int bm = 0, bn = 0, rc;
-  choose_tile(p.M, p.Cout, p.K, p.ksplit, bm, bn);
-  if (bm == 256 && bn == 256) rc = launch<T, OT, 256, 256>(p, st);
+  int kind = 0, bm = 0, bn = 0, rc;
+  constexpr bool is_bf16 = sizeof(T) == 2;
+  choose_tile(p.M, p.Cout, p.K, p.ksplit, is_bf16, kind, bm, bn);
+  if (kind == 8 && !(is_bf16 && mega_igemm8_supports(p))) {    // forced onto a shape it cannot take
+    kind = 0; bm = 128; bn = 128;
+  }
+  if (kind == 8) rc = mega_igemm8_launch(p, bm, sizeof(OT) == 4, st);
+  else if (bm == 256 && bn == 256) rc = launch<T, OT, 256, 256>(p, st);
   else if (bm == 256 && bn == 128) rc = launch<T, OT, 256, 128>(p, st);
   else if (bm == 128 && bn == 128) rc = launch<T, OT, 128, 128>(p, st);
   else if (bm == 128 && bn == 64) rc = launch<T, OT, 128, 64>(p, st);
@@ -379,11 +380,14 @@ int dispatch_tile(const ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mega_conv2d_nhwc_tile(int M, int Cout, int K) {
-  int bm = 0, bn = 0;
-  choose_tile(M, Cout, K, choose_ksplit(K), bm, bn);
-  return bm * 1000 + bn;
+extern "C" int mega_conv2d_nhwc_plan(int M, int Cout, int K, int in_dtype) {
+  int kind = 0, bm = 0, bn = 0;
+  choose_tile(M, Cout, K, choose_ksplit(K), in_dtype == MEGA_BF16, kind, bm, bn);
+  if (kind == 8 && (K >> 6) < 2) { kind = 0; bm = 128; bn = 128; }
+  return kind * 1000000 + bm * 1000 + bn;
 }
+
+extern "C" int mega_conv2d_nhwc_tile(int M, int Cout, int K) { return mega_conv2d_nhwc_plan(M, Cout, K, MEGA_BF16) % 1000000; }
 
 extern "C" size_t mega_conv2d_nhwc_workspace_bytes(int M, int Cout, int K) {
   const int z = choose_ksplit(K);

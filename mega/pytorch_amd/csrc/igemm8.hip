@@ -14,7 +14,7 @@
 //     rows i*128 + wr*64 + [0,64)   (A1 with MF1 = 1: 128 + wr*32 + [0,32)),   cols j*128 + wc*32 + [0,32).
 //   A K-tile is processed in 4 phases (A0,B0) (A0,B1) (A1,B1) (A1,B0); each half-tile is read from LDS exactly once
 //   per K-tile (phases 0,0,1,2), the fragments stay in registers for the second quadrant that uses them.
-// LDS (128 KiB): [parity 2][A0 | A1 | B0 | B1][128 rows][128 B].  A row's eight 16-byte chunks are stored XOR-swizzled
+// LDS (128 KiB): [A0 A1 B0 B1][parity 2][128 rows][128 B].  A row's eight 16-byte chunks are stored XOR-swizzled
 //   (physical chunk = logical chunk ^ ((row >> 1) & 7)): every 16-lane group of a ds_read_b128 then touches 16
 //   different bank quads.  The DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address;
 //   the eight lanes of a row still read one whole 128-byte line.
@@ -24,6 +24,8 @@
 //   [MFMA segment] barrier; wave group 1 (waves 4-7, one per SIMD like group 0) runs one barrier behind group 0.
 //   RAW: the wait that retires a half-tile sits before the barrier that ends the phase BEFORE the one that reads it
 //   (for both groups); WAR: see the schedule table in DESIGN.md section 3.
+#include <type_traits>
+
 #include "common.h"
 #include "igemm_params.h"
 
@@ -32,16 +34,12 @@ namespace {
 constexpr int NT8 = 512;
 constexpr int ROWB = 128;              // bytes per LDS row = one K-tile of one row
 constexpr int HALF = 128 * ROWB;       // one half-tile slot (16 KiB)
-constexpr int PBUF = 4 * HALF;         // the four half-tiles of one K-tile parity
-constexpr int O_A0 = 0, O_A1 = HALF, O_B0 = 2 * HALF, O_B1 = 3 * HALF;
-constexpr int LDS8 = 2 * PBUF;         // 128 KiB
+constexpr int LDS8 = 8 * HALF;         // 128 KiB: A slots in the first 64 KiB, B slots in the second (ds_read offsets are 16 bit)
+__host__ __device__ constexpr int slot_a(int i, int par) { return (i * 2 + par) * HALF; }
+__host__ __device__ constexpr int slot_b(int j, int par) { return 4 * HALF + (j * 2 + par) * HALF; }
 constexpr unsigned OOB = 0x80000000u;  // >= num_records of every operand (operands are < 2 GiB): the DMA writes zeros
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-__device__ __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-}
 
 // scalar (wave-uniform) position of a K-tile inside the (r, s, c) loop of the implicit GEMM
 struct KPos {
@@ -136,24 +134,26 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   int ta0 = 0, ta1 = 0, tb0 = 0, tb1 = 0;   // tile index (relative to kt0) of the next A0 / A1 / B0 / B1 issue
 
   unsigned char* const wbase = smem + wave * 1024;
+  // `live` = the tile exists (tiles past the end of K are still "issued", with every lane out of range: the DMA
+  // writes zeros into a dead slot and the vmcnt bookkeeping stays uniform).  Pure data flow, no branches.
   auto issue_A = [&](int i, int par, const KPos& s, bool live) {
+    const unsigned dead = live ? 0u : OOB;
 #pragma unroll
     for (int u = 0; u < (i == 1 ? CA1 : 2); ++u) {
       const int r = i * 2 + u;
       const int hi = a_hi0[r] + s.dh, wi = a_wi0[r] + s.dw;
-      const bool ok = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      const unsigned off = ok ? a_off[r] + s.uni : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(wbase + par * PBUF + (i ? O_A1 : O_A0) + u * 8192), 16,
-                                               off, 0, 0, 0);
+      const bool ok = ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+      const unsigned off = (ok ? a_off[r] + s.uni : OOB) | dead;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(wbase + slot_a(i, par) + u * 8192), 16, off, 0, 0, 0);
     }
   };
   auto issue_B = [&](int j, int par, int tile, bool live) {
+    const unsigned dead = live ? 0u : OOB;
     const unsigned kb = (unsigned)((kt0 + tile) * 128);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const unsigned off = live ? b_off[j * 2 + u] + kb : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wbase + par * PBUF + (j ? O_B1 : O_B0) + u * 8192), 16,
-                                               off, 0, 0, 0);
+      const unsigned off = (b_off[j * 2 + u] + kb) | dead;       // b_off = OOB for rows past Cout: stays out of range
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wbase + slot_b(j, par) + u * 8192), 16, off, 0, 0, 0);
     }
   };
 
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     const unsigned ch = (unsigned)(((ks * 2 + (lane >> 5)) ^ ((l31 >> 1) & 7)) * 16);
     a_rd[ks] = (unsigned)((wr * 64 + l31) * ROWB) + ch;
     a1_rd[ks] = (unsigned)((wr * WROWS1 + l31) * ROWB) + ch;
-    b_rd[ks] = (unsigned)((wc * 32 + l31) * ROWB) + ch;
+    b_rd[ks] = (unsigned)(4 * HALF + (wc * 32 + l31) * ROWB) + ch;   // B slots start at 64 KiB: base in the register
   }
 
   f32x16_t acc[2][2][2];               // [A half i][M fragment f][B half j]
@@ -179,16 +179,26 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][f][j][r] = 0.f;
 
-  uint4 af[2][4], b0f[4], b1f[4];
-  auto ld = [&](unsigned off) { return *reinterpret_cast<const uint4*>(smem + off); };
-
+  // Fragment reads are inline asm: hipcc would otherwise protect every ds_read that follows an LDS-DMA with
+  // `s_waitcnt vmcnt(0)` (it cannot tell the slots apart), which serialises the whole pipeline.  The compiler does
+  // not know these are asynchronous, so each batch is followed (after the barrier) by an explicit lgkmcnt(0) and a
+  // scheduling barrier before the first MFMA that consumes it.
+  u32x4_t af[2][4], b0f[4], b1f[4];
+#define MEGA_LDS_RD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 #define MEGA_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define MEGA_WAIT_LDS()                                   \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);                    \
+  } while (0)
 #define MEGA_BAR()                    \
   do {                                \
     asm volatile("" ::: "memory");   \
     __builtin_amdgcn_s_barrier();     \
     asm volatile("" ::: "memory");   \
   } while (0)
+#define MEGA_MMA(acc_, a_, b_) \
+  acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a_), __builtin_bit_cast(bf16x8_t, b_), acc_, 0, 0, 0)
   constexpr int VMW = 6 + CA1;         // loads that may stay in flight at the end of a load segment (see header)
 
   // ---- prologue: six half-tiles
@@ -202,72 +212,82 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   MEGA_BAR();
   if (wr == 1) MEGA_BAR();             // group 1 runs one barrier behind group 0
 
+  auto tile_phases = [&](auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    // ================= phase 0: (A0, B0)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      MEGA_LDS_RD(af[0][ks], a_rd[ks], slot_a(0, par));
+      MEGA_LDS_RD(af[1][ks], a_rd[ks], slot_a(0, par) + 32 * ROWB);
+      MEGA_LDS_RD(b0f[ks], b_rd[ks], slot_b(0, par) - 4 * HALF);
+    }
+    issue_B(1, par ^ 1, tb1, tb1 < nkt); ++tb1;
+    MEGA_WAIT_VM(VMW);
+    MEGA_BAR();
+    MEGA_WAIT_LDS();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      MEGA_MMA(acc[0][0][0], af[0][ks], b0f[ks]);
+      MEGA_MMA(acc[0][1][0], af[1][ks], b0f[ks]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    MEGA_BAR();
+    // ================= phase 1: (A0, B1)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) MEGA_LDS_RD(b1f[ks], b_rd[ks], slot_b(1, par) - 4 * HALF);
+    issue_A(1, par ^ 1, pa1, ta1 < nkt); kpos_next(pa1); ++ta1;
+    MEGA_WAIT_VM(VMW);
+    MEGA_BAR();
+    MEGA_WAIT_LDS();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      MEGA_MMA(acc[0][0][1], af[0][ks], b1f[ks]);
+      MEGA_MMA(acc[0][1][1], af[1][ks], b1f[ks]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    MEGA_BAR();
+    // ================= phase 2: (A1, B1)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      MEGA_LDS_RD(af[0][ks], a1_rd[ks], slot_a(1, par));
+      if (MF1 == 2) MEGA_LDS_RD(af[1][ks], a1_rd[ks], slot_a(1, par) + 32 * ROWB);
+    }
+    issue_A(0, par, pa0, ta0 < nkt); kpos_next(pa0); ++ta0;
+    MEGA_BAR();
+    MEGA_WAIT_LDS();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      MEGA_MMA(acc[1][0][1], af[0][ks], b1f[ks]);
+      if (MF1 == 2) MEGA_MMA(acc[1][1][1], af[1][ks], b1f[ks]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    MEGA_BAR();
+    // ================= phase 3: (A1, B0)  -- both operands are still in registers
+    issue_B(0, par, tb0, tb0 < nkt); ++tb0;
+    MEGA_WAIT_VM(VMW);
+    MEGA_BAR();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      MEGA_MMA(acc[1][0][0], af[0][ks], b0f[ks]);
+      if (MF1 == 2) MEGA_MMA(acc[1][1][0], af[1][ks], b0f[ks]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    MEGA_BAR();
+  };
+
   const int nkt2 = (nkt + 1) & ~1;     // an odd tail tile is computed on all-zero operands (its DMAs are out of range)
   for (int t = 0; t < nkt2; t += 2) {
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const unsigned base = (unsigned)(par * PBUF);
-      // ================= phase 0: (A0, B0)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        af[0][ks] = ld(base + O_A0 + a_rd[ks]);
-        af[1][ks] = ld(base + O_A0 + 32 * ROWB + a_rd[ks]);
-        b0f[ks] = ld(base + O_B0 + b_rd[ks]);
-      }
-      issue_B(1, par ^ 1, tb1, tb1 < nkt); ++tb1;
-      MEGA_WAIT_VM(VMW);
-      MEGA_BAR();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        mma(acc[0][0][0], af[0][ks], b0f[ks]);
-        mma(acc[0][1][0], af[1][ks], b0f[ks]);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      MEGA_BAR();
-      // ================= phase 1: (A0, B1)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) b1f[ks] = ld(base + O_B1 + b_rd[ks]);
-      issue_A(1, par ^ 1, pa1, ta1 < nkt); kpos_next(pa1); ++ta1;
-      MEGA_WAIT_VM(VMW);
-      MEGA_BAR();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        mma(acc[0][0][1], af[0][ks], b1f[ks]);
-        mma(acc[0][1][1], af[1][ks], b1f[ks]);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      MEGA_BAR();
-      // ================= phase 2: (A1, B1)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        af[0][ks] = ld(base + O_A1 + a1_rd[ks]);
-        if (MF1 == 2) af[1][ks] = ld(base + O_A1 + 32 * ROWB + a1_rd[ks]);
-      }
-      issue_A(0, par, pa0, ta0 < nkt); kpos_next(pa0); ++ta0;
-      MEGA_BAR();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        mma(acc[1][0][1], af[0][ks], b1f[ks]);
-        if (MF1 == 2) mma(acc[1][1][1], af[1][ks], b1f[ks]);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      MEGA_BAR();
-      // ================= phase 3: (A1, B0)  -- both operands are still in registers
-      issue_B(0, par, tb0, tb0 < nkt); ++tb0;
-      MEGA_WAIT_VM(VMW);
-      MEGA_BAR();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        mma(acc[1][0][0], af[0][ks], b0f[ks]);
-        if (MF1 == 2) mma(acc[1][1][0], af[1][ks], b0f[ks]);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      MEGA_BAR();
-    }
+    tile_phases(std::integral_constant<int, 0>{});
+    tile_phases(std::integral_constant<int, 1>{});
   }
   if (wr == 0) MEGA_BAR();             // group 0 waits for group 1's last MFMA segment
   MEGA_WAIT_VM(0);                     // the out-of-range tail DMAs also write (zeros) into the LDS re-used below
@@ -294,10 +314,27 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     sc[j] = (p.ksplit == 1 && p.scale && n < p.Cout) ? p.scale[n] : 1.f;
     bi[j] = (p.ksplit == 1 && p.bias && n < p.Cout) ? p.bias[n] : 0.f;
   }
+  // The residual rows are fetched at the START of each slab pass (before the accumulators go through LDS), so the HBM
+  // latency of these loads overlaps the staging instead of sitting, four dependent loads per thread, in the read-out
+  // loop (the 1x1 "conv3 + residual" layers are HBM-bound: their epilogue is most of their time).
+  constexpr int NIT = 64 * VPR / NT8;                  // 16-byte output vectors per thread per slab (4 bf16 / 8 f32)
+  const bool res_vec = res != nullptr && vec_ok && sizeof(OT) == 2 && p.ksplit == 1;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int f = 0; f < (i == 1 ? MF1 : 2); ++f) {
+      const int wrows = i == 1 ? WROWS1 : 64;          // rows per wave row inside this A half
+      uint4 rres[NIT];
+      if (res_vec) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int e = tid + it * NT8;
+          const int row = e / VPR, cv = e - row * VPR;
+          const int m = m0 + i * 128 + (row >> 5) * wrows + f * 32 + (row & 31), n = n0 + cv * OVE;
+          rres[it] = make_uint4(0, 0, 0, 0);
+          if (m < p.M && n + OVE <= p.Cout) rres[it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
+        }
+      }
       if (i + f > 0) __syncthreads();                  // the previous slab has been read out
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -307,7 +344,6 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
         for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][f][j][r] * sc[j] + bi[j];
       }
       __syncthreads();
-      const int wrows = i == 1 ? WROWS1 : 64;          // rows per wave row inside this A half
       if (p.ksplit > 1) {                              // raw partial sums; splitk_finalize_kernel (igemm.hip) finishes
         float* part = p.partial + (size_t)blockIdx.z * p.M * p.Cout;
         for (int e = tid; e < 64 * (BN / 4); e += NT8) {
@@ -324,7 +360,9 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
         }
         continue;
       }
-      for (int e = tid; e < 64 * VPR; e += NT8) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * NT8;
         const int row = e / VPR, cv = e - row * VPR;
         const int m = m0 + i * 128 + (row >> 5) * wrows + f * 32 + (row & 31), n = n0 + cv * OVE;
         if (m >= p.M || n >= p.Cout) continue;
@@ -335,11 +373,12 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
           v[t] = q4.x; v[t + 1] = q4.y; v[t + 2] = q4.z; v[t + 3] = q4.w;
         }
         if (vec_ok && n + OVE <= p.Cout) {
-          if (res) {
-            const uint4 rr = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
-            const bf16_t* re = reinterpret_cast<const bf16_t*>(&rr);
+          if (res_vec) {
+            const bf16_t* re = reinterpret_cast<const bf16_t*>(&rres[it]);
 #pragma unroll
             for (int t = 0; t < OVE; ++t) v[t] += bf16_to_f32(re[t]);
+          } else if (res) {
+            for (int t = 0; t < OVE; ++t) v[t] += bf16_to_f32(res[(size_t)m * p.ldr + n + t]);
           }
           uint4 o;
           OT* oe = reinterpret_cast<OT*>(&o);
@@ -356,8 +395,11 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
       }
     }
   }
+#undef MEGA_LDS_RD
 #undef MEGA_WAIT_VM
+#undef MEGA_WAIT_LDS
 #undef MEGA_BAR
+#undef MEGA_MMA
 }
 
 template <typename OT, int MF1>

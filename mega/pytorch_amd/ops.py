@@ -88,6 +88,13 @@ def _pe(tok):
 
 
 # ------------------------------------------------------------------------------------------------ conv / linear
+def _igemm_family(lib, M, Cout, K, dtype):
+    """name of the kernel instantiation a conv / linear of this GEMM shape is dispatched to (profiler families)"""
+    t = lib.mega_conv2d_nhwc_plan(M, Cout, K, _DT[dtype])
+    kind, t = t // 1000000, t % 1000000
+    return "igemm%s_%s_%dx%d" % ("8" if kind == 8 else "", "bf16" if dtype == torch.bfloat16 else "f32", t // 1000, t % 1000)
+
+
 def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,
                 out=None):
     """x [N,H,W,Cin] (contiguous), w [Cout,R,S,Cin] -> [N,Ho,Wo,Cout].  y = act(conv*scale + bias (+res));
@@ -110,8 +117,7 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
     _tok = None
     if _PROF is not None:      # family = the kernel symbol rocprofv3 would report for this launch
-        t = lib.mega_conv2d_nhwc_tile(N * Ho * Wo, Cout, R * S * Cin)
-        _tok = _pb("igemm_%s_%dx%d" % ("bf16" if x.dtype == torch.bfloat16 else "f32", t // 1000, t % 1000),
+        _tok = _pb(_igemm_family(lib, N * Ho * Wo, Cout, R * S * Cin, x.dtype),
                    2.0 * N * Ho * Wo * Cout * R * S * Cin,
                    x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size())
     nb = lib.mega_conv2d_nhwc_workspace_bytes(N * Ho * Wo, Cout, R * S * Cin)     # > 0: long-K layer, split-K
@@ -373,8 +379,7 @@ def linear_transposed(w, x, ld):
     out = torch.zeros((Nout, ld), dtype=x.dtype, device=x.device)
     _tok = None
     if _PROF is not None:
-        t = lib.mega_conv2d_nhwc_tile(Nout, M, K)
-        _tok = _pb("igemm_%s_%dx%d" % ("bf16" if x.dtype == torch.bfloat16 else "f32", t // 1000, t % 1000),
+        _tok = _pb(_igemm_family(lib, Nout, M, K, x.dtype),
                    2.0 * Nout * M * K, (w.numel() + x.numel() + out.numel()) * x.element_size())
     rc = lib.mega_conv2d_nhwc(_ptr(w), _ptr(x), None, None, None, _ptr(out), Nout, 1, 1, K, M, 1, 1, 1, 0, 1, 0, ld,
                               ld, _dt(x), _dt(x), _stream())

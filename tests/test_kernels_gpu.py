@@ -564,3 +564,24 @@ def test_rpn_conv_natural_dispatch_hot_shape(dev):
     for f in (0, 7, Nf - 1):
         one = ops.conv2d_nhwc(xd[f:f + 1].contiguous(), wd, None, bd, pad=1, relu=True)
         assert torch.equal(one[0], out[f]), "frame %d differs between batch-of-1 and batch-of-%d dispatch" % (f, Nf)
+
+
+def test_igemm8_bit_equal_to_register_staged_tiles(dev):
+    """igemm8 (LDS-DMA staging, 8 waves, 256/192 x 256 tiles, the kernel the big frame-stage layers are dispatched to)
+    must give the SAME BITS as the register-staged igemm tiles on every shape class: same MFMA instruction, same
+    ascending-K order per output element -> tile / kernel choice never changes a result (batch invariance).  Each case
+    runs several times (race screen)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "igemm8_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu",
+                                     "igemm8_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    for case in chk.CASES:
+        ref = chk.run(case, "128x128")[0]
+        for force in ("8:256", "8:192"):
+            outs = chk.run(case, force, reps=3)
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), "%s %s: run-to-run difference" % (case, force)
+            assert torch.equal(outs[0], ref), "%s %s: differs from the 128x128 tile (max |d| %.3g)" % (
+                case, force, (outs[0].float() - ref.float()).abs().max().item())
