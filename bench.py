@@ -70,8 +70,9 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true", help="launch the frame stage kernel by kernel (no hipGraph)")
     ap.add_argument("--reuse-records", action="store_true",
                     help="compute each frame's record once per video (engine option; NOT the headline configuration)")
-    ap.add_argument("--no-static-aggregation", action="store_true",
-                    help="step the aggregation eagerly (~80 launches per key frame) instead of replaying one hipGraph")
+    ap.add_argument("--aggregation", default="batched", choices=["batched", "static", "per-frame"],
+                    help="batched (default): the aggregation of a step-batch runs stage by stage over all its key "
+                         "frames; static: one hipGraph replay per key frame on fixed-address pools; per-frame: eager steps")
     ap.add_argument("--cpu-frames", type=int, default=3, help="steady key frames timed by the CPU baseline (memory full)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed blocks cover at least this long")
     ap.add_argument("--max-blocks", type=int, default=60)
@@ -180,7 +181,8 @@ def main():
     gfor = eng.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
     runner = eng.ClipEngine(model, steps_per_batch=spb, dist_group=group, overlap=not args.no_overlap,
                             graphs=not args.no_graphs, reuse_records=args.reuse_records,
-                            static_aggregation=not args.no_static_aggregation)
+                            static_aggregation=args.aggregation == "static",
+                            batch_aggregation=args.aggregation == "batched")
 
     def barrier():
         torch.cuda.synchronize()
@@ -350,7 +352,7 @@ def main():
                                    % (args.arch, args.width, args.height, "" if world == 1 else " sharded = configs[3]"),
                        "steps_per_batch": args.steps_per_batch, "parallelism": "frame-sharded x%d" % world,
                        "frame_record_reuse": bool(args.reuse_records),
-                       "static_aggregation": not args.no_static_aggregation,
+                       "aggregation": args.aggregation,
                        "pre_roll_key_frames": Wm, "pools_full": bool(st0["pools_full"] and st1["pools_full"]),
                        "graph_captures_in_timed_region": captures_in_region,
                        "engine_state_before": st0, "engine_state_after": st1,

@@ -54,9 +54,57 @@ class _On(object):
             self.c.__exit__(*a)
 
 
+class KeyFrameShard(object):
+    """Multi-GPU form of the batched aggregation (MEGAFeatureExtractor.aggregate_batch): the key frames of a
+    step-batch are dealt round-robin to the ranks (owner(t) = t mod world).  What crosses ranks: per stage, the memory
+    entries (75 / 15 / 15 feature rows) of every key frame of the batch -- one all-gather each -- and at the end the
+    padded detections.  Nothing of the per-key-frame step is replicated any more."""
+
+    def __init__(self, dist, group, rank, world):
+        self.dist, self.group, self.rank, self.world = dist, group, rank, world
+
+    def owner(self, t):
+        return t % self.world
+
+    def gather_rows(self, own, nrows, like):
+        """own {t: [n_t, D] rows of my key frames}, nrows[t] for ALL key frames -> list of [n_t, D] for all of them."""
+        S, W = len(nrows), self.world
+        per, R, D = (S + W - 1) // W, max(max(nrows), 1), like.shape[1]
+        buf = like.new_zeros((per, R, D))
+        for t, x in own.items():
+            buf[t // W, :x.shape[0]] = x
+        out = like.new_empty((W * per, R, D))
+        self.dist.all_gather_into_tensor(out, buf, group=self.group)
+        return [out[(t % W) * per + t // W, :nrows[t]] for t in range(S)]
+
+    def gather_detections(self, outs, S, max_det, device):
+        """outs[t] = PostProcessor.run output of my key frames (None elsewhere) -> the same for all S key frames.
+        A frame travels as [cap2 + 1, 6] f32 rows (box, score, label; last row = count), cap2 = 2 * DETECTIONS_PER_IMG
+        (the reference's cut keeps at most DETECTIONS_PER_IMG plus score ties, box_head/inference.py:139-148)."""
+        W = self.world
+        per, cap2 = (S + W - 1) // W, 2 * max_det
+        buf = torch.zeros((per, cap2 + 1, 6), dtype=torch.float32, device=device)
+        for t, o in enumerate(outs):
+            if o is None:
+                continue
+            ob, os_, ol, oc = o[:4]
+            n = min(cap2, ob.shape[0])
+            buf[t // W, :n, :4] = ob[:n]
+            buf[t // W, :n, 4] = os_[:n]
+            buf[t // W, :n, 5] = ol[:n].float()
+            buf[t // W, cap2, 0] = oc.float().clamp(max=cap2)[0]
+        out = torch.empty((W * per, cap2 + 1, 6), dtype=torch.float32, device=device)
+        self.dist.all_gather_into_tensor(out, buf, group=self.group)
+        res = []
+        for t in range(S):
+            r = out[(t % W) * per + t // W]
+            res.append((r[:cap2, :4], r[:cap2, 4], r[:cap2, 5].long(), r[cap2, 0:1].int()))
+        return res
+
+
 class ClipEngine(object):
     def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True, graphs=True, reuse_records=False,
-                 static_aggregation=False, keep_logits=False):
+                 static_aggregation=False, keep_logits=False, batch_aggregation=True):
         """steps_per_batch: key-frame steps whose frame jobs are computed in one frame-stage batch
         (steady state: 2 frames per step).  dist_group: torch.distributed group to shard the frame stage over
         (None = single process).  overlap: use the two-stream pipeline (see module docstring).
@@ -88,6 +136,10 @@ class ClipEngine(object):
         # experimental, opt-in: steady-state aggregation steps on fixed-address pools, replayed from one hipGraph
         self._static = StaticAggregation(model, use_graph=graphs) if static_aggregation else None
         self.use_static = True            # False: step eagerly even when a StaticAggregation exists (instrumented passes)
+        # batch_aggregation: the aggregation of all key frames of a step-batch runs stage by stage over the whole batch
+        # (model.step_batch: projections / stage FCs as one GEMM each); off = one model.step() per key frame
+        fe = getattr(getattr(getattr(model, "roi_heads", None), "box", None), "feature_extractor", None)
+        self.batch_aggregation = batch_aggregation and hasattr(fe, "aggregate_batch")      # (RDN: per-frame steps)
         self.keep_logits = keep_logits    # tests: logits_log[i] = predictor class logits of the i-th key frame stepped
         self.logits_log = []
         self.key_boxes_log = []           # and the key frame's proposal boxes (rows of logits_log[i])
@@ -193,27 +245,48 @@ class ClipEngine(object):
     def records_async(self, clip, jobs):
         """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
         records_resolve()."""
-        m = self.model
         if self.world == 1 and not self.force_sharded:
             return {"st": self._frame_stage(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs])}
-        # ---- sharded: contiguous slices of the (padded) job list per rank, fixed-size records, one all-gather each
-        n = len(jobs)
-        per = (n + self.world - 1) // self.world
-        padded = jobs + [jobs[-1]] * (per * self.world - n)
-        mine = padded[self.rank * per:(self.rank + 1) * per]
-        st = self._frame_stage(self._frames(clip, [j[0] for j in mine]), [j[1] for j in mine])
-        K, dev = m.key_num, st["props"].device
-        feats = torch.zeros((per, K, st["feats"].shape[1]), dtype=st["feats"].dtype, device=dev)
-        o = 0
-        for i, w in enumerate(st["want"]):
-            feats[i, :w] = st["feats"][o:o + w]
-            o += w
-        g = {}
-        for name, t in (("props", st["props"]), ("scores", st["scores"]), ("feats", feats), ("cnt", st["cnt"])):
-            out = torch.empty((self.world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-            self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-            g[name] = out
-        g["want"] = [j[1] for j in jobs]
+        # ---- sharded.  Jobs are grouped by their row count (local-window frames: key_num rows, global-pool frames:
+        # base_num rows -- a global frame's record is 4x smaller on the wire); each group is dealt to the ranks in
+        # contiguous slices (padded by repeating its last job); a rank runs ONE frame-stage launch over its slices of
+        # all groups and the records of a group travel in ONE all-gather of a packed byte buffer
+        # [boxes+score f32 | feats | count], fixed size per frame.
+        groups = {}
+        for pos, j in enumerate(jobs):
+            groups.setdefault(int(j[1]), []).append(pos)
+        plan, mine_ids, mine_want = [], [], []
+        for want, poss in sorted(groups.items(), reverse=True):
+            per = (len(poss) + self.world - 1) // self.world
+            padded = poss + [poss[-1]] * (per * self.world - len(poss))
+            sl = padded[self.rank * per:(self.rank + 1) * per]
+            plan.append((want, poss, per, len(mine_ids)))
+            mine_ids += [jobs[p][0] for p in sl]
+            mine_want += [want] * per
+        st = self._frame_stage(self._frames(clip, mine_ids), mine_want)
+        dev, D, fdt = st["props"].device, st["feats"].shape[1], st["feats"].dtype
+        esz = st["feats"].element_size()
+        got = {}
+        row_off = 0
+        for want, poss, per, first in plan:
+            nb_box, nb_feat = want * 5 * 4, want * D * esz
+            rec_bytes = (nb_box + nb_feat + 16 + 15) // 16 * 16
+            buf = torch.zeros((per, rec_bytes), dtype=torch.uint8, device=dev)
+            bs = torch.cat([st["props"][first:first + per, :want], st["scores"][first:first + per, :want, None]], dim=2)
+            buf[:, :nb_box] = bs.contiguous().view(per, -1).view(torch.uint8)
+            feats = st["feats"][row_off:row_off + per * want].reshape(per, want * D)
+            buf[:, nb_box:nb_box + nb_feat] = feats.contiguous().view(torch.uint8)
+            buf[:, nb_box + nb_feat:nb_box + nb_feat + 4] = st["cnt"][first:first + per].contiguous().view(per, 1).view(torch.uint8)
+            row_off += per * want
+            out = torch.empty((self.world * per, rec_bytes), dtype=torch.uint8, device=dev)
+            self.dist.all_gather_into_tensor(out, buf, group=self.group)
+            bs_all = out[:, :nb_box].contiguous().view(torch.float32).view(-1, want, 5)
+            f_all = out[:, nb_box:nb_box + nb_feat].contiguous().view(fdt).view(-1, want, D)
+            c_all = out[:, nb_box + nb_feat:nb_box + nb_feat + 4].contiguous().view(torch.int32).view(-1)
+            for slot, pos in enumerate(poss):
+                got[pos] = (bs_all[slot, :, :4], bs_all[slot, :, 4], f_all[slot], c_all[slot:slot + 1])
+        order = [got[p] for p in range(len(jobs))]
+        g = {"recs": order, "cnt": torch.cat([r[3] for r in order]), "want": [int(j[1]) for j in jobs]}
         return {"gathered": g}
 
     @staticmethod
@@ -231,7 +304,8 @@ class ClipEngine(object):
         out = []
         for i, w in enumerate(g["want"]):
             n = min(int(counts[i]), w)
-            out.append({"boxes": g["props"][i, :n], "scores": g["scores"][i, :n], "feats": g["feats"][i, :n]})
+            boxes, scores, feats, _ = g["recs"][i]
+            out.append({"boxes": boxes[:n], "scores": scores[:n], "feats": feats[:n]})
         return out
 
     def compute_records(self, clip, jobs):
@@ -351,6 +425,26 @@ class ClipEngine(object):
                         for t in r.values():
                             t.record_stream(sB)
                 pending, o = [], 0
+                batched = (self.batch_aggregation and (self._static is None or not self.use_static)
+                           and m.roi_heads.box.feature_extractor.cache_memory_kv)
+                if batched and self._static is not None:
+                    self._static.leave()          # the pools go back into the model's deques
+                prepared = []                     # (key frame index, snapshot) of the steps awaiting step_batch()
+
+                def flush():
+                    if not prepared:
+                        return
+                    shard = None
+                    if self.world > 1 or self.force_sharded:
+                        shard = KeyFrameShard(self.dist, self.group, self.rank, self.world)
+                    outs = m.step_batch([f for _, f in prepared], (W, H), shard)
+                    for (i2, f), pd in zip(prepared, outs):
+                        pending.append((i2, pd))
+                    if self.keep_logits:     # (sharded: only this rank's own key frames have logits here)
+                        self.logits_log += [None if x is None else x.float().clone() for x in m.last_logits_batch]
+                        self.key_boxes_log += [f["rois_key"].clone() for _, f in prepared]
+                    del prepared[:]
+
                 for i, js in zip(range(b[0], b[1]), per_step):
                     if self.reuse_records:
                         r = [self._rec_cache[j[0]] for j in js]
@@ -367,10 +461,15 @@ class ClipEngine(object):
                             m.records.append(loc[0])
                         for x in loc[1:]:
                             m.records.append(x)
+                        if batched:
+                            prepared.append((i, m.prepare_step(None, glob)))
+                            continue
                         pending.append((i, m.step(None, glob, (W, H), defer=True)))
                         if self.keep_logits:
                             self.logits_log.append(m.last_logits.float().clone())
                             self.key_boxes_log.append(m.records[m.key_frame_location]["boxes"].clone())
+                    elif batched:
+                        prepared.append((i, m.prepare_step(loc[0], glob)))
                     elif self._static is not None and self.use_static and self._static.ready(loc[0], glob):
                         pending.append((i, self._static.step(loc[0], glob, (W, H))))
                         self.static_steps += 1
@@ -384,6 +483,7 @@ class ClipEngine(object):
                         if self.keep_logits:
                             self.logits_log.append(m.last_logits.float().clone())
                             self.key_boxes_log.append(m.records[m.key_frame_location]["boxes"].clone())
+                flush()
                 if use_streams:   # detection counts of the whole batch -> pinned host memory, async + event
                     dc = torch.cat([pd[3] for _, pd in pending])
                     host = torch.empty(dc.shape, dtype=dc.dtype).pin_memory()

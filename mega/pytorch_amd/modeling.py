@@ -21,7 +21,8 @@ import torch
 from torch import nn
 
 from . import ops
-from .relation import RelationWeights, relation_attention_forward
+from .relation import (RelationWeights, relation_attend, relation_attention_forward,
+                       relation_project_batched)
 from .structures import BoxList, cat_boxlist, to_image_list
 from .synth import _cell_anchors
 
@@ -488,6 +489,15 @@ class MEGAFeatureExtractor(_Packed):
         self.mem[i]["k"] = torch.cat(list(q["k"]), dim=0)
         self.mem[i]["vt"] = torch.cat(list(q["vt"]), dim=1)
 
+    def _push_memory(self, i, rois_n, k_n, vt_n):
+        """update_memory + _remember_kv for rows that are already cut to this stage's entry size."""
+        q = self.mem_queue_list[i]
+        q["rois"].append(rois_n)
+        q["k"].append(k_n)
+        q["vt"].append(vt_n.contiguous())
+        self.mem[i] = {"rois": torch.cat(list(q["rois"]), dim=0), "k": torch.cat(list(q["k"]), dim=0),
+                       "vt": torch.cat(list(q["vt"]), dim=1)}
+
     def update_lm(self, feats, i=0):
         pk = self._packed(feats.dtype, feats.device)
         return relation_attention_forward(pk["global"][i], feats, self.global_cache[-1]["feats"], residual=True)
@@ -554,6 +564,108 @@ class MEGAFeatureExtractor(_Packed):
         for i in range(self.global_res_stage):
             x = self.update_lm(x.contiguous(), i + 1)
         return x
+
+    # ---- aggregation of SEVERAL consecutive key frames at once (engine batches)
+    def _update_lm_batched(self, xs, globs, i=0):
+        """update_lm (:690-699) for several key frames: xs[t] attends to globs[t] (that step's global pool)."""
+        pk = self._packed(xs[0].dtype, xs[0].device)
+        w = pk["global"][i]
+        qs, ks, vts = relation_project_batched(w, xs, globs)
+        return [relation_attend(w, xs[t], qs[t], ks[t], vts[t]) for t in range(len(xs))]
+
+    def aggregate_batch(self, frames, shard=None):
+        """aggregate() for a list of consecutive key frames (oldest first), each a dict with the arguments of aggregate():
+        x, rois_key, rois, rois_dis, x_ref, dis_index, and "glob" = the global pool [Ng,1024] of THAT step (or None).
+        Returns the list of box-head outputs x [nk,1024] (entries of frames another rank owns are None).
+
+        Why this is legal: the per-video state looks sequential (memory pools), but stage i of key frame t only
+        depends on stage i-1 of key frames <= t -- what a step pushes into memory[i] are its stage-(i-1) OUTPUT rows
+        of the oldest window frame (update_memory :678-688 is called before the attention, :914-917), never its own
+        stage-i output.  The dependency depth is the number of stages, not the number of frames.  So the batch is
+        processed stage by stage: the Wq / Wk / Wv projections and the stage FCs of all its frames run as ONE GEMM each
+        (M = S x 675 ... S x 1875 rows instead of 64x64-tile launches at 4 % of the MFMA peak), only the attention core
+        and the memory bookkeeping (read-before-push, in frame order) run per frame.  All kernels are batch-invariant,
+        so every frame's result has the same bits as aggregate()'s (tests: engine == reference call convention).
+
+        shard (engine.KeyFrameShard, multi-GPU): the key frames of the batch are dealt round-robin to the ranks; a
+        rank runs the stages only for its own frames.  What other frames need from a frame are its memory entries
+        (75 / 15 / 15 rows): they are all-gathered once per stage (3 small collectives per BATCH), their Wk / Wv
+        projections recomputed by every rank (one tiny GEMM pair per stage), and every rank replays all pushes in
+        frame order, so the memory pools stay replicated.  No key frame is aggregated twice: the step no longer has a
+        serial (replicated) part."""
+        assert self.cache_memory_kv and self.static_pools is None
+        pk = self._packed(frames[0]["x"].dtype, frames[0]["x"].device)
+        S = len(frames)
+        own = [t for t in range(S) if shard is None or shard.owner(t) == shard.rank]
+        nkey = [f["x"].shape[0] for f in frames]
+        nl = [f["x_ref"].shape[0] for f in frames]
+        xs, x_refs = {}, {}
+        use_glob = self.global_enable and frames[0].get("glob") is not None
+        if use_glob and own:                                                     # :757-760
+            z = self._update_lm_batched([torch.cat([frames[t]["x"], frames[t]["x_ref"]], dim=0) for t in own],
+                                        [frames[t]["glob"] for t in own])
+            for j, t in enumerate(own):
+                xs[t], x_refs[t] = z[j][:nkey[t]], z[j][nkey[t]:nkey[t] + nl[t]]
+        elif own:
+            for t in own:
+                xs[t], x_refs[t] = frames[t]["x"], frames[t]["x_ref"]
+        feats_cur = {t: torch.cat([xs[t], x_refs[t].index_select(0, frames[t]["dis_index"])], dim=0) for t in own}
+        feats_ref = x_refs
+        rois_cur01 = {t: torch.cat([frames[t]["rois_key"], frames[t]["rois_dis"]], dim=0) for t in own}
+        for i in range(self.stage):
+            last = i == self.stage - 1
+            w = pk["local"][i]
+            n_push = self.base_num if i == 0 else self.advanced_num
+            rois_ref = [f["rois"] if i == 0 else f["rois_dis"] for f in frames]
+            n_ent = [min(n_push, r.shape[0]) for r in rois_ref]           # rows of each frame's memory entry
+            qs, ks, vts = {}, {}, {}
+            if own:
+                q_, k_, v_ = relation_project_batched(w, [feats_cur[t].contiguous() for t in own],
+                                                      [feats_ref[t].contiguous() for t in own])
+                for j, t in enumerate(own):
+                    qs[t], ks[t], vts[t] = q_[j], k_[j], v_[j]
+            if shard is not None and self.memory_enable:
+                # memory entries of ALL frames: gather the entry rows, project them here (same bits as the owner's)
+                ent = shard.gather_rows({t: feats_ref[t][:n_ent[t]] for t in own}, n_ent, frames[0]["x"])
+                e_all = torch.cat(ent, dim=0)
+                ek_all = ops.linear(e_all, w.wk, w.bk)
+                evt_all = ops.linear_transposed(w.wv, e_all, (e_all.shape[0] + 31) // 32 * 32)
+            outs, o = {}, 0
+            for t in range(S):                                   # memory: read BEFORE this frame's push (:914-917)
+                if t in qs:
+                    memory = self.mem[i] if self.mem[i] else None
+                    rk, mem_kv = rois_ref[t], None
+                    if memory is not None:
+                        rk = torch.cat([rk, memory["rois"]], dim=0)
+                        mem_kv = (memory["k"], memory["vt"])
+                    rc = frames[t]["rois_key"] if last else rois_cur01[t]
+                    outs[t] = relation_attend(w, feats_cur[t], qs[t], ks[t], vts[t], rc.contiguous(), rk.contiguous(), mem_kv)
+                if self.memory_enable:
+                    n = n_ent[t]
+                    if shard is not None:
+                        self._push_memory(i, rois_ref[t][:n], ek_all[o:o + n], evt_all[:, o:o + n])
+                    else:
+                        self._push_memory(i, rois_ref[t][:n], ks[t][:n], vts[t][:, :n])
+                    o += n
+            if last:
+                xs = outs
+                break
+            feats_cur, feats_ref = {}, {}
+            if own:
+                ncur = [outs[t].shape[0] for t in own]
+                fc = ops.linear(torch.cat([outs[t] for t in own], dim=0), pk["fc_w"][i + 1], pk["fc_b"][i + 1], relu=True)
+                o = 0
+                for j, t in enumerate(own):
+                    nx = fc[o:o + ncur[j]]
+                    o += ncur[j]
+                    feats_cur[t] = nx[:nkey[t]] if i == self.stage - 2 else nx
+                    feats_ref[t] = nx[nkey[t]:]
+        for i in range(self.global_res_stage):                                   # :930-931
+            if own:
+                z = self._update_lm_batched([xs[t].contiguous() for t in own], [frames[t]["glob"] for t in own], i + 1)
+                for j, t in enumerate(own):
+                    xs[t] = z[j]
+        return [xs.get(t) for t in range(S)]
 
     # ---- reference call signatures
     def forward(self, x, proposals, pre_calculate=False, key_features=None):
@@ -798,6 +910,48 @@ class GeneralizedRCNNMEGA(nn.Module):
         if defer:
             return pp.run((logits, deltas), kb)
         return pp((logits, deltas), [kb])[0]
+
+    # ------------------------------------------------------------------ batched form of step() (ClipEngine)
+    def prepare_step(self, new_local=None, new_globals=()):
+        """First half of step(): advance the window / global pool by one key frame and snapshot the inputs of its
+        aggregation (no attention yet).  The snapshots of several consecutive key frames go to step_batch()."""
+        fe = self.roi_heads.box.feature_extractor
+        if new_local is not None:
+            self.records.append(new_local)
+        for g in new_globals:
+            fe.update_global(g["feats"][:self.base_num])
+        key = self.records[self.key_frame_location]
+        rois, rois_dis, x_ref, dis_index = self._window()
+        glob = fe.global_cache[-1].get("feats") if (self.global_enable and fe.global_cache) else None
+        return {"x": key["feats"], "rois_key": key["boxes"], "scores": key["scores"], "rois": rois,
+                "rois_dis": rois_dis, "x_ref": x_ref, "dis_index": dis_index, "glob": glob}
+
+    @torch.no_grad()
+    def step_batch(self, frames, im_size, shard=None):
+        """Aggregation + predictor + post-processing of the key frames prepared by prepare_step(), stage by stage over
+        the whole list (MEGAFeatureExtractor.aggregate_batch).  Returns one padded post-processing output per frame
+        (PostProcessor.run form: no host sync).  Same bits as calling step() once per frame.
+        shard: see aggregate_batch; the padded outputs of the frames other ranks own are all-gathered, so every rank
+        returns the outputs of ALL frames."""
+        fe = self.roi_heads.box.feature_extractor
+        xs = fe.aggregate_batch(frames, shard)
+        own = [t for t, x in enumerate(xs) if x is not None]
+        pp = self.roi_heads.box.post_processor
+        outs, self.last_logits_batch = [None] * len(frames), [None] * len(frames)
+        if own:
+            n = [xs[t].shape[0] for t in own]
+            logits, deltas = self.roi_heads.box.predictor(torch.cat([xs[t] for t in own], dim=0) if len(own) > 1
+                                                          else xs[own[0]].contiguous())
+            o = 0
+            for j, t in enumerate(own):
+                lg, dl = logits[o:o + n[j]], deltas[o:o + n[j]]
+                o += n[j]
+                self.last_logits_batch[t] = lg
+                outs[t] = pp.run((lg, dl), BoxList(frames[t]["rois_key"], im_size, "xyxy"))
+            self.last_logits = self.last_logits_batch[own[-1]]
+        if shard is not None:
+            outs = shard.gather_detections(outs, len(frames), pp.detections_per_img, frames[0]["rois_key"].device)
+        return outs
 
     def forward(self, images, targets=None):
         """Reference call convention (generalized_rcnn_mega.py:48-78, data/datasets/vid_mega.py:95-142):

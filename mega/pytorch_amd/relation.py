@@ -69,3 +69,52 @@ def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=Tru
         pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
     out = ops.relation_attention(q, k_all, vt_all, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
     return (out, k, vt) if return_kv else out
+
+
+def _cat(ts):
+    return ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
+
+
+def relation_project_batched(w, xs, refs):
+    """The Wq / Wk / Wv projections of several INDEPENDENT attention problems (the key frames of one engine batch) as
+    ONE GEMM each over the concatenated rows: M = sum of the rows, so the 64x64-tile launches of the per-frame form
+    become a few big-tile launches.  Every GEMM kernel is batch-invariant (an output row never depends on the rows it
+    is batched with), so the slices have the same bits as relation_attention_forward's own projections.
+    xs[i] [Nq_i,1024] queries, refs[i] [Nr_i,1024] keys/values -> (qs, ks, vts): qs[i] [Nq_i,1024], ks[i] [Nr_i,1024],
+    vts[i] [1024,Nr_i] (views into the batched results; a caller that keeps a slice must copy it)."""
+    nq = [x.shape[0] for x in xs]
+    nr = [r.shape[0] for r in refs]
+    r_all = _cat(refs)
+    k_all = ops.linear(r_all, w.wk, w.bk)
+    vt_all = ops.linear_transposed(w.wv, r_all, (r_all.shape[0] + 31) // 32 * 32)
+    q_all = ops.linear(_cat(xs), w.wq, w.bq)
+    qs, ks, vts = [], [], []
+    oq = orr = 0
+    for i in range(len(xs)):
+        qs.append(q_all[oq:oq + nq[i]])
+        ks.append(k_all[orr:orr + nr[i]])
+        vts.append(vt_all[:, orr:orr + nr[i]])
+        oq += nq[i]
+        orr += nr[i]
+    return qs, ks, vts
+
+
+def relation_attend(w, x, q, k, vt, rois_q=None, rois_k=None, mem_kv=None, residual=True):
+    """The attention core of one problem on already-projected operands (relation_project_batched): q [Nq,1024],
+    k [Nr,1024], vt [1024,Nr] (may be a strided view), mem_kv as in relation_attention_forward.  -> x + attention."""
+    Nk = k.shape[0]
+    vparts = [vt]
+    if mem_kv is not None:
+        k_mem, vt_mem = mem_kv
+        Nk += k_mem.shape[0]
+        k = torch.cat([k, k_mem], dim=0)
+        vparts.append(vt_mem)
+    ldv = (Nk + 31) // 32 * 32
+    if ldv > Nk:
+        vparts.append(vt.new_zeros((vt.shape[0], ldv - Nk)))
+    vv = torch.cat(vparts, dim=1) if len(vparts) > 1 else vt.contiguous()
+    pos = None
+    if w.with_pos:
+        fast = x.dtype != torch.float32
+        pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
+    return ops.relation_attention(q, k, vv, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)

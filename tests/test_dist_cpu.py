@@ -1,7 +1,11 @@
-"""CPU, world_size 2 over gloo: the frame-sharded ClipEngine (each rank computes a slice of every frame-stage
-batch, fixed-size frame records exchanged with ONE all-gather, aggregation replicated) must reproduce the
-single-process result.  The kernels are replaced by the oracle-backed CPU twins (tests/cpu_ops.py); on the
-GPU box the same code path runs over RCCL (backend "nccl") -- see bench.py --gpus N.
+"""CPU, world_size 2 and 4 over gloo: the sharded ClipEngine must reproduce the single-process result.
+
+What is sharded (mega/pytorch_amd/engine.py): (1) the frame stage -- each rank computes a slice of every frame-stage
+batch, the fixed-size frame records travel in one packed all-gather per row-count group; (2) the aggregation -- the
+key frames of a step-batch are dealt round-robin to the ranks (KeyFrameShard), the memory entries of every key
+frame are all-gathered once per stage and the padded detections at the end; nothing of the per-key-frame step is
+replicated.  The kernels are replaced by the oracle-backed CPU twins (tests/cpu_ops.py); on the GPU box the same
+code path runs over RCCL (backend "nccl") -- see bench.py --gpus N.
 """
 import os
 import sys
@@ -14,6 +18,7 @@ import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+T, NKEY = 22, 14
 
 
 def _install_cpu_ops():
@@ -26,16 +31,20 @@ def _install_cpu_ops():
 
 
 def _build():
+    """R-50 MEGA with a 7-frame window / memory and a 3-frame global pool: 14 key frames wrap every deque."""
     from mega.pytorch_amd import config, modeling, synth
     cfg = config.get_cfg("R-50")
     cfg.MODEL.DEVICE = "cpu"
+    cfg.merge_from_list(["MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 7, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 3,
+                         "MODEL.VID.MEGA.MIN_OFFSET", -3, "MODEL.VID.MEGA.MAX_OFFSET", 3, "MODEL.VID.MEGA.GLOBAL.SIZE", 3,
+                         "MODEL.RPN.POST_NMS_TOP_N_TEST", 40, "MODEL.VID.RPN.REF_POST_NMS_TOP_N", 10])
     model = modeling.build_detection_model(cfg)
     model.load_state_dict(synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5))
-    frames = synth.preprocess_cpu(synth.make_clip(16, 96, 128, seed=2))
+    frames = synth.preprocess_cpu(synth.make_clip(T, 96, 128, seed=2))
     return cfg, model, frames
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, spb):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -43,35 +52,46 @@ def _worker(rank, world, port, outdir):
     _install_cpu_ops()
     from mega.pytorch_amd import engine
     cfg, model, frames = _build()
-    gfor = engine.global_schedule(16, 10, seed=0)
-    eng = engine.ClipEngine(model, steps_per_batch=2, dist_group=dist.group.WORLD)
-    dets = eng.run(frames, 16, gfor, first=0, last=4)
-    torch.save([(d.bbox, d.get_field("scores"), d.get_field("labels")) for d in dets],
+    gfor = engine.global_schedule(T, 3, seed=0)
+    eng = engine.ClipEngine(model, steps_per_batch=spb, dist_group=dist.group.WORLD)
+    dets = eng.run(frames, T, gfor, first=0, last=NKEY)
+    fe = model.roi_heads.box.feature_extractor
+    torch.save({"dets": [(d.bbox, d.get_field("scores"), d.get_field("labels")) for d in dets],
+                "mem": [fe.mem[i]["k"].clone() for i in range(fe.stage)], "frames_computed": eng.frames_computed},
                os.path.join(outdir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_frame_sharded_engine_matches_single_process():
-    port = 29500 + os.getpid() % 2000
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,spb", [(2, 3), (4, 5)])
+def test_sharded_engine_matches_single_process(world, spb):
+    port = 29500 + (os.getpid() * 7 + world) % 2000
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
-        r0 = torch.load(os.path.join(d, "rank0.pt"))
-        r1 = torch.load(os.path.join(d, "rank1.pt"))
+        mp.spawn(_worker, args=(world, port, d, spb), nprocs=world, join=True)
+        ranks = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(world)]
     _install_cpu_ops()
     torch.set_num_threads(4)
     from mega.pytorch_amd import engine
     cfg, model, frames = _build()
-    single = engine.ClipEngine(model, steps_per_batch=2).run(frames, 16, engine.global_schedule(16, 10, seed=0),
-                                                            first=0, last=4)
-    assert len(r0) == len(r1) == len(single) == 4
-    for (b0, s0, l0), (b1, s1, l1), det in zip(r0, r1, single):
-        # replicated aggregation: every rank holds the same detections
-        assert torch.equal(l0, l1) and torch.allclose(b0, b1, atol=1e-4) and torch.allclose(s0, s1, atol=1e-6)
+    single_eng = engine.ClipEngine(model, steps_per_batch=spb)
+    single = single_eng.run(frames, T, engine.global_schedule(T, 3, seed=0), first=0, last=NKEY)
+    assert all(len(r["dets"]) == NKEY for r in ranks) and len(single) == NKEY
+    for k in range(NKEY):
+        b0, s0, l0 = ranks[0]["dets"][k]
+        n = len(single[k])
+        for r in ranks[1:]:                        # every rank returns the detections of ALL key frames, identical
+            b1, s1, l1 = r["dets"][k]
+            assert torch.equal(l0, l1) and torch.equal(b0, b1) and torch.equal(s0, s1)
         # and they equal the un-sharded run (CPU twins are not batch-invariant to the last bit: MKL)
-        assert torch.equal(l0, det.get_field("labels"))
-        assert (b0 - det.bbox).abs().max() < 5e-3 and (s0 - det.get_field("scores")).abs().max() < 1e-5
+        assert b0.shape[0] == n and torch.equal(l0, single[k].get_field("labels")), k
+        assert (b0 - single[k].bbox).abs().max() < 5e-3 and (s0 - single[k].get_field("scores")).abs().max() < 1e-5
+    # the memory pools stay replicated: same rows on every rank (every rank replays all pushes in frame order)
+    for r in ranks[1:]:
+        for a, b in zip(ranks[0]["mem"], r["mem"]):
+            assert a.shape == b.shape and (a.float() - b.float()).abs().max() < 1e-4
+    # frame-stage work is divided: a rank computes about 1/world of the frames
+    assert ranks[0]["frames_computed"] <= single_eng.frames_computed
 
 
 def test_job_schedule_matches_reference_feed():

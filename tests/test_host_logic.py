@@ -297,7 +297,8 @@ def test_static_aggregation_equals_eager(monkeypatch):
     for static in (False, True):
         model = modeling.build_detection_model(cfg)
         model.load_state_dict(sd)
-        eng = engine.ClipEngine(model, steps_per_batch=3, overlap=False, graphs=False, static_aggregation=static)
+        eng = engine.ClipEngine(model, steps_per_batch=3, overlap=False, graphs=False, static_aggregation=static,
+                                batch_aggregation=False)
         a = eng.run(frames, T, last=12)
         if static:                       # force a round trip static -> eager -> static in the middle of the video
             assert eng._static.active
@@ -318,6 +319,40 @@ def test_static_aggregation_equals_eager(monkeypatch):
     for a, b in zip(*outs):
         assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels"))
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+
+
+def test_batched_aggregation_equals_per_frame_steps(monkeypatch):
+    """ClipEngine(batch_aggregation=True): the aggregation of all key frames of a step-batch runs stage by stage over
+    the batch (MEGAFeatureExtractor.aggregate_batch: legal because stage i of key frame t only depends on stage i-1 of
+    key frames <= t) -- same detections as one model.step() per key frame, through cold start, memory / global deque
+    eviction (7-frame window here) and a second video.  (CPU twins: MKL's GEMMs are not batch-invariant -> 1e-5; the
+    HIP kernels are: tests/test_e2e_gpu.py asserts bit equality.)"""
+    from mega.pytorch_amd import engine
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    cfg = _small_cfg()
+    cfg.merge_from_list(["MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 7, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 3,
+                         "MODEL.VID.MEGA.MIN_OFFSET", -3, "MODEL.VID.MEGA.MAX_OFFSET", 3, "MODEL.VID.MEGA.GLOBAL.SIZE", 3,
+                         "MODEL.RPN.POST_NMS_TOP_N_TEST", 40, "MODEL.VID.RPN.REF_POST_NMS_TOP_N", 10])
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    T, nkey = 26, 18
+    frames = synth.preprocess_cpu(synth.make_clip(T, 96, 128, seed=2))
+    outs = []
+    for batched in (False, True):
+        model = modeling.build_detection_model(cfg)
+        model.load_state_dict(sd)
+        eng = engine.ClipEngine(model, steps_per_batch=4, overlap=False, graphs=False, batch_aggregation=batched,
+                                keep_logits=True)
+        a = eng.run(frames, T, last=nkey)
+        a += eng.run(frames[:12], 12, last=3)
+        outs.append((a, eng.logits_log))
+        fe = model.roi_heads.box.feature_extractor
+        assert [len(q["rois"]) for q in fe.mem_queue_list] == [3, 3, 3]          # second video: 3 key frames
+    assert len(outs[0][0]) == len(outs[1][0]) == nkey + 3
+    for i, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels")), i
+        assert (a.bbox - b.bbox).abs().max() < 1e-3 and (a.get_field("scores") - b.get_field("scores")).abs().max() < 1e-5
+        assert (outs[0][1][i] - outs[1][1][i]).abs().max() < 1e-4
 
 
 def test_fgfa_window_override_matches_oracle(monkeypatch):
