@@ -669,12 +669,9 @@ extern "C" int mega_rpn_select(const float* rpn_out, const float* cell_anchors, 
   p.kmax = k; p.im_w = im_w; p.im_h = im_h; p.min_size = min_size; p.clip = logf(1000.f / 16.f);
   int ns = 64;
   while (ns < k) ns <<= 1;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)rpn_topk_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              SORT_MAX * (int)sizeof(u64));
-    attr_set = true;
-  }
+  // set on every call: a per-process flag would miss the second device of a multi-GPU process
+  (void)hipFuncSetAttribute((const void*)rpn_topk_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            SORT_MAX * (int)sizeof(u64));
   hipLaunchKernelGGL(rpn_topk_decode_kernel, dim3(B), dim3(1024), (size_t)ns * sizeof(u64), st, p);
   int rc = mega_nms_sorted((const float*)sboxes, counts, valid, nullptr, B, k, nms_thresh, strict_gt, post_nms_top_n,
                            keep_pos, prop_cnt, nullptr, mws, mega_nms_workspace_bytes(B, k), stream);

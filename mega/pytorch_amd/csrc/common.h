@@ -20,12 +20,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 
-// round-to-nearest-even, NaN preserved (same rule torch uses for float -> bfloat16)
+// round-to-nearest-even (the rule torch uses for float -> bfloat16), NaN stays NaN: gfx950's hardware conversion
+// (v_cvt_pk_bf16_f32) -- one instruction per pair, no NaN branch in every epilogue / softmax pack.
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
 }
 
 template <typename T> struct Elem;
@@ -43,9 +42,19 @@ template <> struct Elem<bf16_t> {
 // hipGetLastError() is sticky per thread and also reports BENIGN codes left behind by other users of the runtime in
 // this process (e.g. hipErrorNotReady from an event query of torch's caching allocator): every entry point
 // clears it first, so the check after the launches only sees this call's own errors.
-static inline void mega_clear_error() { (void)hipGetLastError(); }
+// What was pending is not this call's error, so it is not returned -- but a code other than the known-benign
+// hipErrorNotReady is kept in g_mega_pending_hip_error so that mega_last_error_string() can name it after a later
+// failure (it usually explains it).
+static inline void mega_clear_error();
+
 
 extern int g_mega_last_hip_error;  // defined in frames.hip; read back through mega_last_error_string()
+extern int g_mega_pending_hip_error;  // a non-benign error found pending by mega_clear_error()
+
+static inline void mega_clear_error() {
+  hipError_t e = hipGetLastError();
+  g_mega_pending_hip_error = (e == hipSuccess || e == hipErrorNotReady) ? 0 : (int)e;
+}
 
 static inline int mega_check_launch() {
   hipError_t e = hipGetLastError();

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const unsigned char* __re
 }  // namespace
 
 int g_mega_last_hip_error = 0;
+int g_mega_pending_hip_error = 0;
 
 extern "C" const char* mega_last_error_string() {
   return hipGetErrorString((hipError_t)g_mega_last_hip_error);

@@ -21,6 +21,8 @@
 //                       f32 -> mfma_32x32x2_f32 (exact f32, parity mode).  The key range can be split over
 //                       blockIdx.z (a call has only Nq/128 * 16 blocks for 256 CUs); partial (m, l, O) are then
 //                       merged by attn_combine_kernel.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -106,6 +108,24 @@ __global__ __launch_bounds__(256) void pos_logits_kernel(const float4* __restric
 // k = 8 (lane >> 4) + e), B = Wg^T (col = head), two K-steps for the 64-d embedding.  The four lanes that share a pair
 // each build a quarter of its embedding (one delta's 8 sines or 8 cosines per K-step), so no value is computed twice
 // and the 1024 FMAs per pair of the VALU version disappear.  D: col = head, rows = 4 consecutive pairs -> 16-B stores.
+// sin(a + 2 pi shift_rev) after a two-constant Cody-Waite reduction: cos(x) = sin(x + 1/4 revolution), so a lane that
+// needs only the sine OR the cosine of its arguments pays one transcendental per value.
+__device__ __forceinline__ float sin_shifted(float a, float shift_rev) {
+  const float INV2PI = 0.15915494309189535f;
+  const float TWO_PI_HI = 6.28318548202514648f;
+  const float TWO_PI_LO = -1.7484555e-7f;
+  const float n = rintf(a * INV2PI);
+  float r = fmaf(-n, TWO_PI_HI, a);
+  r = fmaf(-n, TWO_PI_LO, r);
+  return __builtin_amdgcn_sinf(fmaf(r, INV2PI, shift_rev));
+}
+
+// fast-mode (bf16 path) logarithm / division: v_log_f32 (1 ulp in log2) and v_rcp_f32 -- the position arguments are
+// 100 x log(ratio): an absolute error of ~1e-6 in the log moves the phase by 1e-4 rad, far below the bf16 rounding
+// of the embedding that follows.
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __restrict__ rois_q,
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
   const float4 bq = rois_q[q];
   const float wq = bq.z - bq.x + 1.f, hq = bq.w - bq.y + 1.f;
   const float cxq = 0.5f * (bq.x + bq.z), cyq = 0.5f * (bq.y + bq.w);
-  const bool use_cos = g & 1;
+  const float shift = (g & 1) ? 0.25f : 0.f;          // odd k-groups hold cosines
 #pragma unroll 1
   for (int t = 0; t < 4; ++t) {
     const int k0 = blockIdx.x * 256 + wave * 64 + t * 16;
@@ -146,11 +166,11 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
     // K-step s covers deltas 2 s and 2 s + 1; this lane owns delta d = 2 s + (g >> 1)
     float pm[2];
     if (g >> 1) {
-      pm[0] = logf(fabsf((cyq - cyk) / hq) + 1e-3f);   // d = 1
-      pm[1] = logf(hq / hk);                           // d = 3
+      pm[0] = fast_log(fabsf(fast_div(cyq - cyk, hq)) + 1e-3f);   // d = 1
+      pm[1] = fast_log(fast_div(hq, hk));                           // d = 3
     } else {
-      pm[0] = logf(fabsf((cxq - cxk) / wq) + 1e-3f);   // d = 0
-      pm[1] = logf(wq / wk);                           // d = 2
+      pm[0] = fast_log(fabsf(fast_div(cxq - cxk, wq)) + 1e-3f);   // d = 0
+      pm[1] = fast_log(fast_div(wq, wk));                           // d = 2
     }
     f32x4_t acc = {bias, bias, bias, bias};
 #pragma unroll
@@ -158,17 +178,13 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
       const float pv = pm[s] * 100.0f;
       bf16x8_t a;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float sn, cs;
-        sincos_reduced(pv * rdim[i], &sn, &cs);
-        a[i] = (__bf16)(use_cos ? cs : sn);
-      }
+      for (int i = 0; i < 8; ++i) a[i] = (__bf16)sin_shifted(pv * rdim[i], shift);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[s], acc, 0, 0, 0);
     }
     // D: head = lane & 15, pairs k0 + 4 g + r
     float4 o;
-    o.x = logf(fmaxf(acc[0], 0.f) + 1e-6f); o.y = logf(fmaxf(acc[1], 0.f) + 1e-6f);
-    o.z = logf(fmaxf(acc[2], 0.f) + 1e-6f); o.w = logf(fmaxf(acc[3], 0.f) + 1e-6f);
+    o.x = fast_log(fmaxf(acc[0], 0.f) + 1e-6f); o.y = fast_log(fmaxf(acc[1], 0.f) + 1e-6f);
+    o.z = fast_log(fmaxf(acc[2], 0.f) + 1e-6f); o.w = fast_log(fmaxf(acc[3], 0.f) + 1e-6f);
     if (out_t) {
       const int kf = k0 + 4 * g, kt = kf >> 5, kk = kf & 31;
       bf16_t* dst = out_t + (((size_t)row * ((Nk + 31) >> 5) + kt) * Nq + q) * 32 + ((kk >> 2) & 1) * 16 + (kk >> 3) * 4;
@@ -180,6 +196,76 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
       float* dst = out + ((size_t)row * Nq + q) * ldp + k0 + 4 * g;
       if (k0 + 4 * g + 3 < ldp) *reinterpret_cast<float4*>(dst) = o;    // ldp % 4 == 0: pad columns may be written
     }
+  }
+}
+
+// Tiled-bf16 variant with coalesced output.  The tile-ordered logits [16][ceil(Nk/32)][Nq][32] are contiguous over q
+// for a fixed (head, key tile): a block therefore owns 8 consecutive queries x 64 keys (two key tiles), computes its
+// 512 pairs as 32 MFMA tiles (8 per wave, same operand layout as pos_logits_mfma_kernel), stages the 16 KiB of bf16
+// logits in LDS in their final order and writes 32 runs of 512 contiguous bytes (16 B per lane) instead of 8-byte
+// pieces scattered over 16 head planes.  Each lane needs only the sine OR the cosine of its 16 arguments:
+// cos(x) = sin(x + 1/4 revolution), one transcendental per value instead of two.
+__global__ __launch_bounds__(256) void pos_logits_tiled_kernel(const float4* __restrict__ rois_q,
+                                                               const float4* __restrict__ rois_k,
+                                                               const float* __restrict__ wgt,
+                                                               const float* __restrict__ bg,
+                                                               const float* __restrict__ dim_mat,
+                                                               bf16_t* __restrict__ out_t, int Nq, int Nk) {
+  __shared__ __attribute__((aligned(16))) bf16_t stage[16 * 2 * 8 * 32];   // [head][key tile][q][tile order]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.y * 8, k00 = blockIdx.x * 64;
+  bf16x8_t bw[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bw[s][e] = (__bf16)wgt[(32 * s + 8 * g + e) * 16 + row];
+  float rdim[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rdim[i] = 1.0f / dim_mat[i];
+  const float bias = bg[row];
+  const float shift = (g & 1) ? 0.25f : 0.f;        // odd k-groups hold cosines
+#pragma unroll 1
+  for (int tile = 0; tile < 8; ++tile) {
+    const int ql = 2 * wave + (tile >> 2);
+    const int kb = (tile & 3) * 16;
+    const float4 bq = rois_q[min(q0 + ql, Nq - 1)];
+    const float4 bk = rois_k[min(k00 + kb + row, Nk - 1)];
+    const float wq = bq.z - bq.x + 1.f, hq = bq.w - bq.y + 1.f;
+    const float cxq = 0.5f * (bq.x + bq.z), cyq = 0.5f * (bq.y + bq.w);
+    const float wk = bk.z - bk.x + 1.f, hk = bk.w - bk.y + 1.f;
+    const float cxk = 0.5f * (bk.x + bk.z), cyk = 0.5f * (bk.y + bk.w);
+    float pm[2];
+    if (g >> 1) {
+      pm[0] = fast_log(fabsf(fast_div(cyq - cyk, hq)) + 1e-3f);   // d = 1
+      pm[1] = fast_log(fast_div(hq, hk));                           // d = 3
+    } else {
+      pm[0] = fast_log(fabsf(fast_div(cxq - cxk, wq)) + 1e-3f);   // d = 0
+      pm[1] = fast_log(fast_div(wq, wk));                           // d = 2
+    }
+    f32x4_t acc = {bias, bias, bias, bias};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float pv = pm[s] * 100.0f;
+      bf16x8_t a;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = (__bf16)sin_shifted(pv * rdim[i], shift);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[s], acc, 0, 0, 0);
+    }
+    // D: head = row, keys kb + 4 g + r of the block's 64
+    const int kf = kb + 4 * g, ktl = kf >> 5, kk = kf & 31;
+    uint2 pk;
+    pk.x = (unsigned)f32_to_bf16(fast_log(fmaxf(acc[0], 0.f) + 1e-6f)) | ((unsigned)f32_to_bf16(fast_log(fmaxf(acc[1], 0.f) + 1e-6f)) << 16);
+    pk.y = (unsigned)f32_to_bf16(fast_log(fmaxf(acc[2], 0.f) + 1e-6f)) | ((unsigned)f32_to_bf16(fast_log(fmaxf(acc[3], 0.f) + 1e-6f)) << 16);
+    *reinterpret_cast<uint2*>(&stage[((row * 2 + ktl) * 8 + ql) * 32 + ((kk >> 2) & 1) * 16 + (kk >> 3) * 4]) = pk;
+  }
+  __syncthreads();
+  const int ktiles = (Nk + 31) >> 5, kt0 = k00 >> 5;
+  for (int idx = threadIdx.x; idx < 16 * 2 * 8 * 4; idx += 256) {
+    const int chunk = idx & 3, ql = (idx >> 2) & 7, ktl = (idx >> 5) & 1, head = idx >> 6;
+    if (q0 + ql < Nq && kt0 + ktl < ktiles)
+      *reinterpret_cast<uint4*>(out_t + (((size_t)head * ktiles + kt0 + ktl) * Nq + q0 + ql) * 32 + chunk * 8) =
+          *reinterpret_cast<const uint4*>(&stage[((head * 2 + ktl) * 8 + ql) * 32 + chunk * 8]);
   }
 }
 
@@ -368,11 +454,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = expf(m_run - m_new);
+    // bf16 mode: hardware exp2 (v_exp_f32) instead of libm's expf (range checks + a divergent branch per value)
+    auto ex = [](float v) { return sizeof(T) == 2 ? __expf(v) : expf(v); };
+    const float alpha = ex(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = expf(s[r] - m_new);
+      s[r] = ex(s[r] - m_new);
       psum += s[r];
     }
     l_run = l_run * alpha + psum;
@@ -545,9 +633,16 @@ extern "C" int mega_position_logits_tiled(const float* rois_q, const float* rois
   if (!rois_q || !rois_k || !wg_t || !bg || !dim_mat || !out_bf16 || Nq < 0 || Nk < 0 ||
       (reinterpret_cast<size_t>(out_bf16) & 15))
     return MEGA_ERR_ARG;
-  dim3 grid(cdiv(Nk, 256), Nq);
-  hipLaunchKernelGGL(pos_logits_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
-                     (const float4*)rois_k, wg_t, bg, dim_mat, (float*)nullptr, (bf16_t*)out_bf16, Nq, Nk, 0);
+  static const bool legacy = getenv("MEGA_POS_LEGACY") != nullptr;     // A/B switch (experiments)
+  if (legacy) {
+    dim3 grid(cdiv(Nk, 256), Nq);
+    hipLaunchKernelGGL(pos_logits_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
+                       (const float4*)rois_k, wg_t, bg, dim_mat, (float*)nullptr, (bf16_t*)out_bf16, Nq, Nk, 0);
+  } else {
+    dim3 grid(cdiv(Nk, 64), cdiv(Nq, 8));
+    hipLaunchKernelGGL(pos_logits_tiled_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
+                       (const float4*)rois_k, wg_t, bg, dim_mat, (bf16_t*)out_bf16, Nq, Nk);
+  }
   return mega_check_launch();
 }
 

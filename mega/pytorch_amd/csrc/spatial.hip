@@ -4,6 +4,8 @@
 //   * ROIAlign forward                                           (mega_core/csrc/cuda/ROIAlign_cuda.cu:15-122,
 //                                                                 csrc/cpu/ROIAlign_cpu.cpp:18-219)
 // Activations are NHWC so that a pixel's channels are one contiguous, coalesced run.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -214,7 +216,13 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const T* __restrict__ in,
 // Channel-vectorised NHWC -> bin-major variant (the hot-path layout): one work item = (bin, 16-byte channel
 // vector); a wave reads 64 consecutive 16-B vectors of one pixel = 1 KiB fully coalesced per neighbour.
 // Same arithmetic, same order of operations as roi_align_kernel.
-template <typename T>
+//
+// XCD_SLICED: the eight XCDs have private L2s and consecutive blocks go to consecutive XCDs.  In the plain item order
+// every XCD ends up reading every channel of every map (PMC: 3.5 GB fetched for 196 MB of maps at 20 frames: the
+// overlapping bilinear taps of neighbouring bins / ROIs miss L2).  Sliced, XCD x (= blockIdx.x & 7) owns the channel
+// slice [x C/8, (x+1) C/8): its working set per frame is 1/8 of the map (1.2 MB for 2048 channels: L2-resident), a
+// block covers 256 / (CV/8) consecutive bins of that slice.  Same arithmetic, same results.
+template <typename T, bool XCD_SLICED>
 __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __restrict__ feat,
                                                                  const float* __restrict__ rois, T* __restrict__ out,
                                                                  int K, int C, int H, int W, float spatial_scale,
@@ -222,10 +230,20 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __rest
   constexpr int VE = Elem<T>::VE;
   const int CV = C / VE;
   const long long total = (long long)K * PH * PW * CV;
-  for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
-       item += (long long)gridDim.x * blockDim.x) {
-    const int cv = (int)(item % CV);
-    const int bin = (int)(item / CV);
+  const long long nitems = XCD_SLICED ? total / 8 : total;            // per XCD when sliced
+  const long long first = XCD_SLICED ? (long long)(blockIdx.x >> 3) * blockDim.x + threadIdx.x
+                                     : (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = XCD_SLICED ? (long long)(gridDim.x >> 3) * blockDim.x : (long long)gridDim.x * blockDim.x;
+  for (long long item = first; item < nitems; item += step) {
+    int cv, bin;
+    if (XCD_SLICED) {
+      const int cvs = CV >> 3;                                         // vectors per slice
+      cv = (int)(blockIdx.x & 7) * cvs + (int)(item % cvs);
+      bin = (int)(item / cvs);
+    } else {
+      cv = (int)(item % CV);
+      bin = (int)(item / CV);
+    }
     const int pw = bin % PW;
     const int ph = (bin / PW) % PH;
     const int k = bin / (PW * PH);
@@ -281,6 +299,111 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __rest
   }
 }
 
+
+// bf16-mode variant with SEPARABLE weights.  A bin's value is (1/count) sum over its grid_h x grid_w samples of the
+// bilinear blend of 4 pixels; the blend weights factor into (hy | ly) x (hx | lx), so the bin equals
+//   (1/count) sum_y sum_x Wy[y] Wx[x] f(y, x),   Wy[y] = sum of hy over samples whose lower row is y + ly over those
+// whose upper row is y (same for x).  Adjacent samples are at most one pixel apart (grid = ceil(roi / bins)), so the
+// touched pixels form a dense (<= grid_h + 1) x (<= grid_w + 1) patch: 16 loads instead of 36 for a 3 x 3 grid,
+// 49 instead of 144 for 6 x 6.  The kernel is bound by L1/L2 tap traffic (PMC: 27 GB of loads per 20-frame batch),
+// so fewer taps is the lever.  The sum is re-associated, hence bf16 mode only: the exact-f32 path keeps the
+// reference's term order (roi_align_nhwc_vec_kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_nhwc_sep_kernel(const T* __restrict__ feat,
+                                                                 const float* __restrict__ rois, T* __restrict__ out,
+                                                                 int K, int C, int H, int W, float spatial_scale,
+                                                                 int PH, int PW, int sampling_ratio) {
+  constexpr int VE = Elem<T>::VE;
+  constexpr int MAXP = 10;                                 // patch columns kept in registers (grid <= 9)
+  const int CV = C / VE;
+  const long long total = (long long)K * PH * PW * CV;
+  for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+       item += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(item % CV);
+    const int bin = (int)(item / CV);
+    const int pw = bin % PW;
+    const int ph = (bin / PW) % PH;
+    const int k = bin / (PW * PH);
+    const float* roi = rois + (size_t)k * 5;
+    const int b = (int)roi[0];
+    const float roi_start_w = roi[1] * spatial_scale;
+    const float roi_start_h = roi[2] * spatial_scale;
+    const float roi_end_w = roi[3] * spatial_scale;
+    const float roi_end_h = roi[4] * spatial_scale;
+    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.f);
+    const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.f);
+    const float bin_size_h = roi_height / (float)PH;
+    const float bin_size_w = roi_width / (float)PW;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)PH);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)PW);
+    const float count = (float)(grid_h * grid_w);
+    // one axis sample -> (low index, high index, weight of low, weight of high); weights 0 when the sample is skipped
+    auto axis = [](float p, int n, int& lo, int& hi, float& wl, float& wh) {
+      if (p < -1.0f || p > (float)n) { lo = hi = 0; wl = wh = 0.f; return; }
+      if (p <= 0.f) p = 0.f;
+      lo = (int)p;
+      if (lo >= n - 1) { hi = lo = n - 1; p = (float)lo; } else { hi = lo + 1; }
+      wh = p - (float)lo;
+      wl = 1.f - wh;
+    };
+    // column patch: first touched column and the per-column weights (static register indices)
+    int x_first = W, x_last = -1;
+    for (int ix = 0; ix < grid_w; ++ix) {
+      int lo, hi; float wl, wh;
+      axis(roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)grid_w, W, lo, hi, wl, wh);
+      if (wl + wh > 0.f) { x_first = min(x_first, lo); x_last = max(x_last, hi); }
+    }
+    float wx[MAXP];
+#pragma unroll
+    for (int c = 0; c < MAXP; ++c) wx[c] = 0.f;
+    for (int ix = 0; ix < grid_w; ++ix) {
+      int lo, hi; float wl, wh;
+      axis(roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)grid_w, W, lo, hi, wl, wh);
+#pragma unroll
+      for (int c = 0; c < MAXP; ++c) {
+        if (lo - x_first == c) wx[c] += wl;
+        if (hi - x_first == c) wx[c] += wh;
+      }
+    }
+    int y_first = H, y_last = -1;
+    for (int iy = 0; iy < grid_h; ++iy) {
+      int lo, hi; float wl, wh;
+      axis(roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)grid_h, H, lo, hi, wl, wh);
+      if (wl + wh > 0.f) { y_first = min(y_first, lo); y_last = max(y_last, hi); }
+    }
+    const T* base = feat + (size_t)b * H * W * C + (size_t)cv * VE;
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    const int ncol = x_last - x_first + 1;
+    for (int y = y_first; y <= y_last; ++y) {
+      float wy = 0.f;
+      for (int iy = 0; iy < grid_h; ++iy) {
+        int lo, hi; float wl, wh;
+        axis(roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)grid_h, H, lo, hi, wl, wh);
+        if (lo == y) wy += wl;
+        if (hi == y) wy += wh;
+      }
+      if (wy == 0.f) continue;
+      const T* rowp = base + ((size_t)y * W + x_first) * C;
+#pragma unroll
+      for (int c = 0; c < MAXP; ++c) {
+        if (c < ncol) {
+          const uint4 r = *reinterpret_cast<const uint4*>(rowp + (size_t)c * C);
+          const T* ev = reinterpret_cast<const T*>(&r);
+          const float wgt = wy * wx[c];
+#pragma unroll
+          for (int e = 0; e < VE; ++e) acc[e] = fmaf(wgt, Elem<T>::ld(ev + e), acc[e]);
+        }
+      }
+    }
+    uint4 o;
+    T* oe = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] / count);
+    *reinterpret_cast<uint4*>(out + (size_t)bin * C + (size_t)cv * VE) = o;
+  }
+}
 
 // ------------------------------------------------------------------------------------ stem conv on the matrix cores
 // bf16 path: the same 7x7/2 conv as a GEMM  out[pixel][n] = sum_k A[pixel][k] * W[n][k],  k = (c*7 + r)*7 + s padded
@@ -434,14 +557,34 @@ extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out
     return MEGA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (in_nhwc && out_nhwc && dtype == out_dtype && C % (dtype == MEGA_BF16 ? 8 : 4) == 0) {
-    const long long total = (long long)K * pooled_h * pooled_w * (C / (dtype == MEGA_BF16 ? 8 : 4));
-    const long long nb = (total + 255) / 256;
-    dim3 vgrid((unsigned)(nb > 1048576 ? 1048576 : nb));
-    if (dtype == MEGA_BF16)
-      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<bf16_t>), vgrid, dim3(256), 0, st, (const bf16_t*)feat, rois,
+    const int CV = C / (dtype == MEGA_BF16 ? 8 : 4);
+    const long long total = (long long)K * pooled_h * pooled_w * CV;
+    static const bool no_slice = getenv("MEGA_ROI_NO_XCD_SLICE") != nullptr;       // A/B switch (experiments)
+    const bool sliced = !no_slice && CV % 8 == 0 && CV / 8 >= 16 && total / 8 >= 256 * 64;
+    long long nb = ((sliced ? total / 8 : total) + 255) / 256;
+    if (nb > 131072) nb = 131072;
+    dim3 vgrid((unsigned)(sliced ? nb * 8 : nb));
+    static const bool no_sep = getenv("MEGA_ROI_NO_SEPARABLE") != nullptr;         // A/B switch (experiments)
+    // grid = ceil(roi / bins) <= ceil(max(H, W) / min(ph, pw)): the register patch of the separable form holds 10 columns
+    const int max_grid = sampling_ratio > 0 ? sampling_ratio : (max(H, W) + min(pooled_h, pooled_w) - 1) / min(pooled_h, pooled_w);
+    if (dtype == MEGA_BF16 && !no_sep && max_grid <= 9) {
+      long long nb2 = (total + 255) / 256;
+      if (nb2 > 1048576) nb2 = 1048576;
+      hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<bf16_t>), dim3((unsigned)nb2), dim3(256), 0, st, (const bf16_t*)feat,
+                         rois, (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+      return mega_check_launch();
+    }
+    if (dtype == MEGA_BF16 && sliced)
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<bf16_t, true>), vgrid, dim3(256), 0, st, (const bf16_t*)feat, rois,
                          (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+    else if (dtype == MEGA_BF16)
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<bf16_t, false>), vgrid, dim3(256), 0, st, (const bf16_t*)feat, rois,
+                         (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+    else if (dtype == MEGA_F32 && sliced)
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, true>), vgrid, dim3(256), 0, st, (const float*)feat, rois,
+                         (float*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
     else if (dtype == MEGA_F32)
-      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float>), vgrid, dim3(256), 0, st, (const float*)feat, rois,
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, false>), vgrid, dim3(256), 0, st, (const float*)feat, rois,
                          (float*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
     else
       return MEGA_ERR_ARG;

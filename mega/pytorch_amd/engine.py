@@ -25,11 +25,13 @@ import torch
 from . import ops
 
 
-def global_schedule(seg_len, global_size, seed=0):
-    """Shuffled frame order of a video and the per-key-frame global frame ids (vid_mega.py:21-24,:112-120)."""
+def global_schedule(seg_len, global_size, seed=0, shuffle=True):
+    """Frame order of a video for the global pool and the per-key-frame global frame ids (vid_mega.py:21-24,:112-120).
+    shuffle = cfg.MODEL.VID.MEGA.GLOBAL.SHUFFLE (False: the reference's plain arange order)."""
     rng = np.random.RandomState(seed)
     shuffled = np.arange(seg_len)
-    rng.shuffle(shuffled)
+    if shuffle:
+        rng.shuffle(shuffled)
 
     def for_frame(idx):
         size = global_size if idx == 0 else 1
@@ -355,9 +357,11 @@ class ClipEngine(object):
         # the order in which the schedule first needs them (what a step-batch does not need yet is computed ahead of
         # time): one frame-stage shape for the whole video, i.e. one hipGraph, instead of a new shape per batch.
         plan, plan_pos = [], {}
+        last_use = {}                     # reuse_records: frame id -> last key frame of this run() that consumes it
         if self.reuse_records:
             for i in range(first, last):
                 for f, _, _ in self.jobs_for_step(i, T, gfor):
+                    last_use[f] = i
                     if f not in plan_pos and f not in self._rec_cache and f not in self._rec_pending:
                         plan_pos[f] = len(plan)
                         plan.append(f)
@@ -448,6 +452,10 @@ class ClipEngine(object):
                 for i, js in zip(range(b[0], b[1]), per_step):
                     if self.reuse_records:
                         r = [self._rec_cache[j[0]] for j in js]
+                        if last == T:         # whole video scheduled: a record is dropped after its last use (a
+                            for j in js:      # multi-thousand-frame video would otherwise keep ~1 MB per frame)
+                                if last_use.get(j[0]) == i:
+                                    self._rec_cache.pop(j[0], None)
                     else:
                         r = recs[o:o + len(js)]
                         o += len(js)

@@ -101,7 +101,8 @@ def compute_on_dataset(model, index, img_dir, device, videos=None, steps_per_bat
                                **(source_kwargs or {}))
         t0 = time.perf_counter()
         # vid_mega.py:21-24 shuffles with numpy's global RNG; seeded per video here so runs are reproducible
-        gfor = _engine.global_schedule(v["seg_len"], gsize, seed=seed + v["start"])
+        gfor = _engine.global_schedule(v["seg_len"], gsize, seed=seed + v["start"],
+                                       shuffle=bool(model.cfg.MODEL.VID.MEGA.GLOBAL.SHUFFLE))
         dets = eng.run(src, v["seg_len"], gfor)
         if device.type == "cuda":
             torch.cuda.synchronize(device)

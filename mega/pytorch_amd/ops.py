@@ -120,6 +120,10 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
         _tok = _pb(_igemm_family(lib, N * Ho * Wo, Cout, R * S * Cin, x.dtype),
                    2.0 * N * Ho * Wo * Cout * R * S * Cin,
                    x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size())
+    if x.numel() * x.element_size() >= 0x7FF00000 or w.numel() * w.element_size() >= 0x7FF00000:
+        raise ValueError("conv2d_nhwc: operand of %.2f GiB; the kernels use 32-bit buffer offsets (< 2 GiB per operand): "
+                         "lower the frame-stage batch (ClipEngine steps_per_batch) or split the call over M"
+                         % (max(x.numel() * x.element_size(), w.numel() * w.element_size()) / 2.0 ** 30))
     nb = lib.mega_conv2d_nhwc_workspace_bytes(N * Ho * Wo, Cout, R * S * Cin)     # > 0: long-K layer, split-K
     ws = _ws(nb, x.device) if nb else None
     rc = lib.mega_conv2d_nhwc_ws(_ptr(x), _ptr(w), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin,
@@ -213,6 +217,8 @@ def nms(dets, scores, thr, strict_gt=True):
     n = dets.shape[0]
     if n == 0:
         return torch.empty((0,), dtype=torch.int64, device=dets.device)
+    if n > 8192:
+        raise ValueError("nms: %d boxes; the single-block sort / scan kernels take at most 8192 per problem" % n)
     dets = dets.contiguous().float()
     scores = scores.contiguous().float()
     keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
@@ -235,6 +241,9 @@ def rpn_select(rpn_out, cell_anchors, Hf, Wf, anchor_stride, pre_nms, post_nms, 
     ldc = rpn_out.shape[-1]
     assert rpn_out.dtype == torch.float32 and rpn_out.is_contiguous() and rpn_out.numel() == B * Hf * Wf * ldc
     k = min(pre_nms, Hf * Wf * A)
+    if k > 8192:
+        raise ValueError("rpn_select: PRE_NMS_TOP_N = %d; the on-chip sort takes at most 8192 candidates per frame "
+                         "(MODEL.RPN.PRE_NMS_TOP_N_TEST / MODEL.VID.RPN.REF_PRE_NMS_TOP_N)" % k)
     props = torch.empty((B, post_nms, 4), dtype=torch.float32, device=rpn_out.device)
     scores = torch.empty((B, post_nms), dtype=torch.float32, device=rpn_out.device)
     cnt = torch.empty((B,), dtype=torch.int32, device=rpn_out.device)
@@ -255,6 +264,9 @@ def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh,
     _gpu(logits, deltas, props)
     lib = _lib.load()
     R, NC = logits.shape
+    if R > 1024:
+        raise ValueError("postprocess: %d proposals; the per-class sort takes at most 1024 per image "
+                         "(MODEL.RPN.POST_NMS_TOP_N_TEST)" % R)
     cap = (NC - 1) * R
     dev = logits.device
     ob = torch.empty((cap, 4), dtype=torch.float32, device=dev)

@@ -1,0 +1,211 @@
+"""Extra bench lines for the other BASELINE.json configurations (the headline, configs[2], is bench.py's default):
+
+  python tools/bench_configs.py --config 1     single-frame R-50-C4 detector, 600x1000 (configs/vid_R_50_C4_1x.yaml)
+  python tools/bench_configs.py --config 2     MEGA R-50 fp32, 10 local + 10 global frames (11-frame window)
+  python tools/bench_configs.py --config 5     FGFA R-101, 21-frame window, 600x1000, bf16
+
+Each prints ONE JSON line (same field names as bench.py; `roofline` describes that configuration's own dominant
+kernel).  Synthetic clip and seeded calibrated weights, frames resident in HBM as uint8, preprocessing included.
+Configs 1 and 5 are driven in the reference's call convention, one key frame per model(...) call (the reference has
+no batching there either); config 2 runs through ClipEngine like the headline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def log(msg):
+    sys.stderr.write("[bench_configs] %s\n" % msg)
+    sys.stderr.flush()
+
+
+def families(ops, fn, steps):
+    p = ops.Profiler()
+    ops.set_profiler(p)
+    fn()
+    summ = p.summary()
+    ops.set_profiler(None)
+    fam = {}
+    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+        fam[k] = {"ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": round(v["launches"] / steps, 1),
+                  "tflops": round(v["flops"] / (v["ms"] * 1e9), 2) if v["ms"] > 0 else 0.0,
+                  "gbps": round(v["bytes"] / (v["ms"] * 1e6), 1) if v["ms"] > 0 else 0.0}
+    return fam, summ
+
+
+def timed(fn, steps, min_seconds=1.0, max_blocks=40):
+    """blocks of `steps` calls of fn(i), each bracketed by synchronize; median block."""
+    blocks, i = [], 0
+    while True:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(i)
+            i += 1
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+        if sum(blocks) >= min_seconds or len(blocks) >= max_blocks:
+            break
+    s = sorted(blocks)
+    med = s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+    return med, blocks
+
+
+def config1(args, dev):
+    from mega.pytorch_amd import config, modeling, ops, synth
+    import mega.pytorch_amd.fgfa  # noqa: F401  (registers GeneralizedRCNN)
+    cfg = config.get_cfg("R-50", "base")
+    cfg.DTYPE = args.dtype
+    cfg.MODEL.DEVICE = str(dev)
+    sd = {k: v for k, v in synth.make_fgfa_state_dict(seed=0).items() if not k.startswith(("flownet.", "embednet."))}
+    model = modeling.build_detection_model(cfg)
+    model.load_state_dict(sd)
+    model.to(dev)
+    clip = synth.make_clip(8, args.height, args.width, seed=0).to(dev)
+    mean = tuple(cfg.INPUT.PIXEL_MEAN)
+
+    def step(i):
+        x = ops.preprocess_frames(clip[i % 8:i % 8 + 1].contiguous(), mean, True)
+        return model(x[0])
+    for i in range(4):
+        step(i)
+    med, blocks = timed(step, args.steps)
+    fam, _ = families(ops, lambda: [step(i) for i in range(4)], 4)
+    return {"metric": "frames/sec single-frame R-50-C4 detector, %dx%d frames" % (args.width, args.height),
+            "value": round(args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(1e3 * med / args.steps, 3),
+            "config": {"workload": "GeneralizedRCNN R-50-C4 + ResNetConv52MLPFeatureExtractor, 300 proposals, one frame "
+                                   "per call with a host read of the detection count (BASELINE configs[0])"},
+            "kernel_families": fam, "blocks_ms": [round(1e3 * b, 2) for b in blocks]}
+
+
+def config5(args, dev):
+    from mega.pytorch_amd import config, modeling, ops, synth
+    import mega.pytorch_amd.fgfa  # noqa: F401
+    cfg = config.get_cfg("R-101", "fgfa")
+    cfg.DTYPE = args.dtype
+    cfg.MODEL.DEVICE = str(dev)
+    cfg.MODEL.VID.FGFA.ALL_FRAME_INTERVAL, cfg.MODEL.VID.FGFA.KEY_FRAME_LOCATION = 21, 10
+    cfg.MODEL.VID.FGFA.MIN_OFFSET, cfg.MODEL.VID.FGFA.MAX_OFFSET = -10, 10
+    sd = synth.make_fgfa_state_dict(blocks=(3, 4, 23), reduce_channel=False, seed=0)
+    model = modeling.build_detection_model(cfg)
+    model.load_state_dict(sd)
+    model.to(dev)
+    Tc = 16
+    clip = synth.make_clip(Tc, args.height, args.width, seed=0).to(dev)
+    mean = tuple(cfg.INPUT.PIXEL_MEAN)
+    T = 100000
+
+    def frame(i):
+        return ops.preprocess_frames(clip[i % Tc:i % Tc + 1].contiguous(), mean, True)[0]
+
+    def step(i):
+        if i == 0:
+            images = {"cur": frame(0), "frame_category": 0, "seg_len": T, "ref_init": [frame(j) for j in range(1, 11)]}
+        else:
+            images = {"cur": frame(i), "ref": [frame(i + 10)], "frame_category": 1, "seg_len": T}
+        return model(images)
+    for i in range(4):
+        step(i)
+    state = {"i": 4}
+
+    def steady(_):
+        step(state["i"])
+        state["i"] += 1
+    med, blocks = timed(steady, args.steps)
+    fam, summ = families(ops, lambda: [steady(0) for _ in range(4)], 4)
+    warp = summ.get("fgfa_warp")
+    h, w = (args.height - 1) // 16 + 1, (args.width - 1) // 16 + 1
+    esz = 2 if args.dtype == "bfloat16" else 4
+    warp_bytes = 21 * 3072 * h * w * esz + 1024 * h * w * esz          # every frame's map read once, output written
+    roof = None
+    if warp:
+        us = 1e3 * warp["ms"] / warp["launches"]
+        roof = {"bound": "hbm", "kernel": "fgfa_warp_aggregate_kernel (flow-guided warp + cosine weights + softmax + sum)",
+                "achieved": round(warp_bytes / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(warp_bytes / us / 1e3 / 8000.0, 4), "avg_launch_us": round(us, 1),
+                "bytes_per_launch": warp_bytes, "traffic": None}
+    return {"metric": "frames/sec FGFA R-101 inference, 21-frame window, %dx%d frames" % (args.width, args.height),
+            "value": round(args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(1e3 * med / args.steps, 3),
+            "config": {"workload": "GeneralizedRCNNFGFA R-101-C4, ALL_FRAME_INTERVAL 21 / KEY_FRAME_LOCATION 10 (BASELINE "
+                                   "configs[4]): per key frame 1 backbone + EmbedNet pass, FlowNetS on 21 image pairs, fused warp + "
+                                   "aggregation, RPN + conv5 box head; reference call convention (one key frame per call)"},
+            "roofline": roof, "kernel_families": fam, "blocks_ms": [round(1e3 * b, 2) for b in blocks]}
+
+
+def config2(args, dev):
+    """MEGA R-50, exact-f32 (the reference's own precision), 10 local + 10 global frames: an 11-frame window."""
+    from mega.pytorch_amd import config, engine as eng, modeling, ops, synth
+    cfg = config.get_cfg("R-50")
+    cfg.DTYPE = "float32"
+    cfg.MODEL.DEVICE = str(dev)
+    cfg.merge_from_list(["MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 11, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 5,
+                         "MODEL.VID.MEGA.MIN_OFFSET", -5, "MODEL.VID.MEGA.MAX_OFFSET", 5, "MODEL.VID.MEGA.GLOBAL.SIZE", 10])
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=0)
+    model = modeling.build_detection_model(cfg)
+    model.load_state_dict(sd)
+    model.to(dev)
+    K, spb = args.steps, 10
+    pre = 1 + 4 * spb
+    nblk = 12
+    T = pre + K * nblk + 8 + 8
+    base = synth.make_clip(16, args.height, args.width, seed=0).to(dev)
+    clip = base.index_select(0, torch.arange(T, device=dev) % 16).contiguous()
+    gfor = eng.global_schedule(T, 10, seed=0)
+    runner = eng.ClipEngine(model, steps_per_batch=spb)
+    runner.run(clip, T, gfor, first=0, last=pre)
+    torch.cuda.synchronize()
+    st0 = runner.steady_state()
+    blocks, pos = [], pre
+    for _ in range(nblk):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.run(clip, T, gfor, first=pos, last=pos + K)
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+        pos += K
+        if sum(blocks) > 1.5:
+            break
+    s = sorted(blocks)
+    med = s[len(s) // 2]
+    runner.use_graphs, runner.overlap = False, False
+    fam, summ = families(ops, lambda: runner.run(clip, T, gfor, first=pos, last=pos + 8), 8)
+    ig = {k: v for k, v in summ.items() if k.startswith("igemm")}
+    dom = max(ig, key=lambda k: ig[k]["ms"])
+    ach = ig[dom]["flops"] / (ig[dom]["ms"] * 1e9)
+    return {"metric": "frames/sec MEGA R-50 fp32 inference, 10 local + 10 global frames, %dx%d" % (args.width, args.height),
+            "value": round(K / med, 2), "unit": "frames/s", "ms_per_step": round(1e3 * med / K, 3), "dtype": "f32",
+            "config": {"workload": "MEGA R-50-C4, exact-f32 MFMA (v_mfma_f32_32x32x2_f32), ALL_FRAME_INTERVAL 11 / "
+                                   "KEY_FRAME_LOCATION 5, GLOBAL.SIZE 10 (BASELINE configs[1])", "engine_state": st0},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(ach / 157.3, 4), "traffic": None},
+            "kernel_families": fam, "blocks_ms": [round(1e3 * b, 2) for b in blocks]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, required=True, choices=[1, 2, 5])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--width", type=int, default=1000)
+    args = ap.parse_args()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    with torch.no_grad():
+        line = {1: config1, 2: config2, 5: config5}[args.config](args, dev)
+    line.setdefault("dtype", "bf16" if args.dtype == "bfloat16" else "f32")
+    line.update({"n_gpus": 1, "steps": args.steps, "higher_is_better": True, "data": "synthetic", "vs_baseline": None})
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+
+if __name__ == "__main__":
+    main()

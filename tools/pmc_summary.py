@@ -51,9 +51,32 @@ def counter_table(argv):
         print("%-64s x%-5d %s %14.0f  %8.1f us" % (k[:64], n, name, v, t))
 
 
+def mfma_busy(argv):
+    """python tools/pmc_summary.py --mfma-busy <SQ_VALU_MFMA_BUSY_CYCLES csv> <GRBM_GUI_ACTIVE csv> out.csv :
+    busy fraction per kernel = busy SIMD-cycles / (1024 SIMDs x GUI_ACTIVE cycles / 8 XCDs)  (GRBM_GUI_ACTIVE is summed
+    over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES counts cycles: 32 per v_mfma_f32_32x32x16_bf16 on its SIMD)."""
+    busy, gui, out = argv
+    b = agg(busy, "SQ_VALU_MFMA_BUSY_CYCLES")
+    g = agg(gui, "GRBM_GUI_ACTIVE")
+    rows = []
+    for k, (n, v, t) in b.items():
+        if k in g and g[k][1] > 0:
+            gn, gv, gt = g[k]
+            rows.append((k, n, v / n, gv / gn, (v / n) / (1024.0 * (gv / gn) / 8.0), t / n / 1e3))
+    rows.sort(key=lambda r: -r[1] * r[5])
+    with open(out, "w") as fh:
+        fh.write("kernel,launches,mfma_busy_cycles_per_launch,gui_active_per_launch,mfma_busy_fraction,avg_us_under_pmc\n")
+        for r in rows:
+            fh.write('"%s",%d,%.0f,%.0f,%.4f,%.2f\n' % r)
+    for r in rows[:12]:
+        print("%-60s x%-5d MFMA busy %5.1f %%  %8.1f us" % (r[0][:60], r[1], 100 * r[4], r[5]))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--counter":
         return counter_table(sys.argv[2:5])
+    if len(sys.argv) > 1 and sys.argv[1] == "--mfma-busy":
+        return mfma_busy(sys.argv[2:5])
     f = agg(sys.argv[1], "FETCH_SIZE")
     w = agg(sys.argv[2], "WRITE_SIZE")
     prefix = sys.argv[3]
@@ -69,7 +92,9 @@ def main():
         wr.writeheader()
         for r in rows:
             wr.writerow({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()})
-    json.dump({"note": __doc__.split("writes")[1].strip(), "kernels": {r["kernel"]: r for r in rows[:12]}},
+    for r in rows:          # GB/s against the 8 TB/s HBM peak, from the (PMC-slowed) durations of the same pass
+        r["hbm_gbps_under_pmc"] = r["hbm_bytes_per_launch_corrected"] / max(r["avg_us_under_pmc"], 1e-9) / 1e3
+    json.dump({"note": __doc__.split("writes")[1].strip(), "kernels": {r["kernel"]: r for r in rows[:24]}},
               open(prefix + "_summary.json", "w"), indent=1)
     for r in rows[:10]:
         print("%-64s x%-5d fetch %9.0f KiB  write %9.0f KiB  -> %7.1f MB/launch" % (

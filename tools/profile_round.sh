@@ -1,18 +1,28 @@
 #!/bin/bash
 # One pass of everything profiles/ needs, on the GPU box (run through gpurun; every step under its own timeout):
-#   tools/profile_round.sh <tag>      e.g. r01  ->  gpurun_out/<tag>/...
-# 1. pytest -m gpu   2. __graft_entry__.smoke()   3. bench.py (defaults)   4. rocprofv3 kernel stats of the bench
-# 5. rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: one counter per pass, kernel trace only -- MI355X_MICROARCH.md HBM)
-tag=${1:-r01}
+#   tools/profile_round.sh <tag> [quick]      e.g. r02  ->  gpurun_out/<tag>/...
+# 1. pytest -m gpu   2. __graft_entry__.smoke()   3. bench.py (defaults, incl. CPU baseline unless "quick")
+# 4. rocprofv3 kernel stats of the bench   5. rocprofv3 PMC passes, ONE counter per pass, kernel trace only
+#    (MI355X_MICROARCH.md HBM section): FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE
+#    -> reduce with tools/pmc_summary.py (per kernel family: HBM bytes per launch, MFMA-busy fraction)
+tag=${1:-r02}
+quick=${2:-}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest_gpu.log; tail -2 $out/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
-timeout 400 python bench.py > $out/bench_n1.json 2> $out/bench_n1.err; tail -3 $out/bench_n1.err; cut -c1-260 $out/bench_n1.json
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python bench.py --steps 48 --warmup 40 --no-cpu-baseline --no-roofline > $out/bench_under_rocprof.json 2> $out/prof.err; ls $out/prof | head -3
-# (MFMA-busy: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, again one counter per pass; reduce with
-#  `python tools/pmc_summary.py --counter NAME <csv> profiles/<tag>_<NAME>.csv`)
-for c in FETCH_SIZE WRITE_SIZE ${EXTRA_PMC:-}; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python bench.py --steps 8 --warmup 26 --no-cpu-baseline --no-roofline --no-graphs --no-overlap > $out/pmc_$c.json 2> $out/pmc_$c.err; ls -la $out/pmc_$c | tail -2
+root=$(pwd)
+if [ -z "$quick" ]; then
+  timeout 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest_gpu.log; tail -2 $out/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
+  timeout 900 python bench.py > $out/bench_n1.json 2> $out/bench_n1.err; tail -3 $out/bench_n1.err; cut -c1-260 $out/bench_n1.json
+else
+  timeout 300 python bench.py --no-cpu-baseline > $out/bench_n1.json 2> $out/bench_n1.err; tail -3 $out/bench_n1.err; cut -c1-260 $out/bench_n1.json
+fi
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_n1_driver_cli.json 2> $out/bench_n1_driver_cli.err
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof -o bench -- python $root/bench.py --no-cpu-baseline --no-roofline > $root/$out/bench_under_rocprof.json 2> $root/$out/prof.err); ls $out/prof | head -3
+pmcargs="--steps 10 --warmup 5 --no-cpu-baseline --no-roofline --no-graphs --no-overlap --min-seconds 0.01 --max-blocks 1"
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ${EXTRA_PMC:-}; do
+  (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/$out/pmc_$c -o pmc -- python $root/bench.py $pmcargs > $root/$out/pmc_$c.json 2> $root/$out/pmc_$c.err); ls -la $out/pmc_$c | tail -1
 done
+# keep only what the reducers need (the kernel-trace CSVs are large)
+rm -f $out/pmc_*/pmc_kernel_trace.csv $out/prof/bench_kernel_trace.csv
