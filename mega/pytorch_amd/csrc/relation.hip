@@ -443,10 +443,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         pe[0] = pw.x; pe[1] = pw.y; pe[2] = pw.z; pe[3] = pw.w;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = k0 + 8 * rq + 4 * h2 + e;
-        const float v = st[4 * rq + e] * p.scale + pe[e];
-        s[4 * rq + e] = key < p.Nk ? v : -INFINITY;
+      for (int e = 0; e < 4; ++e) s[4 * rq + e] = st[4 * rq + e] * p.scale + pe[e];
+    }
+    if (k0 + 32 > p.Nk) {        // only the last tile of the key range has keys to mask (wave-uniform branch)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + 8 * (r >> 2) + 4 * h2 + (r & 3);
+        s[r] = key < p.Nk ? s[r] : -INFINITY;
       }
     }
     float mt = s[0];
@@ -466,16 +469,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     l_run = l_run * alpha + psum;
     m_run = m_new;
 
-    // ---- rescale O: alpha is per query (lane&31) but O rows are (r&3)+8*(r>>2)+4*h2 -> exchange through LDS
-    if (h2 == 0) sRow[wave][l31] = alpha;
-    __builtin_amdgcn_wave_barrier();
+    // ---- rescale O: alpha is per query (lane&31) but O rows are (r&3)+8*(r>>2)+4*h2 -> exchange through LDS.
+    //      Skipped (exactly: every alpha is 1) when no query of this wave saw a larger maximum in this tile, which
+    //      is the common case once the first few tiles have been seen (wave-uniform branch).
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+      if (h2 == 0) sRow[wave][l31] = alpha;
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const float4 a4 = *reinterpret_cast<const float4*>(&sRow[wave][8 * rq + 4 * h2]);
-      o0[4 * rq + 0] *= a4.x; o0[4 * rq + 1] *= a4.y; o0[4 * rq + 2] *= a4.z; o0[4 * rq + 3] *= a4.w;
-      o1[4 * rq + 0] *= a4.x; o1[4 * rq + 1] *= a4.y; o1[4 * rq + 2] *= a4.z; o1[4 * rq + 3] *= a4.w;
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&sRow[wave][8 * rq + 4 * h2]);
+        o0[4 * rq + 0] *= a4.x; o0[4 * rq + 1] *= a4.y; o0[4 * rq + 2] *= a4.z; o0[4 * rq + 3] *= a4.w;
+        o1[4 * rq + 0] *= a4.x; o1[4 * rq + 1] *= a4.y; o1[4 * rq + 2] *= a4.z; o1[4 * rq + 3] *= a4.w;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
 
     // ---- O[q][dv] += sum_key P[q][key] * V[key][dv]
     const unsigned char* vb0 = &Vs[cur][l31 * C::VROW];

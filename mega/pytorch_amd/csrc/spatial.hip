@@ -300,108 +300,118 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __rest
 }
 
 
-// bf16-mode variant with SEPARABLE weights.  A bin's value is (1/count) sum over its grid_h x grid_w samples of the
-// bilinear blend of 4 pixels; the blend weights factor into (hy | ly) x (hx | lx), so the bin equals
-//   (1/count) sum_y sum_x Wy[y] Wx[x] f(y, x),   Wy[y] = sum of hy over samples whose lower row is y + ly over those
-// whose upper row is y (same for x).  Adjacent samples are at most one pixel apart (grid = ceil(roi / bins)), so the
-// touched pixels form a dense (<= grid_h + 1) x (<= grid_w + 1) patch: 16 loads instead of 36 for a 3 x 3 grid,
-// 49 instead of 144 for 6 x 6.  The kernel is bound by L1/L2 tap traffic (PMC: 27 GB of loads per 20-frame batch),
-// so fewer taps is the lever.  The sum is re-associated, hence bf16 mode only: the exact-f32 path keeps the
-// reference's term order (roi_align_nhwc_vec_kernel).
+// bf16-mode variant with SEPARABLE weights, computed ONCE per block.  A bin's value is (1/count) sum over its
+// grid_h x grid_w samples of the bilinear blend of 4 pixels; the blend weights factor into (hy | ly) x (hx | lx), so
+//   bin = (1/count) sum_y sum_x Wy[y] Wx[x] f(y, x),   Wy[y] = sum of hy over samples whose lower row is y + ly over
+// those whose upper row is y (same for x).  Adjacent samples are at most one pixel apart (grid = ceil(roi / bins)), so
+// the touched pixels form a dense (<= grid_h + 1) x (<= grid_w + 1) patch: 16 loads instead of 36 for a 3 x 3 grid.
+// The per-lane form of this kernel is VALU-bound on the sample-position arithmetic that all 64 lanes of a wave (the
+// channel vectors of one bin) repeat identically (~1400 VALU instructions per output vector).  Here a block owns one
+// ROW of bins of one ROI (pooled_w bins, all channels): one wave's lanes build the row's Wy and the pooled_w Wx tables
+// in LDS, then every thread only does (load, 8 fma) per patch pixel with broadcast LDS reads of the weights.
+// The sum is re-associated, hence bf16 mode only: the exact-f32 path keeps the reference's term order
+// (roi_align_nhwc_vec_kernel).
+constexpr int RS_MAXP = 10;     // patch rows / columns (grid <= 9)
+constexpr int RS_MAXPW = 8;     // pooled_w <= 8
+
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_nhwc_sep_kernel(const T* __restrict__ feat,
                                                                  const float* __restrict__ rois, T* __restrict__ out,
                                                                  int K, int C, int H, int W, float spatial_scale,
                                                                  int PH, int PW, int sampling_ratio) {
   constexpr int VE = Elem<T>::VE;
-  constexpr int MAXP = 10;                                 // patch columns kept in registers (grid <= 9)
+  __shared__ float s_wy[RS_MAXP];
+  __shared__ float s_wx[RS_MAXPW][RS_MAXP];
+  __shared__ int s_y[2];                    // first row, number of rows
+  __shared__ int s_x[RS_MAXPW][2];          // per bin: first column, number of columns
   const int CV = C / VE;
-  const long long total = (long long)K * PH * PW * CV;
-  for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
-       item += (long long)gridDim.x * blockDim.x) {
-    const int cv = (int)(item % CV);
-    const int bin = (int)(item / CV);
-    const int pw = bin % PW;
-    const int ph = (bin / PW) % PH;
-    const int k = bin / (PW * PH);
-    const float* roi = rois + (size_t)k * 5;
-    const int b = (int)roi[0];
-    const float roi_start_w = roi[1] * spatial_scale;
-    const float roi_start_h = roi[2] * spatial_scale;
-    const float roi_end_w = roi[3] * spatial_scale;
-    const float roi_end_h = roi[4] * spatial_scale;
-    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.f);
-    const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.f);
-    const float bin_size_h = roi_height / (float)PH;
-    const float bin_size_w = roi_width / (float)PW;
-    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)PH);
-    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)PW);
-    const float count = (float)(grid_h * grid_w);
-    // one axis sample -> (low index, high index, weight of low, weight of high); weights 0 when the sample is skipped
-    auto axis = [](float p, int n, int& lo, int& hi, float& wl, float& wh) {
-      if (p < -1.0f || p > (float)n) { lo = hi = 0; wl = wh = 0.f; return; }
-      if (p <= 0.f) p = 0.f;
-      lo = (int)p;
-      if (lo >= n - 1) { hi = lo = n - 1; p = (float)lo; } else { hi = lo + 1; }
-      wh = p - (float)lo;
-      wl = 1.f - wh;
-    };
-    // column patch: first touched column and the per-column weights (static register indices)
-    int x_first = W, x_last = -1;
-    for (int ix = 0; ix < grid_w; ++ix) {
+  const int k = blockIdx.x / PH, ph = blockIdx.x - k * PH;
+  const float* roi = rois + (size_t)k * 5;
+  const int b = (int)roi[0];
+  const float roi_start_w = roi[1] * spatial_scale;
+  const float roi_start_h = roi[2] * spatial_scale;
+  const float roi_end_w = roi[3] * spatial_scale;
+  const float roi_end_h = roi[4] * spatial_scale;
+  const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.f);
+  const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.f);
+  const float bin_size_h = roi_height / (float)PH;
+  const float bin_size_w = roi_width / (float)PW;
+  const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)PH);
+  const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)PW);
+  const float count = (float)(grid_h * grid_w);
+  // one axis sample -> (low index, high index, weight of low, weight of high); weights 0 when the sample is skipped
+  auto axis = [](float p, int n, int& lo, int& hi, float& wl, float& wh) {
+    if (p < -1.0f || p > (float)n) { lo = hi = 0; wl = wh = 0.f; return; }
+    if (p <= 0.f) p = 0.f;
+    lo = (int)p;
+    if (lo >= n - 1) { hi = lo = n - 1; p = (float)lo; } else { hi = lo + 1; }
+    wh = p - (float)lo;
+    wl = 1.f - wh;
+  };
+  // weight of index `idx` along one axis of one bin, and the touched index range
+  auto table = [&](float start, float bin_size, int bin_index, int grid, int n, int slot, int& first, int& cnt) {
+    int f = n, l = -1;
+    for (int i = 0; i < grid; ++i) {
       int lo, hi; float wl, wh;
-      axis(roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)grid_w, W, lo, hi, wl, wh);
-      if (wl + wh > 0.f) { x_first = min(x_first, lo); x_last = max(x_last, hi); }
+      axis(start + bin_index * bin_size + (i + .5f) * bin_size / (float)grid, n, lo, hi, wl, wh);
+      if (wl + wh > 0.f) { f = min(f, lo); l = max(l, hi); }
     }
-    float wx[MAXP];
-#pragma unroll
-    for (int c = 0; c < MAXP; ++c) wx[c] = 0.f;
-    for (int ix = 0; ix < grid_w; ++ix) {
+    float w = 0.f;
+    for (int i = 0; i < grid; ++i) {
       int lo, hi; float wl, wh;
-      axis(roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)grid_w, W, lo, hi, wl, wh);
-#pragma unroll
-      for (int c = 0; c < MAXP; ++c) {
-        if (lo - x_first == c) wx[c] += wl;
-        if (hi - x_first == c) wx[c] += wh;
-      }
+      axis(start + bin_index * bin_size + (i + .5f) * bin_size / (float)grid, n, lo, hi, wl, wh);
+      if (lo - f == slot) w += wl;
+      if (hi - f == slot) w += wh;
     }
-    int y_first = H, y_last = -1;
-    for (int iy = 0; iy < grid_h; ++iy) {
-      int lo, hi; float wl, wh;
-      axis(roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)grid_h, H, lo, hi, wl, wh);
-      if (wl + wh > 0.f) { y_first = min(y_first, lo); y_last = max(y_last, hi); }
-    }
-    const T* base = feat + (size_t)b * H * W * C + (size_t)cv * VE;
-    float acc[VE];
+    first = f;
+    cnt = l - f + 1;
+    return w;
+  };
+  const int tid = threadIdx.x;
+  if (tid < RS_MAXP) {
+    int first, cnt;
+    s_wy[tid] = table(roi_start_h, bin_size_h, ph, grid_h, H, tid, first, cnt);
+    if (tid == 0) { s_y[0] = first; s_y[1] = cnt; }
+  } else if (tid >= 64 && tid < 64 + PW * RS_MAXP) {
+    const int pw = (tid - 64) / RS_MAXP, slot = (tid - 64) - pw * RS_MAXP;
+    int first, cnt;
+    s_wx[pw][slot] = table(roi_start_w, bin_size_w, pw, grid_w, W, slot, first, cnt);
+    if (slot == 0) { s_x[pw][0] = first; s_x[pw][1] = cnt; }
+  }
+  __syncthreads();
+  const int y_first = s_y[0], nrow = s_y[1];
+  const float inv_count = 1.f / count;
+  const T* fb = feat + (size_t)b * H * W * C;
+  for (int pw = 0; pw < PW; ++pw) {
+    const int x_first = s_x[pw][0], ncol = s_x[pw][1];
+    for (int cv = tid; cv < CV; cv += 256) {
+      float acc[VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
-    const int ncol = x_last - x_first + 1;
-    for (int y = y_first; y <= y_last; ++y) {
-      float wy = 0.f;
-      for (int iy = 0; iy < grid_h; ++iy) {
-        int lo, hi; float wl, wh;
-        axis(roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)grid_h, H, lo, hi, wl, wh);
-        if (lo == y) wy += wl;
-        if (hi == y) wy += wh;
-      }
-      if (wy == 0.f) continue;
-      const T* rowp = base + ((size_t)y * W + x_first) * C;
+      for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+      for (int r = 0; r < nrow; ++r) {
+        const float wy = s_wy[r];
+        if (wy == 0.f) continue;
+        const T* rowp = fb + ((size_t)(y_first + r) * W + x_first) * C + (size_t)cv * VE;
+        uint4 rv[RS_MAXP];                    // the whole patch row is requested before the first FMA (ncol is
+#pragma unroll                                // block-uniform: scalar branches, up to 10 loads in flight per lane)
+        for (int c = 0; c < RS_MAXP; ++c)
+          if (c < ncol) rv[c] = *reinterpret_cast<const uint4*>(rowp + (size_t)c * C);
 #pragma unroll
-      for (int c = 0; c < MAXP; ++c) {
-        if (c < ncol) {
-          const uint4 r = *reinterpret_cast<const uint4*>(rowp + (size_t)c * C);
-          const T* ev = reinterpret_cast<const T*>(&r);
-          const float wgt = wy * wx[c];
+        for (int c = 0; c < RS_MAXP; ++c) {
+          if (c < ncol) {
+            const T* ev = reinterpret_cast<const T*>(&rv[c]);
+            const float wgt = wy * s_wx[pw][c];
 #pragma unroll
-          for (int e = 0; e < VE; ++e) acc[e] = fmaf(wgt, Elem<T>::ld(ev + e), acc[e]);
+            for (int e = 0; e < VE; ++e) acc[e] = fmaf(wgt, Elem<T>::ld(ev + e), acc[e]);
+          }
         }
       }
-    }
-    uint4 o;
-    T* oe = reinterpret_cast<T*>(&o);
+      uint4 o;
+      T* oe = reinterpret_cast<T*>(&o);
 #pragma unroll
-    for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] / count);
-    *reinterpret_cast<uint4*>(out + (size_t)bin * C + (size_t)cv * VE) = o;
+      for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] * inv_count);
+      *reinterpret_cast<uint4*>(out + ((size_t)(k * PH + ph) * PW + pw) * C + (size_t)cv * VE) = o;
+    }
   }
 }
 
@@ -567,11 +577,10 @@ extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out
     static const bool no_sep = getenv("MEGA_ROI_NO_SEPARABLE") != nullptr;         // A/B switch (experiments)
     // grid = ceil(roi / bins) <= ceil(max(H, W) / min(ph, pw)): the register patch of the separable form holds 10 columns
     const int max_grid = sampling_ratio > 0 ? sampling_ratio : (max(H, W) + min(pooled_h, pooled_w) - 1) / min(pooled_h, pooled_w);
-    if (dtype == MEGA_BF16 && !no_sep && max_grid <= 9) {
-      long long nb2 = (total + 255) / 256;
-      if (nb2 > 1048576) nb2 = 1048576;
-      hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<bf16_t>), dim3((unsigned)nb2), dim3(256), 0, st, (const bf16_t*)feat,
-                         rois, (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+    if (dtype == MEGA_BF16 && !no_sep && max_grid <= 9 && pooled_w <= RS_MAXPW) {
+      hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<bf16_t>), dim3((unsigned)(K * pooled_h)), dim3(256), 0, st,
+                         (const bf16_t*)feat, rois, (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w,
+                         sampling_ratio);
       return mega_check_launch();
     }
     if (dtype == MEGA_BF16 && sliced)
