@@ -12,18 +12,20 @@
 //   half-tiles: A0 = rows 0..127, A1 = rows 128..BM-1, B0 = cols 0..127, B1 = cols 128..255 (16 KiB each);
 //   wave (wr, wc) of a 2 x 4 grid owns, in every (Ai, Bj) quadrant of the tile, a 64(32) x 32 piece:
 //     rows i*128 + wr*64 + [0,64)   (A1 with MF1 = 1: 128 + wr*32 + [0,32)),   cols j*128 + wc*32 + [0,32).
-//   A K-tile is processed in 4 phases (A0,B0) (A0,B1) (A1,B1) (A1,B0); each half-tile is read from LDS exactly once
-//   per K-tile (phases 0,0,1,2), the fragments stay in registers for the second quadrant that uses them.
+//   A K-tile is processed in 2 phases, A0 x (B0,B1) then A1 x (B1,B0); each half-tile is read from LDS exactly once
+//   per K-tile, the B fragments stay in registers for the second phase.
 // LDS (128 KiB): [A0 A1 B0 B1][parity 2][128 rows][128 B].  A row's eight 16-byte chunks are stored XOR-swizzled
 //   (physical chunk = logical chunk ^ ((row >> 1) & 7)): every 16-lane group of a ds_read_b128 then touches 16
 //   different bank quads.  The DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address;
 //   the eight lanes of a row still read one whole 128-byte line.
-// Pipeline.  Half-tiles are issued in the order of use A0(t) B0(t) B1(t) A1(t) A0(t+1) ..., one per phase, six
-//   half-tiles ahead of the phase that issues (1.5 K-tiles: > 2000 cycles).  A slot is re-filled two or three phases
-//   after its last ds_read.  Every phase = [load segment: ds_reads of this phase, DMA issue, counted vmcnt] barrier
-//   [MFMA segment] barrier; wave group 1 (waves 4-7, one per SIMD like group 0) runs one barrier behind group 0.
+// Pipeline.  Half-tiles are issued in the order of use A0(t) B0(t) B1(t) A1(t) A0(t+1) ..., three phases (1.5
+//   K-tiles: > 2000 cycles) ahead of the phase that reads them.  A slot is re-filled one or two phases after its
+//   last ds_read.  Every phase = [load segment: ds_reads of this phase, counted vmcnt] barrier
+//   [MFMA segment with the phase's two DMA issues in the MFMA shadow] barrier; wave group 1 (waves 4-7, one per SIMD like group 0) runs one barrier behind group 0.
 //   RAW: the wait that retires a half-tile sits before the barrier that ends the phase BEFORE the one that reads it
 //   (for both groups); WAR: see the schedule table in DESIGN.md section 3.
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -47,7 +49,9 @@ struct KPos {
   unsigned uni;                        // ((dh * W + dw) * Cin + kc) * 2 bytes
 };
 
-template <typename OT, int MF1>
+// ABL != 0: timing-only ablations for tools/gpu (1: no fragment ds_reads in the loop, 2: no DMA in the loop, 3: no MFMA);
+// results are garbage by construction.
+template <typename OT, int MF1, int ABL = 0>
 __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   constexpr int BM = 128 + 64 * MF1;
   constexpr int BN = 256;
@@ -136,25 +140,30 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   unsigned char* const wbase = smem + wave * 1024;
   // `live` = the tile exists (tiles past the end of K are still "issued", with every lane out of range: the DMA
   // writes zeros into a dead slot and the vmcnt bookkeeping stays uniform).  Pure data flow, no branches.
-  auto issue_A = [&](int i, int par, const KPos& s, bool live) {
+  bool in_loop = false;
+  auto issue_A1 = [&](int i, int u, int par, const KPos& s, bool live) {     // one 1-KiB piece per wave
+    if (ABL == 2 && in_loop) return;
     const unsigned dead = live ? 0u : OOB;
-#pragma unroll
-    for (int u = 0; u < (i == 1 ? CA1 : 2); ++u) {
-      const int r = i * 2 + u;
-      const int hi = a_hi0[r] + s.dh, wi = a_wi0[r] + s.dw;
-      const bool ok = ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-      const unsigned off = (ok ? a_off[r] + s.uni : OOB) | dead;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(wbase + slot_a(i, par) + u * 8192), 16, off, 0, 0, 0);
-    }
+    const int r = i * 2 + u;
+    const int hi = a_hi0[r] + s.dh, wi = a_wi0[r] + s.dw;
+    const bool ok = ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+    const unsigned off = (ok ? a_off[r] + s.uni : OOB) | dead;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(wbase + slot_a(i, par) + u * 8192), 16, off, 0, 0, 0);
   };
-  auto issue_B = [&](int j, int par, int tile, bool live) {
+  auto issue_B1 = [&](int j, int u, int par, int tile, bool live) {
+    if (ABL == 2 && in_loop) return;
     const unsigned dead = live ? 0u : OOB;
     const unsigned kb = (unsigned)((kt0 + tile) * 128);
+    const unsigned off = (b_off[j * 2 + u] + kb) | dead;         // b_off = OOB for rows past Cout: stays out of range
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wbase + slot_b(j, par) + u * 8192), 16, off, 0, 0, 0);
+  };
+  auto issue_A = [&](int i, int par, const KPos& s, bool live) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const unsigned off = (b_off[j * 2 + u] + kb) | dead;       // b_off = OOB for rows past Cout: stays out of range
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wbase + slot_b(j, par) + u * 8192), 16, off, 0, 0, 0);
-    }
+    for (int u = 0; u < (i == 1 ? CA1 : 2); ++u) issue_A1(i, u, par, s, live);
+  };
+  auto issue_B = [&](int j, int par, int tile, bool live) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) issue_B1(j, u, par, tile, live);
   };
 
   // ---- fragment read addresses (bytes inside a half-tile slot): row (lane & 31) of the wave's piece, K step ks:
@@ -184,7 +193,21 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   // not know these are asynchronous, so each batch is followed (after the barrier) by an explicit lgkmcnt(0) and a
   // scheduling barrier before the first MFMA that consumes it.
   u32x4_t af[2][4], b0f[4], b1f[4];
-#define MEGA_LDS_RD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+  // ABL == 4: s_memtime stamps of block 0 at every segment boundary (timeline experiments, tools/gpu/ablate8.py)
+  __shared__ unsigned long long tr_buf[ABL == 4 ? 8 * 96 : 1];
+  int tr_n = 0;
+#define MEGA_STAMP()                                                                                   \
+  do {                                                                                                 \
+    if (ABL == 4 && blockIdx.x == 0 && tr_n < 96) {                                                    \
+      const unsigned long long tt = __builtin_amdgcn_s_memtime();                                      \
+      if (lane == 0) tr_buf[wave * 96 + tr_n] = tt;                                                    \
+      ++tr_n;                                                                                          \
+    }                                                                                                  \
+  } while (0)
+#define MEGA_LDS_RD(dst, addr, imm)                                                                          \
+  do {                                                                                                       \
+    if (ABL != 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory"); \
+  } while (0)
 #define MEGA_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MEGA_WAIT_LDS()                                   \
   do {                                                    \
@@ -197,97 +220,121 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     __builtin_amdgcn_s_barrier();     \
     asm volatile("" ::: "memory");   \
   } while (0)
-#define MEGA_MMA(acc_, a_, b_) \
-  acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a_), __builtin_bit_cast(bf16x8_t, b_), acc_, 0, 0, 0)
-  constexpr int VMW = 6 + CA1;         // loads that may stay in flight at the end of a load segment (see header)
+#define MEGA_MMA(acc_, a_, b_)                                                                                          \
+  do {                                                                                                                  \
+    if (ABL != 3)                                                                                                       \
+      acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a_), __builtin_bit_cast(bf16x8_t, b_), \
+                                                     acc_, 0, 0, 0);                                                    \
+    else                                                                                                                \
+      asm volatile("" ::"v"(a_), "v"(b_));                                                                              \
+  } while (0)
 
-  // ---- prologue: six half-tiles
+  // ---- prologue: six half-tiles in the steady-state issue order
   issue_A(0, 0, pa0, ta0 < nkt); kpos_next(pa0); ++ta0;
   issue_B(0, 0, tb0, tb0 < nkt); ++tb0;
   issue_B(1, 0, tb1, tb1 < nkt); ++tb1;
   issue_A(1, 0, pa1, ta1 < nkt); kpos_next(pa1); ++ta1;
   issue_A(0, 1, pa0, ta0 < nkt); kpos_next(pa0); ++ta0;
   issue_B(0, 1, tb0, tb0 < nkt); ++tb0;
-  MEGA_WAIT_VM(VMW);
+  MEGA_WAIT_VM(4 + CA1);               // A0(0) B0(0) B1(0) have landed
+  in_loop = true;
+  if (ABL == 1) {                      // the ablation reads its fragments once
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(af[0][ks]) : "v"(a_rd[ks]) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[1][ks]) : "v"(a_rd[ks]) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(b0f[ks]) : "v"(b_rd[ks]) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:32768" : "=v"(b1f[ks]) : "v"(b_rd[ks]) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   MEGA_BAR();
   if (wr == 1) MEGA_BAR();             // group 1 runs one barrier behind group 0
 
+  // Two phases per K-tile: (a) A0 x (B0, B1) = 16 MFMAs, (b) A1 x (B0, B1) = 8 MF1 MFMAs.  Timeline measurements
+  // (s_memtime stamps, tools/gpu/ablate8.py): the waves never wait for DMA data; what stretches a K-tile beyond its
+  // 2048 MFMA cycles is the ISSUE time of the load-side instructions -- an LDS-DMA costs ~110 cycles in a segment
+  // with ds_reads and ~45 in the shadow of MFMAs, a fragment ds_read ~20 -- so the 8 DMA pieces of a K-tile are spread
+  // over all four segments so that each interval's two concurrent segments (one group's MFMA cluster, the other's
+  // load segment) are as even as the hazards allow.  Per wave and K-tile t (parity t & 1):
+  //   L(a,t): 16 fragment reads, B1(t+1) x2          M(a,t): 16 MFMAs
+  //   L(b,t):  8 fragment reads, A1(t+1) x CA1       M(b,t): 16 MFMAs with A0(t+2) x2, B0(t+2) x2 in their shadow
+  //   WAR: a slot is refilled at the earliest from the MFMA segment of the phase AFTER its last read (both groups'
+  //        reads are retired by their lgkmcnt(0) at least one barrier before any wave issues that DMA);
+  //   RAW: L(a,t) waits for A1(t) [6 newer DMAs in flight], L(b,t) for A0 B0 B1 (t+1) [CA1 newer], each one barrier
+  //        before the first wave reads them; every half-tile is issued >= 2 segments before the wait that retires it.
+#define MEGA_SB() __builtin_amdgcn_sched_barrier(0)
   auto tile_phases = [&](auto PAR) {
     constexpr int par = decltype(PAR)::value;
-    // ================= phase 0: (A0, B0)
+    // ================= phase a: A0 x (B0, B1)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       MEGA_LDS_RD(af[0][ks], a_rd[ks], slot_a(0, par));
       MEGA_LDS_RD(af[1][ks], a_rd[ks], slot_a(0, par) + 32 * ROWB);
       MEGA_LDS_RD(b0f[ks], b_rd[ks], slot_b(0, par) - 4 * HALF);
+      MEGA_LDS_RD(b1f[ks], b_rd[ks], slot_b(1, par) - 4 * HALF);
     }
-    issue_B(1, par ^ 1, tb1, tb1 < nkt); ++tb1;
-    MEGA_WAIT_VM(VMW);
+    issue_B1(1, 0, par ^ 1, tb1, tb1 < nkt); issue_B1(1, 1, par ^ 1, tb1, tb1 < nkt); ++tb1;
+    MEGA_STAMP();
+    MEGA_WAIT_VM(6);
+    MEGA_STAMP();
     MEGA_BAR();
+    MEGA_STAMP();
     MEGA_WAIT_LDS();
+    MEGA_STAMP();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      MEGA_MMA(acc[0][0][0], af[0][ks], b0f[ks]);
-      MEGA_MMA(acc[0][1][0], af[1][ks], b0f[ks]);
+      MEGA_MMA(acc[0][0][0], af[0][ks], b0f[ks]); MEGA_MMA(acc[0][1][0], af[1][ks], b0f[ks]);
+      MEGA_MMA(acc[0][0][1], af[0][ks], b1f[ks]); MEGA_MMA(acc[0][1][1], af[1][ks], b1f[ks]);
     }
     __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    MEGA_SB();
+    MEGA_STAMP();
     MEGA_BAR();
-    // ================= phase 1: (A0, B1)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) MEGA_LDS_RD(b1f[ks], b_rd[ks], slot_b(1, par) - 4 * HALF);
-    issue_A(1, par ^ 1, pa1, ta1 < nkt); kpos_next(pa1); ++ta1;
-    MEGA_WAIT_VM(VMW);
-    MEGA_BAR();
-    MEGA_WAIT_LDS();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      MEGA_MMA(acc[0][0][1], af[0][ks], b1f[ks]);
-      MEGA_MMA(acc[0][1][1], af[1][ks], b1f[ks]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    MEGA_BAR();
-    // ================= phase 2: (A1, B1)
+    MEGA_STAMP();
+    // ================= phase b: A1 x (B1, B0)  -- the B fragments are still in registers
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       MEGA_LDS_RD(af[0][ks], a1_rd[ks], slot_a(1, par));
       if (MF1 == 2) MEGA_LDS_RD(af[1][ks], a1_rd[ks], slot_a(1, par) + 32 * ROWB);
     }
-    issue_A(0, par, pa0, ta0 < nkt); kpos_next(pa0); ++ta0;
+    issue_A1(1, 0, par ^ 1, pa1, ta1 < nkt);
+    if (CA1 == 2) issue_A1(1, 1, par ^ 1, pa1, ta1 < nkt);
+    kpos_next(pa1); ++ta1;
+    MEGA_STAMP();
+    MEGA_WAIT_VM(CA1);
+    MEGA_STAMP();
     MEGA_BAR();
+    MEGA_STAMP();
     MEGA_WAIT_LDS();
+    MEGA_STAMP();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      MEGA_MMA(acc[1][0][1], af[0][ks], b1f[ks]);
-      if (MF1 == 2) MEGA_MMA(acc[1][1][1], af[1][ks], b1f[ks]);
+      MEGA_MMA(acc[1][0][1], af[0][ks], b1f[ks]); if (MF1 == 2) MEGA_MMA(acc[1][1][1], af[1][ks], b1f[ks]);
+      MEGA_MMA(acc[1][0][0], af[0][ks], b0f[ks]); if (MF1 == 2) MEGA_MMA(acc[1][1][0], af[1][ks], b0f[ks]);
+      MEGA_SB();
+      if (ks == 0) issue_A1(0, 0, par, pa0, ta0 < nkt);
+      if (ks == 1) { issue_A1(0, 1, par, pa0, ta0 < nkt); kpos_next(pa0); ++ta0; issue_B1(0, 0, par, tb0, tb0 < nkt); }
+      if (ks == 2) { issue_B1(0, 1, par, tb0, tb0 < nkt); ++tb0; }
+      MEGA_SB();
     }
     __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    MEGA_SB();
+    MEGA_STAMP();
     MEGA_BAR();
-    // ================= phase 3: (A1, B0)  -- both operands are still in registers
-    issue_B(0, par, tb0, tb0 < nkt); ++tb0;
-    MEGA_WAIT_VM(VMW);
-    MEGA_BAR();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      MEGA_MMA(acc[1][0][0], af[0][ks], b0f[ks]);
-      if (MF1 == 2) MEGA_MMA(acc[1][1][0], af[1][ks], b0f[ks]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    MEGA_BAR();
+    MEGA_STAMP();
   };
 
   const int nkt2 = (nkt + 1) & ~1;     // an odd tail tile is computed on all-zero operands (its DMAs are out of range)
   for (int t = 0; t < nkt2; t += 2) {
     tile_phases(std::integral_constant<int, 0>{});
     tile_phases(std::integral_constant<int, 1>{});
+  }
+  if (ABL == 4 && blockIdx.x == 0 && p.partial) {
+    __syncthreads();
+    for (int e = tid; e < 8 * 96; e += NT8) reinterpret_cast<unsigned long long*>(p.partial)[e] = tr_buf[e];
   }
   if (wr == 0) MEGA_BAR();             // group 0 waits for group 1's last MFMA segment
   MEGA_WAIT_VM(0);                     // the out-of-range tail DMAs also write (zeros) into the LDS re-used below
@@ -400,15 +447,17 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #undef MEGA_WAIT_LDS
 #undef MEGA_BAR
 #undef MEGA_MMA
+#undef MEGA_SB
+#undef MEGA_STAMP
 }
 
-template <typename OT, int MF1>
+template <typename OT, int MF1, int ABL = 0>
 int launch8(const ConvParams& p, hipStream_t st) {
   constexpr int BM = 128 + 64 * MF1;
   const int ntm = cdiv(p.M, BM), ntn = cdiv(p.Cout, 256);
   // set on every launch (a per-process flag would miss the second device of a multi-GPU process)
-  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
-  hipLaunchKernelGGL((igemm8_kernel<OT, MF1>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8, st, p);
+  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+  hipLaunchKernelGGL((igemm8_kernel<OT, MF1, ABL>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8, st, p);
   return mega_check_launch();
 }
 
@@ -419,6 +468,36 @@ int mega_igemm8_supports(const ConvParams& p) {
 }
 
 int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st) {
+  static const int abl = getenv("MEGA_IGEMM8_ABLATE") ? atoi(getenv("MEGA_IGEMM8_ABLATE")) : 0;   // timing experiments only
+  if (abl && bm == 256 && !out_f32) {
+    if (abl == 1) return launch8<bf16_t, 2, 1>(p, st);
+    if (abl == 2) return launch8<bf16_t, 2, 2>(p, st);
+    if (abl == 3) return launch8<bf16_t, 2, 3>(p, st);
+    if (abl == 4) {          // timeline of block 0: 12 stamps per K-tile per wave, first 8 K-tiles
+      static unsigned long long* d_tr = nullptr;
+      if (!d_tr) (void)hipMalloc(&d_tr, 8 * 96 * sizeof(unsigned long long));
+      ConvParams q = p;
+      q.partial = reinterpret_cast<float*>(d_tr);
+      const int rc = launch8<bf16_t, 2, 4>(q, st);
+      (void)hipStreamSynchronize(st);
+      static unsigned long long h[8 * 96];
+      (void)hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost);
+      static int printed = 0;
+      if (printed++ == 2) {    // third launch: warm
+        const char* names[12] = {"a:reads", "a:vmcnt", "a:bar", "a:lgkm", "a:mfma", "a:bar2", "b:reads", "b:vmcnt", "b:bar", "b:lgkm", "b:mfma", "b:bar2"};
+        for (int w = 0; w < 8; w += 4) {
+          printf("wave %d (group %d): stamp deltas (100 MHz ticks x? -> raw s_memtime units) over K-tiles 2..5\n", w, w >> 2);
+          for (int t = 2; t < 6; ++t) {
+            printf("  tile %d:", t);
+            for (int e = 0; e < 12; ++e) printf(" %s %llu", names[e], h[w * 96 + t * 12 + e] - h[w * 96 + t * 12 + e - 1]);
+            printf("  | tile total %llu\n", h[w * 96 + t * 12 + 11] - h[w * 96 + (t - 1) * 12 + 11]);
+          }
+        }
+        fflush(stdout);
+      }
+      return rc;
+    }
+  }
   if (bm == 256) return out_f32 ? launch8<float, 2>(p, st) : launch8<bf16_t, 2>(p, st);
   if (bm == 192) return out_f32 ? launch8<float, 1>(p, st) : launch8<bf16_t, 1>(p, st);
   return MEGA_ERR_ARG;
