@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--aggregation", default="batched", choices=["batched", "static", "per-frame"],
                     help="batched (default): the aggregation of a step-batch runs stage by stage over all its key "
                          "frames; static: one hipGraph replay per key frame on fixed-address pools; per-frame: eager steps")
+    ap.add_argument("--ramp", action="store_true",
+                    help="short first / last step-batch inside a timed block (ClipEngine ramp; measured slower: 555 vs 585 FPS)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="steady key frames timed by the CPU baseline (memory full)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed blocks cover at least this long")
     ap.add_argument("--max-blocks", type=int, default=60)
@@ -173,16 +175,16 @@ def main():
     # lengthen it.  Rounded so that the timed region starts on a batch boundary.
     pre = max(args.warmup, afi + 12 + 1, 3 * spb + 1)
     pre = 1 + -(-(pre - 1) // spb) * spb
-    extra_cap = 6 * spb                           # further pre-roll batches if the engine is not yet in steady state
+    extra_cap = 6 * max(spb, K)                   # further pre-roll blocks if the engine is not yet in steady state
     max_blocks = max(1, min(args.max_blocks, -(-1200 // K)))
     prof_steps = 0 if args.no_roofline else 8
-    T = pre + extra_cap + K * max_blocks + prof_steps + 1 + K + 13
+    T = pre + K + extra_cap + K * max_blocks + prof_steps + 1 + K + 13
     clip = make_clip(T, args.height, args.width, device)
     gfor = eng.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
     runner = eng.ClipEngine(model, steps_per_batch=spb, dist_group=group, overlap=not args.no_overlap,
                             graphs=not args.no_graphs, reuse_records=args.reuse_records,
                             static_aggregation=args.aggregation == "static",
-                            batch_aggregation=args.aggregation == "batched")
+                            batch_aggregation=args.aggregation == "batched", ramp=args.ramp)
 
     def barrier():
         torch.cuda.synchronize()
@@ -202,13 +204,21 @@ def main():
     runner.run(clip, T, gfor, first=0, last=1)
     barrier()
     log("cold start done")
-    runner.run(clip, T, gfor, first=1, last=pre)
-    barrier()
-    pos = pre
-    while not runner.steady_state()["steady"] and pos < pre + extra_cap:
-        runner.run(clip, T, gfor, first=pos, last=pos + spb)
+    pos = 1
+    while pos < pre:                       # same call pattern as the timed blocks: the same batch shapes get captured
+        runner.run(clip, T, gfor, first=pos, last=pos + K)
         barrier()
-        pos += spb
+        pos += K
+    prev_stats = None
+    while pos < pre + extra_cap:           # until a whole block runs without an eager batch or a capture
+        before = dict(runner.graph_stats)
+        runner.run(clip, T, gfor, first=pos, last=pos + K)
+        barrier()
+        pos += K
+        after = runner.graph_stats
+        if runner.steady_state()["steady"] and (args.no_graphs or (after["eager"] == before["eager"] and
+                                                                   after["captured"] == before["captured"])):
+            break
     st0 = engine_state()
     log("pre-roll done at key frame %d: %s" % (pos, st0))
     if not st0["steady"]:
@@ -350,7 +360,8 @@ def main():
             "config": {"workload": "MEGA %s-C4, %dx%d frames, 25 local + 10 global frames + 25-frame memory, "
                                    "300 key / 75 ref proposals, 3 attention stages (BASELINE configs[2]%s)"
                                    % (args.arch, args.width, args.height, "" if world == 1 else " sharded = configs[3]"),
-                       "steps_per_batch": args.steps_per_batch, "parallelism": "frame-sharded x%d" % world,
+                       "steps_per_batch": args.steps_per_batch, "batch_sizes_in_a_block": runner.batch_sizes(K),
+                       "parallelism": "frame-sharded x%d" % world,
                        "frame_record_reuse": bool(args.reuse_records),
                        "aggregation": args.aggregation,
                        "pre_roll_key_frames": Wm, "pools_full": bool(st0["pools_full"] and st1["pools_full"]),

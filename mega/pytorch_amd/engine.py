@@ -106,7 +106,7 @@ class KeyFrameShard(object):
 
 class ClipEngine(object):
     def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True, graphs=True, reuse_records=False,
-                 static_aggregation=False, keep_logits=False, batch_aggregation=True):
+                 static_aggregation=False, keep_logits=False, batch_aggregation=True, ramp=False):
         """steps_per_batch: key-frame steps whose frame jobs are computed in one frame-stage batch
         (steady state: 2 frames per step).  dist_group: torch.distributed group to shard the frame stage over
         (None = single process).  overlap: use the two-stream pipeline (see module docstring).
@@ -142,6 +142,11 @@ class ClipEngine(object):
         # (model.step_batch: projections / stage FCs as one GEMM each); off = one model.step() per key frame
         fe = getattr(getattr(getattr(model, "roi_heads", None), "box", None), "feature_extractor", None)
         self.batch_aggregation = batch_aggregation and hasattr(fe, "aggregate_batch")      # (RDN: per-frame steps)
+        # ramp: every run() call is its own pipeline fill / drain (the first batch's frame stage and the last batch's
+        # aggregation have nothing to overlap with).  With ramp=True a call's key frames are split into a SHORT first
+        # and last batch (steps_per_batch // 4) around equal middle batches, so the un-overlapped head and tail shrink
+        # (results are unchanged: every kernel is batch-invariant).  Each distinct batch size is its own hipGraph.
+        self.ramp = ramp
         self.keep_logits = keep_logits    # tests: logits_log[i] = predictor class logits of the i-th key frame stepped
         self.logits_log = []
         self.key_boxes_log = []           # and the key frame's proposal boxes (rows of logits_log[i])
@@ -181,6 +186,20 @@ class ClipEngine(object):
         return {"pools_full": bool(full), "graphs_warm": bool(warm), "steady": bool(full and warm)}
 
     # ------------------------------------------------------------------ schedule
+    def batch_sizes(self, n):
+        """Key frames per batch for a run() call of n (non-cold-start) key frames."""
+        spb = self.steps_per_batch
+        if n <= 0:
+            return []
+        if not self.ramp or n <= spb:
+            return [spb] * (n // spb) + ([n % spb] if n % spb else [])
+        r = max(1, spb // 4)
+        tail = r if n - r > r else 0
+        mid = n - r - tail
+        k = -(-mid // spb)
+        sizes = [r] + [mid // k + (1 if i < mid % k else 0) for i in range(k)] + ([tail] if tail else [])
+        return [x for x in sizes if x > 0]
+
     def jobs_for_step(self, idx, T, gfor):
         """[(frame_id, want, role)] consumed by key frame idx, in consumption order."""
         m = self.model
@@ -335,10 +354,12 @@ class ClipEngine(object):
             sB.wait_stream(cur)
         batches = []
         idx = first
-        while idx < last:
-            hi = min(last, idx + (1 if idx == 0 else self.steps_per_batch))
-            batches.append((idx, hi))
-            idx = hi
+        if idx == 0 and idx < last:           # the cold start (13 local + GLOBAL.SIZE global frames) is its own batch
+            batches.append((0, 1))
+            idx = 1
+        for n in self.batch_sizes(last - idx):
+            batches.append((idx, idx + n))
+            idx += n
         out = []
         pp = m.roi_heads.box.post_processor
 
@@ -393,7 +414,8 @@ class ClipEngine(object):
                     take = take + [take[-1]] * (n - len(take))      # end of the plan: repeat (result ignored)
                     launches = [[(f, m.key_num, "l") for f in take[o:o + C]] for o in range(0, n, C)]
             else:
-                if self.use_graphs and clip.is_cuda and b[0] > 0 and 0 < b[1] - b[0] < self.steps_per_batch and per_step[-1]:
+                if (self.use_graphs and clip.is_cuda and b[0] > 0 and 0 < b[1] - b[0] < self.steps_per_batch and per_step[-1]
+                        and not self.ramp):
                     # a short last batch would be a NEW frame-stage shape: eager launches plus fresh allocator blocks
                     # (hipMalloc synchronises the device and stalls both streams, ~15 ms).  Pad it with repeats of
                     # its last step's jobs to the steady batch shape so that it replays the captured graph; the
