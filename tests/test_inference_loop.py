@@ -89,7 +89,9 @@ def test_inference_writes_reference_format_predictions(monkeypatch, tmp_path):
     start = 0
     for name, L in VIDEOS:
         clip = torch.from_numpy(np.stack([pil_resize.resize_bilinear_u8(f, MIN_S, MAX_S) for f in clips[name]]))
-        ref = engine.ClipEngine(model2, steps_per_batch=2, overlap=False, graphs=False).run(
+        # (same steps_per_batch as inference(): the CPU twins' GEMMs are not batch-invariant, the HIP kernels are --
+        # tests/test_e2e_gpu.py::test_inference_loop_on_gpu_from_files compares different batchings bit for bit)
+        ref = engine.ClipEngine(model2, steps_per_batch=3, overlap=False, graphs=False).run(
             clip, L, engine.global_schedule(L, GSIZE, seed=start))
         for i, r in enumerate(ref):
             p = preds[start + i]
