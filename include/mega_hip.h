@@ -56,7 +56,7 @@ int mega_conv2d_nhwc_plan(int M, int Cout, int K, int in_dtype);
 
 /* mega_conv2d_nhwc with a caller-owned workspace of mega_conv2d_nhwc_workspace_bytes(M, Cout, K) bytes (M = N*Ho*Wo,
  * K = R*S*Cin; 0 for most layers).  With it, layers with K >= 32768 (the box head's first FC, K = 100352) run
- * split-K: two K ranges per output tile write f32 partial sums into the workspace and a second kernel adds them in a
+ * split-K: three K ranges per output tile write f32 partial sums into the workspace and a second kernel adds them in a
  * fixed order and applies scale / bias / residual / activation.  The split depends on K only, never on M, so a
  * row's result does not depend on the batch it is computed in.  mega_conv2d_nhwc (no workspace) never splits. */
 size_t mega_conv2d_nhwc_workspace_bytes(int M, int Cout, int K);

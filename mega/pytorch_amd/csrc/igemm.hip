@@ -331,8 +331,8 @@ int launch_finalize(const ConvParams& p, hipStream_t st) {
 // grids shrink the tile to keep >= ~1.5 rounds of blocks over the 256 CUs.
 // Split-K depends on K ALONE (never on M): a row of a layer is then summed in the same order whatever batch it is part
 // of, which keeps results batch-invariant (tests: reference call convention == batched engine, bit for bit).  Only
-// the box head's first FC (K = 100352 on R-101) qualifies: two halves of 784 K-tiles double the resident blocks.
-inline int choose_ksplit(int K) { return K >= 32768 ? 2 : 1; }
+// the box head's first FC (K = 100352 on R-101) qualifies: three ranges of 523 K-tiles (240 blocks on 256 CUs at 3750 rows).
+inline int choose_ksplit(int K) { return K >= 32768 ? 3 : 1; }   // (3 x 20 x 4 = 240 blocks of 192 rows for the first FC of a 20-frame batch)
 
 // kind 0: igemm_kernel<.., bm, bn> (this file);  kind 8: igemm8_kernel (igemm8.hip: LDS-DMA, 8 waves, bm x 256), bf16 only.
 // MEGA_IGEMM_TILE forces a choice (experiments / tests): "128x64" or "8:256" / "8:192".
