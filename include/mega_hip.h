@@ -197,6 +197,23 @@ int mega_dff_warp_scale(const void* feats, const float* flow, const void* scale,
 /* hipGetErrorString of the last launch failure any entry point of this library reported (MEGA_ERR_LAUNCH). */
 const char* mega_last_error_string(void);
 
+/* Several independent relation-attention problems (the key frames of one engine step-batch at the same stage) in ONE
+ * launch (+ one combine launch).  Every problem runs exactly the code and the key-range split of its own
+ * mega_relation_attention / mega_relation_attention_tiled_pos call: identical bits.  n <= 16; all problems share groups,
+ * scale, dtype and the kind of position term (none / f32 rows `pos` with ldp / tile-ordered bf16 `pos_tiled`). */
+typedef struct {
+  const void* q; const void* k; const void* vt; const float* pos; const void* pos_tiled; const void* resid;
+  const float* bias_v; void* out; void* ws; size_t ws_bytes;
+  int ldq, ldk, ldv, ldp, ldr, ldo, Nq, Nk;
+} mega_attn_desc;
+int mega_relation_attention_batched(const void* descs /* mega_attn_desc[n], host memory */, int n, int groups,
+                                    float scale, int dtype, void* stream);
+
+/* mega_position_logits_tiled for n <= 16 (query boxes, key boxes) problems in one launch. */
+typedef struct { const float* rois_q; const float* rois_k; void* out_bf16; int Nq, Nk; } mega_pos_desc;
+int mega_position_logits_tiled_batched(const void* descs /* mega_pos_desc[n], host memory */, int n, const float* wg_t,
+                                       const float* bg, const float* dim_mat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,8 @@ SIGNATURES = {
     "mega_relation_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                         c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                         c_int, c_void_p, c_size_t, c_void_p]),
+    "mega_relation_attention_batched": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+    "mega_position_logits_tiled_batched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mega_conv2d_nhwc_tile": (c_int, [c_int] * 3),
     "mega_conv2d_nhwc_plan": (c_int, [c_int] * 4),
     "mega_preprocess_frames": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),

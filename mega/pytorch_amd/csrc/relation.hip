@@ -205,12 +205,11 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
 // logits in LDS in their final order and writes 32 runs of 512 contiguous bytes (16 B per lane) instead of 8-byte
 // pieces scattered over 16 head planes.  Each lane needs only the sine OR the cosine of its 16 arguments:
 // cos(x) = sin(x + 1/4 revolution), one transcendental per value instead of two.
-__global__ __launch_bounds__(256) void pos_logits_tiled_kernel(const float4* __restrict__ rois_q,
-                                                               const float4* __restrict__ rois_k,
-                                                               const float* __restrict__ wgt,
-                                                               const float* __restrict__ bg,
-                                                               const float* __restrict__ dim_mat,
-                                                               bf16_t* __restrict__ out_t, int Nq, int Nk) {
+__device__ __forceinline__ void pos_logits_tiled_body(const float4* __restrict__ rois_q,
+                                                      const float4* __restrict__ rois_k,
+                                                      const float* __restrict__ wgt, const float* __restrict__ bg,
+                                                      const float* __restrict__ dim_mat, bf16_t* __restrict__ out_t,
+                                                      int Nq, int Nk) {
   __shared__ __attribute__((aligned(16))) bf16_t stage[16 * 2 * 8 * 32];   // [head][key tile][q][tile order]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 15, g = lane >> 4;
@@ -269,6 +268,28 @@ __global__ __launch_bounds__(256) void pos_logits_tiled_kernel(const float4* __r
   }
 }
 
+__global__ __launch_bounds__(256) void pos_logits_tiled_kernel(const float4* __restrict__ rois_q,
+                                                               const float4* __restrict__ rois_k,
+                                                               const float* __restrict__ wgt,
+                                                               const float* __restrict__ bg,
+                                                               const float* __restrict__ dim_mat,
+                                                               bf16_t* __restrict__ out_t, int Nq, int Nk) {
+  pos_logits_tiled_body(rois_q, rois_k, wgt, bg, dim_mat, out_t, Nq, Nk);
+}
+
+// the same for several (query boxes, key boxes) problems in one launch: blockIdx.z = problem
+constexpr int POS_MAXB = 16;
+struct PosBatch {
+  struct { const float4* rq; const float4* rk; bf16_t* out; int Nq, Nk; } p[POS_MAXB];
+};
+__global__ __launch_bounds__(256) void pos_logits_tiled_batched_kernel(PosBatch b, const float* __restrict__ wgt,
+                                                                       const float* __restrict__ bg,
+                                                                       const float* __restrict__ dim_mat) {
+  const auto& q = b.p[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= q.Nk || (int)blockIdx.y * 8 >= q.Nq) return;
+  pos_logits_tiled_body(q.rq, q.rk, wgt, bg, dim_mat, q.out, q.Nq, q.Nk);
+}
+
 // ----------------------------------------------------------------------------------------------- attention
 template <typename T> struct AttnCfg;
 template <> struct AttnCfg<bf16_t> {
@@ -323,7 +344,7 @@ struct AttnParams {
 };
 
 template <typename T, bool POS_TILED>
-__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+__device__ __forceinline__ void attn_body(const AttnParams& p, const int split) {
   using C = AttnCfg<T>;
   constexpr int VE = 16 / (int)sizeof(T);
   constexpr int KV_PER_ROW = 64 * (int)sizeof(T) / 16;  // 16-B vectors per K row
@@ -336,7 +357,6 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = lane >> 5, l31 = lane & 31;
   const int head = blockIdx.y;
-  const int split = blockIdx.z;
   const int qw0 = blockIdx.x * 128 + wave * 32;  // first query row of this wave
   const T* __restrict__ Qp = (const T*)p.Q;
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
@@ -585,9 +605,34 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   }
 }
 
+template <typename T, bool POS_TILED>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+  attn_body<T, POS_TILED>(p, (int)blockIdx.z);
+}
+
+// Several independent attention problems (the key frames of one engine step-batch at the same stage) in ONE launch:
+// blockIdx.z enumerates (problem, key-range split) pairs through a small table, so the chip is filled by all
+// problems together and the host pays one launch per stage instead of one per key frame.  Every problem runs exactly
+// the code (and the split count) of its single-problem launch: same bits.
+constexpr int ATTN_MAXB = 16;
+constexpr int ATTN_MAXZ = 256;
+struct AttnBatch {
+  int n, nz;
+  unsigned char zprob[ATTN_MAXZ], zsplit[ATTN_MAXZ];
+  AttnParams p[ATTN_MAXB];
+};
+
+template <typename T, bool POS_TILED>
+__global__ __launch_bounds__(256) void attn_batched_kernel(AttnBatch b) {
+  const int z = blockIdx.z;
+  const AttnParams& p = b.p[b.zprob[z]];
+  if ((int)blockIdx.x * 128 >= p.Nq) return;          // (block-uniform: the grid is sized for the largest problem)
+  attn_body<T, POS_TILED>(p, (int)b.zsplit[z]);
+}
+
 // out[q][c] = resid + bias + (sum_s e^{m_s - M} O_s[q][c]) / (sum_s e^{m_s - M} l_s),  M = max_s m_s  (head = c / 64)
 template <typename T>
-__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
+__device__ __forceinline__ void attn_combine_body(const AttnParams& p) {
   const int D = p.G * 64;
   const size_t total = (size_t)p.Nq * D;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -606,6 +651,17 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
     if (p.resid) v += Elem<T>::ld((const T*)p.resid + (size_t)q * p.ldr + c);
     Elem<T>::st((T*)p.out + (size_t)q * p.ldo + c, v);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
+  attn_combine_body<T>(p);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_batched_kernel(AttnBatch b) {
+  const AttnParams& p = b.p[blockIdx.y];
+  if (p.nsplit > 1) attn_combine_body<T>(p);
 }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -672,18 +728,14 @@ extern "C" size_t mega_relation_attention_workspace_bytes(int Nq, int Nk, int gr
 }
 
 // Multi-head relation attention core (groups heads x 64).  See header comment for the formula.
-static int relation_attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
-                                   const float* pos, int ldp, const void* pos_tiled, const void* resid, int ldr,
-                                   const float* bias_v, void* out, int ldo, int Nq, int Nk, int groups, float scale,
-                                   int dtype, void* ws, size_t ws_bytes, void* stream) {
-  mega_clear_error();
-  if (Nq == 0) return MEGA_OK;
-  if (!q || !k || !vt || !out || Nq < 0 || Nk <= 0 || groups <= 0) return MEGA_ERR_ARG;
+static int attn_fill(AttnParams& p, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
+                     const float* pos, int ldp, const void* pos_tiled, const void* resid, int ldr, const float* bias_v,
+                     void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype, void* ws, size_t ws_bytes) {
+  if (!q || !k || !vt || !out || Nq <= 0 || Nk <= 0 || groups <= 0) return MEGA_ERR_ARG;
   const int ve = dtype == MEGA_BF16 ? 8 : 4;
   if (ldq % ve || ldk % ve || ldv % ve || (pos && (ldp % 32 || ldp < Nk))) return MEGA_ERR_ARG;
   if (ldv < ((Nk + ve - 1) / ve) * ve) return MEGA_ERR_ARG;
   if (pos_tiled && (pos || dtype != MEGA_BF16 || (reinterpret_cast<size_t>(pos_tiled) & 15))) return MEGA_ERR_ARG;
-  AttnParams p;
   p.pos_t = (const bf16_t*)pos_tiled;
   p.Q = q; p.ldq = ldq; p.K = k; p.ldk = ldk; p.Vt = vt; p.ldv = ldv; p.pos = pos; p.ldp = ldp;
   p.resid = resid; p.ldr = ldr; p.bias_v = bias_v; p.out = out; p.ldo = ldo; p.Nq = Nq; p.Nk = Nk; p.G = groups;
@@ -698,6 +750,20 @@ static int relation_attention_impl(const void* q, int ldq, const void* k, int ld
   p.part_o = (float*)ws;
   p.part_ml = nsplit > 1 ? (float*)((unsigned char*)ws + align_up((size_t)want * Nq * groups * 64 * sizeof(float), 256))
                          : nullptr;
+  return MEGA_OK;
+}
+
+static int relation_attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
+                                   const float* pos, int ldp, const void* pos_tiled, const void* resid, int ldr,
+                                   const float* bias_v, void* out, int ldo, int Nq, int Nk, int groups, float scale,
+                                   int dtype, void* ws, size_t ws_bytes, void* stream) {
+  mega_clear_error();
+  if (Nq == 0) return MEGA_OK;
+  AttnParams p;
+  const int rc = attn_fill(p, q, ldq, k, ldk, vt, ldv, pos, ldp, pos_tiled, resid, ldr, bias_v, out, ldo, Nq, Nk, groups,
+                           scale, dtype, ws, ws_bytes);
+  if (rc != MEGA_OK) return rc;
+  const int nsplit = p.nsplit;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(Nq, 128), groups, nsplit);
   if (dtype == MEGA_BF16 && pos_tiled) hipLaunchKernelGGL((attn_kernel<bf16_t, true>), grid, dim3(256), 0, st, p);
@@ -710,6 +776,77 @@ static int relation_attention_impl(const void* q, int ldq, const void* k, int ld
     if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_combine_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_combine_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
   }
+  return mega_check_launch();
+}
+
+// n <= 16 independent problems in one launch (+ one combine launch when any of them splits its key range).  All
+// problems share groups / scale / dtype and the kind of position term (none, f32 rows, or tile-ordered bf16).
+struct MegaAttnDescC {
+  const void* q; const void* k; const void* vt; const float* pos; const void* pos_tiled; const void* resid;
+  const float* bias_v; void* out; void* ws; size_t ws_bytes;
+  int ldq, ldk, ldv, ldp, ldr, ldo, Nq, Nk;
+};
+
+extern "C" int mega_relation_attention_batched(const void* descs, int n, int groups, float scale, int dtype,
+                                               void* stream) {
+  mega_clear_error();
+  if (n == 0) return MEGA_OK;
+  if (!descs || n < 0 || n > ATTN_MAXB) return MEGA_ERR_ARG;
+  const MegaAttnDescC* d = (const MegaAttnDescC*)descs;
+  AttnBatch b;                 // by-value kernel argument (~2.5 KB)
+  b.n = n;
+  int nz = 0, max_q = 0, any_split = 0;
+  size_t max_total = 0;
+  const bool tiled = d[0].pos_tiled != nullptr;
+  for (int i = 0; i < n; ++i) {
+    if ((d[i].pos_tiled != nullptr) != tiled) return MEGA_ERR_ARG;
+    const int rc = attn_fill(b.p[i], d[i].q, d[i].ldq, d[i].k, d[i].ldk, d[i].vt, d[i].ldv, d[i].pos, d[i].ldp,
+                             d[i].pos_tiled, d[i].resid, d[i].ldr, d[i].bias_v, d[i].out, d[i].ldo, d[i].Nq, d[i].Nk,
+                             groups, scale, dtype, d[i].ws, d[i].ws_bytes);
+    if (rc != MEGA_OK) return rc;
+    if (nz + b.p[i].nsplit > ATTN_MAXZ) return MEGA_ERR_ARG;
+    for (int s2 = 0; s2 < b.p[i].nsplit; ++s2) { b.zprob[nz] = (unsigned char)i; b.zsplit[nz] = (unsigned char)s2; ++nz; }
+    max_q = d[i].Nq > max_q ? d[i].Nq : max_q;
+    any_split |= b.p[i].nsplit > 1;
+    const size_t total = (size_t)d[i].Nq * groups * 64;
+    max_total = total > max_total ? total : max_total;
+  }
+  b.nz = nz;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(max_q, 128), groups, nz);
+  if (dtype == MEGA_BF16 && tiled) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, true>), grid, dim3(256), 0, st, b);
+  else if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, false>), grid, dim3(256), 0, st, b);
+  else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_batched_kernel<float, false>), grid, dim3(256), 0, st, b);
+  else return MEGA_ERR_ARG;
+  if (any_split) {
+    const int blocks = (int)((max_total + 255) / 256 > 4096 ? 4096 : (max_total + 255) / 256);
+    if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_combine_batched_kernel<bf16_t>), dim3(blocks, n), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((attn_combine_batched_kernel<float>), dim3(blocks, n), dim3(256), 0, st, b);
+  }
+  return mega_check_launch();
+}
+
+struct MegaPosDescC { const float* rois_q; const float* rois_k; void* out_bf16; int Nq, Nk; };
+
+extern "C" int mega_position_logits_tiled_batched(const void* descs, int n, const float* wg_t, const float* bg,
+                                                  const float* dim_mat, void* stream) {
+  mega_clear_error();
+  if (n == 0) return MEGA_OK;
+  if (!descs || n < 0 || n > POS_MAXB || !wg_t || !bg || !dim_mat) return MEGA_ERR_ARG;
+  const MegaPosDescC* d = (const MegaPosDescC*)descs;
+  PosBatch b;
+  int max_q = 0, max_k = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!d[i].rois_q || !d[i].rois_k || !d[i].out_bf16 || d[i].Nq <= 0 || d[i].Nk <= 0 ||
+        (reinterpret_cast<size_t>(d[i].out_bf16) & 15))
+      return MEGA_ERR_ARG;
+    b.p[i].rq = (const float4*)d[i].rois_q; b.p[i].rk = (const float4*)d[i].rois_k; b.p[i].out = (bf16_t*)d[i].out_bf16;
+    b.p[i].Nq = d[i].Nq; b.p[i].Nk = d[i].Nk;
+    max_q = d[i].Nq > max_q ? d[i].Nq : max_q;
+    max_k = d[i].Nk > max_k ? d[i].Nk : max_k;
+  }
+  dim3 grid(cdiv(max_k, 64), cdiv(max_q, 8), n);
+  hipLaunchKernelGGL(pos_logits_tiled_batched_kernel, grid, dim3(256), 0, (hipStream_t)stream, b, wg_t, bg, dim_mat);
   return mega_check_launch();
 }
 

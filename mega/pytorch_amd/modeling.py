@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .relation import (RelationWeights, relation_attend, relation_attention_forward,
+from .relation import (RelationWeights, relation_attend, relation_attend_batched, relation_attention_forward,
                        relation_project_batched)
 from .structures import BoxList, cat_boxlist, to_image_list
 from .synth import _cell_anchors
@@ -566,6 +566,7 @@ class MEGAFeatureExtractor(_Packed):
         return x
 
     # ---- aggregation of SEVERAL consecutive key frames at once (engine batches)
+    batched_attention = True  # the attention core / position logits of all key frames of a stage in ONE launch each
     attend_streams = 1        # > 1: the per-key-frame attention calls of one stage run on that many side HIP streams
                               # (measured with 4: 528 vs 580 FPS -- the extra host work per job outweighs the overlap)
 
@@ -602,6 +603,8 @@ class MEGAFeatureExtractor(_Packed):
         pk = self._packed(xs[0].dtype, xs[0].device)
         w = pk["global"][i]
         qs, ks, vts = relation_project_batched(w, xs, globs)
+        if self.batched_attention:
+            return relation_attend_batched(w, [{"x": xs[t], "q": qs[t], "k": ks[t], "vt": vts[t]} for t in range(len(xs))])
         return self._attend_many([lambda t=t: relation_attend(w, xs[t], qs[t], ks[t], vts[t]) for t in range(len(xs))])
 
     def aggregate_batch(self, frames, shard=None):
@@ -681,7 +684,20 @@ class MEGAFeatureExtractor(_Packed):
                     mem_kv = (memory["k"], memory["vt"])
                 rc = frames[t]["rois_key"] if last else rois_cur01[t]
                 return relation_attend(w, feats_cur[t], qs[t], ks[t], vts[t], rc.contiguous(), rk.contiguous(), mem_kv)
-            outs = dict(zip(own, self._attend_many([lambda t=t: attend(t) for t in own])))
+            if self.batched_attention and own:
+                jobs = []
+                for t in own:
+                    memory = snaps[t]
+                    rk, mem_kv = rois_ref[t], None
+                    if memory is not None:
+                        rk = torch.cat([rk, memory["rois"]], dim=0)
+                        mem_kv = (memory["k"], memory["vt"])
+                    rc = frames[t]["rois_key"] if last else rois_cur01[t]
+                    jobs.append({"x": feats_cur[t], "q": qs[t], "k": ks[t], "vt": vts[t], "rois_q": rc.contiguous(),
+                                 "rois_k": rk.contiguous(), "mem_kv": mem_kv})
+                outs = dict(zip(own, relation_attend_batched(w, jobs)))
+            else:
+                outs = dict(zip(own, self._attend_many([lambda t=t: attend(t) for t in own])))
             if last:
                 xs = outs
                 break

@@ -4,6 +4,7 @@ torch is used here only for device memory and the current HIP stream; every comp
 hand-written gfx950 kernel in libmega_hip.so.  All wrappers raise if the library is missing, a
 tensor is not on a HIP device, or a kernel call returns non-zero -- there is no CPU fallback.
 """
+import ctypes
 import math
 
 import torch
@@ -343,6 +344,89 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     _pe(_tok)
     _lib.check(rc, "mega_relation_attention")
     return out
+
+
+class _AttnDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("q", "k", "vt", "pos", "pos_tiled", "resid", "bias_v", "out", "ws")] + \
+               [("ws_bytes", ctypes.c_size_t)] + \
+               [(n, ctypes.c_int) for n in ("ldq", "ldk", "ldv", "ldp", "ldr", "ldo", "Nq", "Nk")]
+
+
+class _PosDesc(ctypes.Structure):
+    _fields_ = [("rois_q", ctypes.c_void_p), ("rois_k", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("Nq", ctypes.c_int), ("Nk", ctypes.c_int)]
+
+
+def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, tiled=False):
+    """position_logits for several (query boxes, key boxes) problems; the tile-ordered bf16 form (bf16 mode) runs as
+    ONE launch per 16 problems, the f32 forms fall back to one call per problem."""
+    if not tiled:
+        return [position_logits(a, b, wg_t, bg, dim_mat, precise=precise, tiled=False) for a, b in zip(rois_qs, rois_ks)]
+    _gpu(wg_t, bg, dim_mat, *rois_qs, *rois_ks)
+    lib = _lib.load()
+    outs, keep = [], []
+    for a, b in zip(rois_qs, rois_ks):
+        a, b = a.contiguous(), b.contiguous()
+        keep.append((a, b))
+        outs.append(torch.empty((16, (b.shape[0] + 31) // 32, a.shape[0], 32), dtype=torch.bfloat16, device=a.device))
+    for o in range(0, len(outs), 16):
+        n = min(16, len(outs) - o)
+        arr = (_PosDesc * n)()
+        for i in range(n):
+            a, b = keep[o + i]
+            arr[i].rois_q, arr[i].rois_k, arr[i].out = a.data_ptr(), b.data_ptr(), outs[o + i].data_ptr()
+            arr[i].Nq, arr[i].Nk = a.shape[0], b.shape[0]
+        _tok = _pb("pos_logits", sum(2.0 * arr[i].Nq * arr[i].Nk * 1024 for i in range(n)),
+                   sum(outs[o + i].numel() * 2.0 for i in range(n)))
+        rc = lib.mega_position_logits_tiled_batched(ctypes.addressof(arr), n, _ptr(wg_t), _ptr(bg), _ptr(dim_mat), _stream())
+        _pe(_tok)
+        _lib.check(rc, "mega_position_logits_tiled_batched")
+    return outs
+
+
+def relation_attention_batched(items, groups=16):
+    """relation_attention for a list of independent problems, each a dict(q, k, vt, Nk, pos, resid, bias_v), in ONE launch
+    per 16 problems (+ one combine launch).  Every problem gets the bits of its own relation_attention call."""
+    if not items:
+        return []
+    lib = _lib.load()
+    dt = items[0]["q"].dtype
+    outs, wss = [], []
+    for it in items:
+        q, k, vt, pos = it["q"], it["k"], it["vt"], it.get("pos")
+        _gpu(q, k, vt, pos, it.get("resid"), it.get("bias_v"))
+        assert q.dtype == k.dtype == vt.dtype == dt and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+        assert (pos is None) == (items[0].get("pos") is None) and (pos is None or pos.dtype == items[0]["pos"].dtype)
+        outs.append(torch.empty((q.shape[0], groups * 64), dtype=dt, device=q.device))
+        nb = lib.mega_relation_attention_workspace_bytes(q.shape[0], it["Nk"], groups)
+        wss.append(_ws(nb, q.device) if nb else None)
+    for o in range(0, len(items), 16):
+        n = min(16, len(items) - o)
+        arr = (_AttnDesc * n)()
+        fl = by = 0.0
+        for i in range(n):
+            it, d = items[o + i], arr[i]
+            q, k, vt, pos, resid = it["q"], it["k"], it["vt"], it.get("pos"), it.get("resid")
+            Nq, Nk = q.shape[0], it["Nk"]
+            d.q, d.k, d.vt, d.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), outs[o + i].data_ptr()
+            d.ldq, d.ldk, d.ldv, d.ldo, d.Nq, d.Nk = q.shape[1], k.shape[1], vt.shape[1], groups * 64, Nq, Nk
+            d.resid, d.ldr = _ptr(resid), 0 if resid is None else resid.shape[1]
+            d.bias_v = _ptr(it.get("bias_v"))
+            if pos is not None and pos.dtype == torch.bfloat16:
+                assert pos.is_contiguous() and tuple(pos.shape) == (groups, (Nk + 31) // 32, Nq, 32)
+                d.pos_tiled = pos.data_ptr()
+            elif pos is not None:
+                d.pos, d.ldp = pos.data_ptr(), pos.shape[2]
+            w = wss[o + i]
+            d.ws, d.ws_bytes = _ptr(w), 0 if w is None else w.numel()
+            fl += 4.0 * Nq * Nk * 64 * groups
+            by += (q.numel() + k.numel() + vt.numel() + outs[o + i].numel()) * q.element_size() + \
+                (0 if pos is None else pos.numel() * pos.element_size())
+        _tok = _pb("attention_" + ("bf16" if dt == torch.bfloat16 else "f32"), fl, by)
+        rc = lib.mega_relation_attention_batched(ctypes.addressof(arr), n, groups, 1.0 / math.sqrt(64.0), _DT[dt], _stream())
+        _pe(_tok)
+        _lib.check(rc, "mega_relation_attention_batched")
+    return outs
 
 
 def resize_bilinear_u8(frames_u8, out_hw, tables):

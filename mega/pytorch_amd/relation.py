@@ -118,3 +118,32 @@ def relation_attend(w, x, q, k, vt, rois_q=None, rois_k=None, mem_kv=None, resid
         fast = x.dtype != torch.float32
         pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
     return ops.relation_attention(q, k, vv, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
+
+
+def relation_attend_batched(w, jobs, residual=True):
+    """relation_attend for several problems of the SAME weights (the key frames of a step-batch at one stage) with the
+    position logits and the attention core each as ONE launch: jobs = list of dict(x, q, k, vt, rois_q, rois_k, mem_kv).
+    Same bits per problem as relation_attend."""
+    items, rq, rk = [], [], []
+    for j in jobs:
+        k, vt = j["k"], j["vt"]
+        Nk = k.shape[0]
+        vparts = [vt]
+        if j.get("mem_kv") is not None:
+            k_mem, vt_mem = j["mem_kv"]
+            Nk += k_mem.shape[0]
+            k = torch.cat([k, k_mem], dim=0)
+            vparts.append(vt_mem)
+        ldv = (Nk + 31) // 32 * 32
+        if ldv > Nk:
+            vparts.append(vt.new_zeros((vt.shape[0], ldv - Nk)))
+        vv = torch.cat(vparts, dim=1) if len(vparts) > 1 else vt.contiguous()
+        items.append({"q": j["q"], "k": k, "vt": vv, "Nk": Nk, "resid": j["x"] if residual else None, "bias_v": w.bv})
+        rq.append(j.get("rois_q"))
+        rk.append(j.get("rois_k"))
+    if w.with_pos:
+        fast = jobs[0]["x"].dtype != torch.float32
+        pos = ops.position_logits_batched(rq, rk, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
+        for it, p in zip(items, pos):
+            it["pos"] = p
+    return ops.relation_attention_batched(items)

@@ -121,6 +121,15 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     return o.to(q.dtype)
 
 
+def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, tiled=False):
+    return [position_logits(a, b, wg_t, bg, dim_mat) for a, b in zip(rois_qs, rois_ks)]
+
+
+def relation_attention_batched(items, groups=16):
+    return [relation_attention(it["q"], it["k"], it["vt"], it["Nk"], pos=it.get("pos"), resid=it.get("resid"),
+                               bias_v=it.get("bias_v"), groups=groups) for it in items]
+
+
 def preprocess_frames(frames_u8, mean, to_bgr=True):
     x = frames_u8.permute(0, 3, 1, 2).float() / 255.0
     if to_bgr:
@@ -139,7 +148,8 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
 
 
 ALL = ["pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
-       "postprocess", "position_logits", "relation_attention", "preprocess_frames"]
+       "postprocess", "position_logits", "relation_attention", "preprocess_frames", "position_logits_batched",
+       "relation_attention_batched"]
 
 
 def dff_warp_scale(feats, flow, scale):
