@@ -709,12 +709,15 @@ extern "C" int mega_position_logits_tiled(const float* rois_q, const float* rois
   return mega_check_launch();
 }
 
-// Number of key-range splits the attention core uses for (Nq, Nk): enough blocks for ~3 per CU, >= 4 key tiles each.
+// Number of key-range splits the attention core uses for (Nq, Nk) -- a function of the problem alone, so a problem
+// gets the same bits in a single launch and inside a batched launch.  The engine batches ~10 problems per launch, so a
+// problem only needs ~1 block per CU of its own (MEGA_ATTN_BLOCKS, default 256; round 1 used 768 for single launches).
 extern "C" int mega_relation_attention_splits(int Nq, int Nk, int groups) {
   if (Nq <= 0 || Nk <= 0 || groups <= 0) return 1;
+  static const int target = getenv("MEGA_ATTN_BLOCKS") ? atoi(getenv("MEGA_ATTN_BLOCKS")) : 256;
   const int blocks = cdiv(Nq, 128) * groups;
   const int ntiles = cdiv(Nk, 32);
-  int s = cdiv(768, blocks);
+  int s = cdiv(target, blocks);
   if (s > ntiles / 4) s = ntiles / 4;
   if (s > 16) s = 16;
   return s < 1 ? 1 : s;
