@@ -267,8 +267,9 @@ def main():
         assert captures_in_region == 0, "a frame-stage batch ran eagerly / was captured inside the timed region: %s -> %s" % (st0, st1)
     assert st1["pools_full"], "pools not full in the timed region: %s" % (st1,)
     ht = dict(runner.host_times)
-    log("host ms/step: frame-stage enqueue %.3f, aggregation enqueue %.3f, waiting for results %.3f" % tuple(
-        1e3 * ht[k] / max(ht["steps"], 1) for k in ("frame_enqueue", "aggregate_enqueue", "finish_wait")))
+    log("host ms/step: frame-stage enqueue %.3f, aggregation enqueue %.3f (of which waiting for the frame stage %.3f), "
+        "waiting for results %.3f" % tuple(1e3 * ht[k] / max(ht["steps"], 1)
+                                            for k in ("frame_enqueue", "aggregate_enqueue", "frame_wait", "finish_wait")))
     Wm = pos - K * len(blocks)       # key frames processed before the first timed block
 
     roofline = None

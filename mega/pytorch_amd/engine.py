@@ -157,7 +157,7 @@ class ClipEngine(object):
         self.graph_stats = {"eager": 0, "captured": 0, "replayed": 0}
         self._streams = None
         # host-side seconds spent enqueuing / waiting, accumulated over run() calls (diagnostics for bench.py)
-        self.host_times = {"frame_enqueue": 0.0, "aggregate_enqueue": 0.0, "finish_wait": 0.0, "steps": 0}
+        self.host_times = {"frame_enqueue": 0.0, "aggregate_enqueue": 0.0, "frame_wait": 0.0, "finish_wait": 0.0, "steps": 0}
 
     # ------------------------------------------------------------------ state report (bench.py, tests)
     def static_replays(self):
@@ -437,7 +437,9 @@ class ClipEngine(object):
             with _On(sB):
                 if use_streams and ev is not None:
                     sB.wait_event(ev)
+                    tw = _time.perf_counter()
                     ev.synchronize()                  # host waits for THIS frame-stage batch only, not the stream
+                    ht["frame_wait"] += _time.perf_counter() - tw
                 recs = []
                 for h in hs:
                     r = self.records_resolve(h, h["cnt_host"].tolist() if use_streams else None)
@@ -455,7 +457,8 @@ class ClipEngine(object):
                            and m.roi_heads.box.feature_extractor.cache_memory_kv)
                 if batched and self._static is not None:
                     self._static.leave()          # the pools go back into the model's deques
-                prepared = []                     # (key frame index, snapshot) of the steps awaiting step_batch()
+                prepared = []                     # (key frame index, (new local record, new global records)) of
+                                                  # the steps awaiting prepare_batch() + step_batch()
 
                 def flush():
                     if not prepared:
@@ -463,12 +466,13 @@ class ClipEngine(object):
                     shard = None
                     if self.world > 1 or self.force_sharded:
                         shard = KeyFrameShard(self.dist, self.group, self.rank, self.world)
-                    outs = m.step_batch([f for _, f in prepared], (W, H), shard)
-                    for (i2, f), pd in zip(prepared, outs):
+                    frames = m.prepare_batch([st for _, st in prepared])
+                    outs = m.step_batch(frames, (W, H), shard)
+                    for (i2, _), pd in zip(prepared, outs):
                         pending.append((i2, pd))
                     if self.keep_logits:     # (sharded: only this rank's own key frames have logits here)
                         self.logits_log += [None if x is None else x.float().clone() for x in m.last_logits_batch]
-                        self.key_boxes_log += [f["rois_key"].clone() for _, f in prepared]
+                        self.key_boxes_log += [f["rois_key"].clone() for f in frames]
                     del prepared[:]
 
                 for i, js in zip(range(b[0], b[1]), per_step):
@@ -492,14 +496,14 @@ class ClipEngine(object):
                         for x in loc[1:]:
                             m.records.append(x)
                         if batched:
-                            prepared.append((i, m.prepare_step(None, glob)))
+                            prepared.append((i, (None, glob)))
                             continue
                         pending.append((i, m.step(None, glob, (W, H), defer=True)))
                         if self.keep_logits:
                             self.logits_log.append(m.last_logits.float().clone())
                             self.key_boxes_log.append(m.records[m.key_frame_location]["boxes"].clone())
                     elif batched:
-                        prepared.append((i, m.prepare_step(loc[0], glob)))
+                        prepared.append((i, (loc[0], glob)))
                     elif self._static is not None and self.use_static and self._static.ready(loc[0], glob):
                         pending.append((i, self._static.step(loc[0], glob, (W, H))))
                         self.static_steps += 1
@@ -554,7 +558,7 @@ class ClipEngine(object):
                 finish(prev_pending)                                               # results of B(b-1)
             t3 = _time.perf_counter()
             ht["frame_enqueue"] += t1 - t0
-            ht["aggregate_enqueue"] += t2 - t1
+            ht["aggregate_enqueue"] += t2 - t1      # (includes frame_wait)
             ht["finish_wait"] += t3 - t2
             ht["steps"] += b[1] - b[0]
             prev_pending, staged = pending, nxt

@@ -21,8 +21,8 @@ import torch
 from torch import nn
 
 from . import ops
-from .relation import (RelationWeights, relation_attend, relation_attend_batched, relation_attention_forward,
-                       relation_project_batched)
+from .relation import (RelationWeights, cat_rows, relation_attend, relation_attend_batched,
+                       relation_attention_forward, relation_project_batched)
 from .structures import BoxList, cat_boxlist, to_image_list
 from .synth import _cell_anchors
 
@@ -567,45 +567,25 @@ class MEGAFeatureExtractor(_Packed):
 
     # ---- aggregation of SEVERAL consecutive key frames at once (engine batches)
     batched_attention = True  # the attention core / position logits of all key frames of a stage in ONE launch each
-    attend_streams = 1        # > 1: the per-key-frame attention calls of one stage run on that many side HIP streams
-                              # (measured with 4: 528 vs 580 FPS -- the extra host work per job outweighs the overlap)
-
-    def _attend_many(self, jobs):
-        """Run independent per-key-frame jobs (each: cat the key set, position logits, attention, combine -- small
-        launches that do not fill 256 CUs one at a time).  On the device they are dealt to side streams forked from
-        the current stream and joined before returning, so the frames of a stage overlap each other; their inputs
-        were all enqueued on the current stream before the fork, their outputs are handed back to it."""
-        if len(jobs) < 2 or not torch.cuda.is_available() or self.attend_streams < 2 or \
-                not next(self.parameters()).is_cuda or torch.cuda.is_current_stream_capturing():
-            return [j() for j in jobs]
-        main = torch.cuda.current_stream()
-        if getattr(self, "_side_streams", None) is None:
-            self._side_streams = [torch.cuda.Stream() for _ in range(self.attend_streams)]
-        fork = torch.cuda.Event()
-        fork.record(main)
-        outs, dones = [], []
-        for n, job in enumerate(jobs):
-            s = self._side_streams[n % len(self._side_streams)]
-            with torch.cuda.stream(s):
-                s.wait_event(fork)
-                o = job()
-                d = torch.cuda.Event()
-                d.record(s)
-            o.record_stream(main)            # allocated on the side stream, consumed on the main one
-            outs.append(o)
-            dones.append(d)
-        for d in dones:
-            main.wait_event(d)
-        return outs
+                              # (False: one relation_attend call per key frame -- the A/B switch of that change)
 
     def _update_lm_batched(self, xs, globs, i=0):
-        """update_lm (:690-699) for several key frames: xs[t] attends to globs[t] (that step's global pool)."""
-        pk = self._packed(xs[0].dtype, xs[0].device)
+        """update_lm (:690-699) for several key frames: xs[t] (a tensor or a tuple of row blocks) attends to globs[t]
+        (that step's global pool).  Returns consecutive row blocks of one buffer."""
+        pk = self._packed(globs[0].dtype, globs[0].device)
         w = pk["global"][i]
-        qs, ks, vts = relation_project_batched(w, xs, globs)
+        qs, ks, vts, xc = relation_project_batched(w, xs, globs, want_x=True)
         if self.batched_attention:
-            return relation_attend_batched(w, [{"x": xs[t], "q": qs[t], "k": ks[t], "vt": vts[t]} for t in range(len(xs))])
-        return self._attend_many([lambda t=t: relation_attend(w, xs[t], qs[t], ks[t], vts[t]) for t in range(len(xs))])
+            return relation_attend_batched(w, [{"x": xc[t], "q": qs[t], "k": ks[t], "vt": vts[t]} for t in range(len(xs))])
+        return [relation_attend(w, xc[t], qs[t], ks[t], vts[t]) for t in range(len(xs))]
+
+    def _zero_cols(self, like, n):
+        """[rows of like, n] zeros (n < 32), cut from one cached block: the pad columns between V^T blocks"""
+        z = getattr(self, "_zpad", None)
+        if z is None or z.dtype != like.dtype or z.device != like.device or z.shape[0] != like.shape[0]:
+            z = like.new_zeros((like.shape[0], 32))
+            self._zpad = z
+        return z[:, :n]
 
     def aggregate_batch(self, frames, shard=None):
         """aggregate() for a list of consecutive key frames (oldest first), each a dict with the arguments of aggregate():
@@ -617,9 +597,16 @@ class MEGAFeatureExtractor(_Packed):
         of the oldest window frame (update_memory :678-688 is called before the attention, :914-917), never its own
         stage-i output.  The dependency depth is the number of stages, not the number of frames.  So the batch is
         processed stage by stage: the Wq / Wk / Wv projections and the stage FCs of all its frames run as ONE GEMM each
-        (M = S x 675 ... S x 1875 rows instead of 64x64-tile launches at 4 % of the MFMA peak), only the attention core
-        and the memory bookkeeping (read-before-push, in frame order) run per frame.  All kernels are batch-invariant,
-        so every frame's result has the same bits as aggregate()'s (tests: engine == reference call convention).
+        (M = S x 675 ... S x 1875 rows instead of 64x64-tile launches at 4 % of the MFMA peak), the position logits and
+        the attention core as one launch each.  All kernels are batch-invariant, so every frame's result has the same
+        bits as aggregate()'s (tests: engine == reference call convention).
+
+        Data movement: the memory pool a frame reads is a SLIDING window over the entries in push order, so per stage
+        the old pool and the batch's new entries are laid out once as one "tape" (3 concatenations: boxes, K, V^T) and
+        frame t's read-before-push snapshot is a row / column range of it; the key sets [local window ; memory] of all
+        frames are then assembled by 3 more concatenations into flat buffers whose row (K, boxes) / 32-aligned column
+        (V^T) blocks are handed to the kernels as views.  Per-frame torch.cat launches (7 per frame and stage before)
+        were the largest kernel family of the aggregation; the operands' values and order are unchanged.
 
         shard (engine.KeyFrameShard, multi-GPU): the key frames of the batch are dealt round-robin to the ranks; a
         rank runs the stages only for its own frames.  What other frames need from a frame are its memory entries
@@ -633,19 +620,47 @@ class MEGAFeatureExtractor(_Packed):
         own = [t for t in range(S) if shard is None or shard.owner(t) == shard.rank]
         nkey = [f["x"].shape[0] for f in frames]
         nl = [f["x_ref"].shape[0] for f in frames]
+        ndis = [f["rois_dis"].shape[0] for f in frames]
         xs, x_refs = {}, {}
         use_glob = self.global_enable and frames[0].get("glob") is not None
+        z = None
         if use_glob and own:                                                     # :757-760
-            z = self._update_lm_batched([torch.cat([frames[t]["x"], frames[t]["x_ref"]], dim=0) for t in own],
+            z = self._update_lm_batched([(frames[t]["x"], frames[t]["x_ref"]) for t in own],
                                         [frames[t]["glob"] for t in own])
             for j, t in enumerate(own):
                 xs[t], x_refs[t] = z[j][:nkey[t]], z[j][nkey[t]:nkey[t] + nl[t]]
         elif own:
             for t in own:
                 xs[t], x_refs[t] = frames[t]["x"], frames[t]["x_ref"]
-        feats_cur = {t: torch.cat([xs[t], x_refs[t].index_select(0, frames[t]["dis_index"])], dim=0) for t in own}
+        # stage-0 queries [key rows ; 'dis' rows of the window] of every own frame: ONE gather from the update_lm output
+        feats_cur = {}
+        sig = tuple((nkey[t], nl[t], frames[t].get("dis_key")) for t in own)
+        if z is not None and own and all(sg[2] is not None for sg in sig):
+            z_all = cat_rows(z)
+            cache = getattr(self, "_cur_index", None)
+            if cache is None or cache[0] != sig or cache[1].device != z_all.device:
+                idx, o = [], 0
+                for t in own:
+                    idx.append(torch.arange(o, o + nkey[t], device=z_all.device))
+                    idx.append(frames[t]["dis_index"] + (o + nkey[t]))
+                    o += nkey[t] + nl[t]
+                cache = (sig, torch.cat(idx))
+                self._cur_index = cache
+            cur_all = z_all.index_select(0, cache[1])
+            o = 0
+            for t in own:
+                feats_cur[t] = cur_all[o:o + nkey[t] + ndis[t]]
+                o += nkey[t] + ndis[t]
+        else:
+            for t in own:
+                feats_cur[t] = torch.cat([xs[t], x_refs[t].index_select(0, frames[t]["dis_index"])], dim=0)
         feats_ref = x_refs
-        rois_cur01 = {t: torch.cat([frames[t]["rois_key"], frames[t]["rois_dis"]], dim=0) for t in own}
+        rois_cur01 = {}
+        if own:
+            rc_all, o = torch.cat([r for t in own for r in (frames[t]["rois_key"], frames[t]["rois_dis"])], dim=0), 0
+            for t in own:
+                rois_cur01[t] = rc_all[o:o + nkey[t] + ndis[t]]
+                o += nkey[t] + ndis[t]
         for i in range(self.stage):
             last = i == self.stage - 1
             w = pk["local"][i]
@@ -654,57 +669,60 @@ class MEGAFeatureExtractor(_Packed):
             n_ent = [min(n_push, r.shape[0]) for r in rois_ref]           # rows of each frame's memory entry
             qs, ks, vts = {}, {}, {}
             if own:
-                q_, k_, v_ = relation_project_batched(w, [feats_cur[t].contiguous() for t in own],
-                                                      [feats_ref[t].contiguous() for t in own])
+                q_, k_, v_ = relation_project_batched(w, [feats_cur[t] for t in own], [feats_ref[t] for t in own])
                 for j, t in enumerate(own):
                     qs[t], ks[t], vts[t] = q_[j], k_[j], v_[j]
-            if shard is not None and self.memory_enable:
-                # memory entries of ALL frames: gather the entry rows, project them here (same bits as the owner's)
-                ent = shard.gather_rows({t: feats_ref[t][:n_ent[t]] for t in own}, n_ent, frames[0]["x"])
-                e_all = torch.cat(ent, dim=0)
-                ek_all = ops.linear(e_all, w.wk, w.bk)
-                evt_all = ops.linear_transposed(w.wv, e_all, (e_all.shape[0] + 31) // 32 * 32)
-            snaps, o = {}, 0
-            for t in range(S):                                   # memory: read BEFORE this frame's push (:914-917)
-                if t in qs:
-                    snaps[t] = self.mem[i] if self.mem[i] else None     # (a push replaces the dict: this IS a snapshot)
-                if self.memory_enable:
-                    n = n_ent[t]
-                    if shard is not None:
-                        self._push_memory(i, rois_ref[t][:n], ek_all[o:o + n], evt_all[:, o:o + n])
-                    else:
-                        self._push_memory(i, rois_ref[t][:n], ks[t][:n], vts[t][:, :n])
-                    o += n
-
-            def attend(t):
-                memory = snaps[t]
-                rk, mem_kv = rois_ref[t], None
-                if memory is not None:
-                    rk = torch.cat([rk, memory["rois"]], dim=0)
-                    mem_kv = (memory["k"], memory["vt"])
-                rc = frames[t]["rois_key"] if last else rois_cur01[t]
-                return relation_attend(w, feats_cur[t], qs[t], ks[t], vts[t], rc.contiguous(), rk.contiguous(), mem_kv)
-            if self.batched_attention and own:
-                jobs = []
+            snaps = {}
+            if self.memory_enable:
+                if shard is not None:
+                    # memory entries of ALL frames: gather the entry rows, project them here (same bits as the owner's)
+                    ent = shard.gather_rows({t: feats_ref[t][:n_ent[t]] for t in own}, n_ent, frames[0]["x"])
+                    e_all = torch.cat(ent, dim=0)
+                    ek_all = ops.linear(e_all, w.wk, w.bk)
+                    evt_all = ops.linear_transposed(w.wv, e_all, (e_all.shape[0] + 31) // 32 * 32)
+                    o, new_k, new_vt = 0, [], []
+                    for t in range(S):
+                        new_k.append(ek_all[o:o + n_ent[t]])
+                        new_vt.append(evt_all[:, o:o + n_ent[t]])
+                        o += n_ent[t]
+                else:
+                    new_k = [ks[t][:n_ent[t]] for t in range(S)]
+                    new_vt = [vts[t][:, :n_ent[t]] for t in range(S)]
+                snaps = self._push_memory_batch(i, [rois_ref[t][:n_ent[t]] for t in range(S)], new_k, new_vt)
+            jobs = []
+            if own:
+                # key sets [local window ; memory snapshot] of all own frames, assembled by three concatenations
+                kp, vp, rp, Nk, ldv = [], [], [], {}, {}
                 for t in own:
-                    memory = snaps[t]
-                    rk, mem_kv = rois_ref[t], None
-                    if memory is not None:
-                        rk = torch.cat([rk, memory["rois"]], dim=0)
-                        mem_kv = (memory["k"], memory["vt"])
+                    m = snaps.get(t)
+                    kp.append(ks[t]); vp.append(vts[t]); rp.append(rois_ref[t])
+                    Nk[t] = ks[t].shape[0]
+                    if m is not None:
+                        kp.append(m["k"]); vp.append(m["vt"]); rp.append(m["rois"])
+                        Nk[t] += m["k"].shape[0]
+                    ldv[t] = (Nk[t] + 31) // 32 * 32
+                    if ldv[t] > Nk[t]:
+                        vp.append(self._zero_cols(vts[t], ldv[t] - Nk[t]))
+                k_flat, vt_flat, r_flat = torch.cat(kp, dim=0), torch.cat(vp, dim=1), torch.cat(rp, dim=0)
+                ok = oc = 0
+                for t in own:
                     rc = frames[t]["rois_key"] if last else rois_cur01[t]
-                    jobs.append({"x": feats_cur[t], "q": qs[t], "k": ks[t], "vt": vts[t], "rois_q": rc.contiguous(),
-                                 "rois_k": rk.contiguous(), "mem_kv": mem_kv})
+                    jobs.append({"x": feats_cur[t], "q": qs[t], "k_all": k_flat[ok:ok + Nk[t]],
+                                 "vt_all": vt_flat[:, oc:oc + ldv[t]], "Nk": Nk[t], "rois_q": rc,
+                                 "rois_k": r_flat[ok:ok + Nk[t]]})
+                    ok += Nk[t]
+                    oc += ldv[t]
+            if self.batched_attention:
                 outs = dict(zip(own, relation_attend_batched(w, jobs)))
             else:
-                outs = dict(zip(own, self._attend_many([lambda t=t: attend(t) for t in own])))
+                outs = dict(zip(own, [relation_attend_batched(w, [j])[0] for j in jobs]))
             if last:
                 xs = outs
                 break
             feats_cur, feats_ref = {}, {}
             if own:
                 ncur = [outs[t].shape[0] for t in own]
-                fc = ops.linear(torch.cat([outs[t] for t in own], dim=0), pk["fc_w"][i + 1], pk["fc_b"][i + 1], relu=True)
+                fc = ops.linear(cat_rows([outs[t] for t in own]), pk["fc_w"][i + 1], pk["fc_b"][i + 1], relu=True)
                 o = 0
                 for j, t in enumerate(own):
                     nx = fc[o:o + ncur[j]]
@@ -713,10 +731,44 @@ class MEGAFeatureExtractor(_Packed):
                     feats_ref[t] = nx[nkey[t]:]
         for i in range(self.global_res_stage):                                   # :930-931
             if own:
-                z = self._update_lm_batched([xs[t].contiguous() for t in own], [frames[t]["glob"] for t in own], i + 1)
+                z = self._update_lm_batched([xs[t] for t in own], [frames[t]["glob"] for t in own], i + 1)
                 for j, t in enumerate(own):
                     xs[t] = z[j]
         return [xs.get(t) for t in range(S)]
+
+    def _push_memory_batch(self, i, new_rois, new_k, new_vt):
+        """The pushes of S consecutive key frames into memory[i] (update_memory + _remember_kv, in frame order) as one
+        tape: [live entries ; the S new entries] laid out by three concatenations.  Returns {t: snapshot} where
+        snapshot = dict(rois, k, vt) views of the pool frame t READS (the live entries before its own push, :914-917;
+        absent while the pool is empty).  The deques / self.mem[i] are left as S single pushes would leave them
+        (their tensors are views of the tape)."""
+        q = self.mem_queue_list[i]
+        cap = q["rois"].maxlen
+        old = [r.shape[0] for r in q["rois"]]
+        E0, S = len(old), len(new_rois)
+        have_old = E0 > 0
+        tr = torch.cat(([self.mem[i]["rois"]] if have_old else []) + list(new_rois), dim=0)
+        tk = torch.cat(([self.mem[i]["k"]] if have_old else []) + list(new_k), dim=0)
+        tv = torch.cat(([self.mem[i]["vt"]] if have_old else []) + list(new_vt), dim=1)
+        off = [0]
+        for n in old + [r.shape[0] for r in new_rois]:
+            off.append(off[-1] + n)
+
+        def view(lo, hi):      # entries lo .. hi-1 of the tape
+            a, b = off[lo], off[hi]
+            return {"rois": tr[a:b], "k": tk[a:b], "vt": tv[:, a:b]}
+        snaps = {}
+        for t in range(S):
+            hi = E0 + t
+            if hi > 0:
+                snaps[t] = view(max(0, hi - cap), hi)
+        for t in range(S):
+            e = view(E0 + t, E0 + t + 1)
+            q["rois"].append(e["rois"])
+            q["k"].append(e["k"])
+            q["vt"].append(e["vt"])
+        self.mem[i] = view(max(0, E0 + S - cap), E0 + S)
+        return snaps
 
     # ---- reference call signatures
     def forward(self, x, proposals, pre_calculate=False, key_features=None):
@@ -922,6 +974,23 @@ class GeneralizedRCNNMEGA(nn.Module):
         if self.global_enable:
             fe.init_global()
 
+    def _dis_index(self, ns, device):
+        """rows of the concatenated window (ns[r] rows per record) that form the 'dis' set: the first advanced_num of
+        each record.  Cached per row-count signature (one signature in steady state)."""
+        cache = getattr(self, "_dis_cache", None)
+        if cache is None or not isinstance(cache, dict):
+            cache = self._dis_cache = {}
+        hit = cache.get(ns)
+        if hit is None or hit.device != device:
+            an, rows, off = self.advanced_num, [], 0
+            for n in ns:
+                rows.append(torch.arange(off, off + min(an, n)))
+                off += n
+            if len(cache) > 64:
+                cache.clear()
+            hit = cache[ns] = torch.cat(rows).to(device)
+        return hit
+
     def _window(self):
         """Concatenated local window (oldest first) in the reference's terms (:213-216)."""
         bn, an = self.base_num, self.advanced_num
@@ -929,15 +998,7 @@ class GeneralizedRCNNMEGA(nn.Module):
         rois = torch.cat([r["boxes"][:n] for r, n in zip(self.records, ns)], 0)
         feats = torch.cat([r["feats"][:n] for r, n in zip(self.records, ns)], 0)
         rois_dis = torch.cat([r["boxes"][:min(an, n)] for r, n in zip(self.records, ns)], 0)
-        cache = getattr(self, "_dis_cache", None)
-        if cache is None or cache[0] != ns or cache[1].device != feats.device:
-            rows, off = [], 0
-            for n in ns:
-                rows.append(torch.arange(off, off + min(an, n)))
-                off += n
-            cache = (ns, torch.cat(rows).to(feats.device))
-            self._dis_cache = cache
-        return rois, rois_dis, feats, cache[1]
+        return rois, rois_dis, feats, self._dis_index(ns, feats.device), ns
 
     @torch.no_grad()
     def step(self, new_local=None, new_globals=(), im_size=None, defer=False):
@@ -951,7 +1012,7 @@ class GeneralizedRCNNMEGA(nn.Module):
         for g in new_globals:
             fe.update_global(g["feats"][:self.base_num])
         key = self.records[self.key_frame_location]
-        rois, rois_dis, x_ref, dis_index = self._window()
+        rois, rois_dis, x_ref, dis_index, _ = self._window()
         x = fe.aggregate(key["feats"], key["boxes"], rois, rois_dis, x_ref, dis_index)
         logits, deltas = self.roi_heads.box.predictor(x)
         self.last_logits = logits
@@ -972,10 +1033,67 @@ class GeneralizedRCNNMEGA(nn.Module):
         for g in new_globals:
             fe.update_global(g["feats"][:self.base_num])
         key = self.records[self.key_frame_location]
-        rois, rois_dis, x_ref, dis_index = self._window()
+        rois, rois_dis, x_ref, dis_index, ns = self._window()
         glob = fe.global_cache[-1].get("feats") if (self.global_enable and fe.global_cache) else None
         return {"x": key["feats"], "rois_key": key["boxes"], "scores": key["scores"], "rois": rois,
-                "rois_dis": rois_dis, "x_ref": x_ref, "dis_index": dis_index, "glob": glob}
+                "rois_dis": rois_dis, "x_ref": x_ref, "dis_index": dis_index, "dis_key": ns, "glob": glob}
+
+    def prepare_batch(self, steps):
+        """prepare_step() for S consecutive key frames, steps = [(new_local or None, new_globals), ...]: the same
+        snapshots, but the local windows -- 25 records sliding by one per key frame -- are row ranges of ONE tape of the
+        S + 24 records involved (3 concatenations per batch instead of 3 per key frame), and so are the global pools."""
+        fe = self.roi_heads.box.feature_extractor
+        bn, an, cap = self.base_num, self.advanced_num, self.records.maxlen
+        L, ends = list(self.records), []
+        for new_local, _ in steps:
+            if new_local is not None:
+                self.records.append(new_local)
+                L.append(new_local)
+            ends.append(len(L))                           # frame j's window = the last <= cap records of L[:ends[j]]
+        lo0 = max(0, ends[0] - cap)
+        used = L[lo0:]
+        ns = [min(bn, r["boxes"].shape[0]) for r in used]
+        nd = [min(an, n) for n in ns]
+        tape_r = torch.cat([r["boxes"][:n] for r, n in zip(used, ns)], 0)
+        tape_f = torch.cat([r["feats"][:n] for r, n in zip(used, ns)], 0)
+        tape_d = torch.cat([r["boxes"][:n] for r, n in zip(used, nd)], 0)
+        offc, offd = [0], [0]
+        for n, d in zip(ns, nd):
+            offc.append(offc[-1] + n)
+            offd.append(offd[-1] + d)
+        # global pools: a sliding window over the pushed entries as well
+        globs = [None] * len(steps)
+        if self.global_enable:
+            gq = fe.global_queue_list[0]["feats"]
+            G, gends = list(gq), []
+            for _, new_globals in steps:
+                for g in new_globals:
+                    e = g["feats"][:bn]
+                    gq.append(e)
+                    G.append(e)
+                gends.append(len(G))
+            if G:
+                glo0 = max(0, gends[0] - gq.maxlen)
+                gused = G[glo0:]
+                tape_g = torch.cat(gused, 0) if len(gused) > 1 else gused[0]
+                goff = [0]
+                for e in gused:
+                    goff.append(goff[-1] + e.shape[0])
+                for j, ge in enumerate(gends):
+                    if ge > 0:
+                        globs[j] = tape_g[goff[max(0, ge - gq.maxlen) - glo0]:goff[ge - glo0]]
+                if globs[-1] is not None:
+                    fe.global_cache[0]["feats"] = globs[-1]
+        frames = []
+        for j, e in enumerate(ends):
+            a, b = max(0, e - cap) - lo0, e - lo0
+            key = used[a + self.key_frame_location]
+            nsj = tuple(ns[a:b])
+            frames.append({"x": key["feats"], "rois_key": key["boxes"], "scores": key["scores"],
+                           "rois": tape_r[offc[a]:offc[b]], "rois_dis": tape_d[offd[a]:offd[b]],
+                           "x_ref": tape_f[offc[a]:offc[b]], "dis_index": self._dis_index(nsj, tape_f.device),
+                           "dis_key": nsj, "glob": globs[j]})
+        return frames
 
     @torch.no_grad()
     def step_batch(self, frames, im_size, shard=None):

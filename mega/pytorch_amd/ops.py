@@ -392,12 +392,19 @@ def relation_attention_batched(items, groups=16):
     lib = _lib.load()
     dt = items[0]["q"].dtype
     outs, wss = [], []
+    # one output buffer, the problems' row blocks in order (the next batched GEMM reads it without a concatenation)
+    out_all = torch.empty((sum(it["q"].shape[0] for it in items), groups * 64), dtype=dt, device=items[0]["q"].device)
+    o = 0
     for it in items:
         q, k, vt, pos = it["q"], it["k"], it["vt"], it.get("pos")
         _gpu(q, k, vt, pos, it.get("resid"), it.get("bias_v"))
-        assert q.dtype == k.dtype == vt.dtype == dt and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+        assert q.dtype == k.dtype == vt.dtype == dt and q.is_contiguous() and k.is_contiguous()
+        # vt: [G*64, >= ceil32(Nk)] with unit column stride; a column block of a wider matrix is fine (16-B aligned)
+        assert vt.stride(1) == 1 and vt.shape[1] >= (it["Nk"] + 31) // 32 * 32 and vt.data_ptr() % 16 == 0 and \
+            (vt.stride(0) * vt.element_size()) % 16 == 0
         assert (pos is None) == (items[0].get("pos") is None) and (pos is None or pos.dtype == items[0]["pos"].dtype)
-        outs.append(torch.empty((q.shape[0], groups * 64), dtype=dt, device=q.device))
+        outs.append(out_all[o:o + q.shape[0]])
+        o += q.shape[0]
         nb = lib.mega_relation_attention_workspace_bytes(q.shape[0], it["Nk"], groups)
         wss.append(_ws(nb, q.device) if nb else None)
     for o in range(0, len(items), 16):
@@ -409,7 +416,7 @@ def relation_attention_batched(items, groups=16):
             q, k, vt, pos, resid = it["q"], it["k"], it["vt"], it.get("pos"), it.get("resid")
             Nq, Nk = q.shape[0], it["Nk"]
             d.q, d.k, d.vt, d.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), outs[o + i].data_ptr()
-            d.ldq, d.ldk, d.ldv, d.ldo, d.Nq, d.Nk = q.shape[1], k.shape[1], vt.shape[1], groups * 64, Nq, Nk
+            d.ldq, d.ldk, d.ldv, d.ldo, d.Nq, d.Nk = q.shape[1], k.shape[1], vt.stride(0), groups * 64, Nq, Nk
             d.resid, d.ldr = _ptr(resid), 0 if resid is None else resid.shape[1]
             d.bias_v = _ptr(it.get("bias_v"))
             if pos is not None and pos.dtype == torch.bfloat16:

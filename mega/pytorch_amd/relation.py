@@ -71,32 +71,62 @@ def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=Tru
     return (out, k, vt) if return_kv else out
 
 
-def _cat(ts):
-    return ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
+def cat_rows(ts):
+    """torch.cat(ts, 0) for 2-D row blocks -- without a copy when the pieces already ARE consecutive row blocks of one
+    buffer (slices of a batched GEMM / attention output handed back in order)."""
+    ts = [t for t in ts if t.shape[0] > 0] or list(ts[:1])
+    if len(ts) == 1:
+        return ts[0]
+    t0 = ts[0]
+    if t0.dim() == 2 and all(t.dim() == 2 and t.is_contiguous() and t.dtype == t0.dtype and t.device == t0.device
+                             and t.shape[1] == t0.shape[1] for t in ts):
+        base, ptr, es = t0.untyped_storage().data_ptr(), t0.data_ptr(), t0.element_size()
+        for t in ts:
+            if t.data_ptr() != ptr or t.untyped_storage().data_ptr() != base:
+                break
+            ptr += t.numel() * es
+        else:
+            rows = sum(t.shape[0] for t in ts)
+            return t0.as_strided((rows, t0.shape[1]), (t0.shape[1], 1), t0.storage_offset())
+    return torch.cat(ts, dim=0)
 
 
-def relation_project_batched(w, xs, refs):
+def _flat(xs):
+    """problems given as a tensor or as a tuple of row blocks -> (flat list of blocks, rows per problem)"""
+    flat, rows = [], []
+    for x in xs:
+        parts = list(x) if isinstance(x, (tuple, list)) else [x]
+        flat += parts
+        rows.append(sum(p.shape[0] for p in parts))
+    return flat, rows
+
+
+def relation_project_batched(w, xs, refs, want_x=False):
     """The Wq / Wk / Wv projections of several INDEPENDENT attention problems (the key frames of one engine batch) as
     ONE GEMM each over the concatenated rows: M = sum of the rows, so the 64x64-tile launches of the per-frame form
     become a few big-tile launches.  Every GEMM kernel is batch-invariant (an output row never depends on the rows it
     is batched with), so the slices have the same bits as relation_attention_forward's own projections.
-    xs[i] [Nq_i,1024] queries, refs[i] [Nr_i,1024] keys/values -> (qs, ks, vts): qs[i] [Nq_i,1024], ks[i] [Nr_i,1024],
-    vts[i] [1024,Nr_i] (views into the batched results; a caller that keeps a slice must copy it)."""
-    nq = [x.shape[0] for x in xs]
-    nr = [r.shape[0] for r in refs]
-    r_all = _cat(refs)
+    xs[i] [Nq_i,1024] queries, refs[i] [Nr_i,1024] keys/values -- each a tensor or a tuple of row blocks (concatenated
+    here, once, together with everything else) -> (qs, ks, vts): qs[i] [Nq_i,1024], ks[i] [Nr_i,1024],
+    vts[i] [1024,Nr_i] (views into the batched results; a caller that keeps a slice must copy it).
+    want_x: also return the views xcat[i] [Nq_i,1024] of the concatenated queries (the attention's residual)."""
+    xf, nq = _flat(xs)
+    rf, nr = _flat(refs)
+    r_all = cat_rows(rf)
     k_all = ops.linear(r_all, w.wk, w.bk)
     vt_all = ops.linear_transposed(w.wv, r_all, (r_all.shape[0] + 31) // 32 * 32)
-    q_all = ops.linear(_cat(xs), w.wq, w.bq)
-    qs, ks, vts = [], [], []
+    x_all = cat_rows(xf)
+    q_all = ops.linear(x_all, w.wq, w.bq)
+    qs, ks, vts, xc = [], [], [], []
     oq = orr = 0
     for i in range(len(xs)):
         qs.append(q_all[oq:oq + nq[i]])
+        xc.append(x_all[oq:oq + nq[i]])
         ks.append(k_all[orr:orr + nr[i]])
         vts.append(vt_all[:, orr:orr + nr[i]])
         oq += nq[i]
         orr += nr[i]
-    return qs, ks, vts
+    return (qs, ks, vts, xc) if want_x else (qs, ks, vts)
 
 
 def relation_attend(w, x, q, k, vt, rois_q=None, rois_k=None, mem_kv=None, residual=True):
@@ -122,22 +152,29 @@ def relation_attend(w, x, q, k, vt, rois_q=None, rois_k=None, mem_kv=None, resid
 
 def relation_attend_batched(w, jobs, residual=True):
     """relation_attend for several problems of the SAME weights (the key frames of a step-batch at one stage) with the
-    position logits and the attention core each as ONE launch: jobs = list of dict(x, q, k, vt, rois_q, rois_k, mem_kv).
-    Same bits per problem as relation_attend."""
+    position logits and the attention core each as ONE launch: jobs = list of dict(x, q, k, vt, rois_q, rois_k, mem_kv),
+    or, with the key sets already assembled by the caller, dict(x, q, k_all [Nk,1024], vt_all [1024,>=ceil32(Nk)]
+    (unit column stride, any row stride), Nk, rois_q, rois_k).  Same bits per problem as relation_attend.
+    The outputs are consecutive row blocks of one buffer (cat_rows() of them in order is free)."""
+    if not jobs:
+        return []
     items, rq, rk = [], [], []
     for j in jobs:
-        k, vt = j["k"], j["vt"]
-        Nk = k.shape[0]
-        vparts = [vt]
-        if j.get("mem_kv") is not None:
-            k_mem, vt_mem = j["mem_kv"]
-            Nk += k_mem.shape[0]
-            k = torch.cat([k, k_mem], dim=0)
-            vparts.append(vt_mem)
-        ldv = (Nk + 31) // 32 * 32
-        if ldv > Nk:
-            vparts.append(vt.new_zeros((vt.shape[0], ldv - Nk)))
-        vv = torch.cat(vparts, dim=1) if len(vparts) > 1 else vt.contiguous()
+        if "k_all" in j:
+            k, vv, Nk = j["k_all"], j["vt_all"], j["Nk"]
+        else:
+            k, vt = j["k"], j["vt"]
+            Nk = k.shape[0]
+            vparts = [vt]
+            if j.get("mem_kv") is not None:
+                k_mem, vt_mem = j["mem_kv"]
+                Nk += k_mem.shape[0]
+                k = torch.cat([k, k_mem], dim=0)
+                vparts.append(vt_mem)
+            ldv = (Nk + 31) // 32 * 32
+            if ldv > Nk:
+                vparts.append(vt.new_zeros((vt.shape[0], ldv - Nk)))
+            vv = torch.cat(vparts, dim=1) if len(vparts) > 1 else vt.contiguous()
         items.append({"q": j["q"], "k": k, "vt": vv, "Nk": Nk, "resid": j["x"] if residual else None, "bias_v": w.bv})
         rq.append(j.get("rois_q"))
         rk.append(j.get("rois_k"))
