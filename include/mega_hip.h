@@ -129,6 +129,18 @@ int mega_postprocess(const float* logits, const float* deltas, const float* prop
                      long long* out_labels, int* out_cnt, float* probs_out, void* ws, size_t ws_bytes,
                      void* stream);
 
+/* The same post-processor for B images of R rows each in one launch chain (the key frames of a step-batch: the
+ * reference calls PostProcessor.forward once per key frame, tools/test_net.py -> engine/inference.py:23-46).
+ *   logits [B][R][NC], deltas [B][R][NC*4], props [B][R][4], nprop device int[B] or NULL; outputs [B][(NC-1)*R]...,
+ *   out_cnt device int[B].  Image b's results have the bits of mega_postprocess on image b alone (same kernels,
+ *   the image is a grid dimension). */
+size_t mega_postprocess_batched_workspace_bytes(int B, int R, int NC);
+int mega_postprocess_batched(const float* logits, const float* deltas, const float* props, const int* nprop, int B,
+                             int R, int NC, float wx, float wy, float ww, float wh, float im_w, float im_h,
+                             float score_thresh, float nms_thresh, int strict_gt, int max_det, float* out_boxes,
+                             float* out_scores, long long* out_labels, int* out_cnt, float* probs_out, void* ws,
+                             size_t ws_bytes, void* stream);
+
 /* Position-embedding logits of the relation module: log(relu(Wg . pe(q,k) + bg) + 1e-6).
  * Replaces extract_position_matrix + extract_position_embedding + the Wgs 1x1 conv + relu + log
  * (roi_box_feature_extractors.py:147-176,:126-144,:593-597,:630) without materialising the

@@ -33,6 +33,9 @@ SIGNATURES = {
     "mega_postprocess_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mega_postprocess": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_float] * 8 + [c_int, c_int] + [c_void_p] * 6 +
                          [c_size_t, c_void_p]),
+    "mega_postprocess_batched_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mega_postprocess_batched": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_float] * 8 + [c_int, c_int] +
+                                 [c_void_p] * 6 + [c_size_t, c_void_p]),
     "mega_position_logits": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "mega_position_logits_tiled": (c_int, [c_void_p] * 6 + [c_int] * 2 + [c_void_p]),
     "mega_relation_attention_tiled_pos": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,

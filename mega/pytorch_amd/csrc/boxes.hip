@@ -380,6 +380,7 @@ __global__ void gather_kept_kernel(const float4* __restrict__ boxes, const float
 
 // ---------------------------------------------------------------------------------------------- box-head post-processing
 // P1: softmax + per-class decode (weights wx,wy,ww,wh) + clip + score threshold.
+// Image b = blockIdx.y of a batch (every image R rows):
 // logits [R][NC], deltas [R][NC*4], props [R][4]  ->  cboxes [NC-1][R][4], cscores [NC-1][R] (-1 when below thr)
 __global__ void post_prepare_kernel(const float* __restrict__ logits, const float* __restrict__ deltas,
                                     const float4* __restrict__ props, const int* __restrict__ nprop_ptr, int R, int NC,
@@ -388,7 +389,14 @@ __global__ void post_prepare_kernel(const float* __restrict__ logits, const floa
                                     float* __restrict__ probs_out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
-  const int nprop = nprop_ptr ? min(*nprop_ptr, R) : R;
+  const int b = blockIdx.y;
+  logits += (size_t)b * R * NC;
+  deltas += (size_t)b * R * NC * 4;
+  props += (size_t)b * R;
+  cboxes += (size_t)b * (NC - 1) * R;
+  cscores += (size_t)b * (NC - 1) * R;
+  if (probs_out) probs_out += (size_t)b * R * NC;
+  const int nprop = nprop_ptr ? min(nprop_ptr[b], R) : R;
   const bool live = r < nprop;
   const float* lg = logits + (size_t)r * NC;
   float mx = -INFINITY;
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(256) void post_sort_kernel(const float4* __restrict
 
 // P4: class-major / proposal-ascending compaction of the kept detections, then the
 // detections_per_img cut: keep score >= (D - max_det + 1)-th smallest score (inference.py:139-148).
-// flags [NCm1][R]; outputs capacity NCm1*R.
+// flags [NCm1][R]; outputs capacity NCm1*R.  One block per image (blockIdx.x) of a batch.
 __global__ __launch_bounds__(1024) void post_finalize_kernel(const unsigned char* __restrict__ flags,
                                                              const float4* __restrict__ cboxes,
                                                              const float* __restrict__ cscores, int NCm1, int R,
@@ -468,6 +476,11 @@ __global__ __launch_bounds__(1024) void post_finalize_kernel(const unsigned char
   __shared__ unsigned sh_prefix, sh_k;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int total = NCm1 * R;
+  {
+    const size_t img = (size_t)blockIdx.x * total;
+    flags += img; cboxes += img; cscores += img; tmp_idx += img;
+    out_boxes += img; out_scores += img; out_labels += img; out_cnt += blockIdx.x;
+  }
   if (tid == 0) base = 0;
   __syncthreads();
   // pass 1: compaction of kept (class, proposal) pairs into tmp_idx (flat index c*R + r), order preserved
@@ -685,25 +698,31 @@ extern "C" int mega_rpn_select(const float* rpn_out, const float* cell_anchors, 
 // Box-head post-processor for one image (roi_heads/box_head/inference.py:45-149).
 //   logits [R][NC], deltas [R][NC*4], props [R][4], nprop (device int, may be null -> R)
 //   outputs (capacity (NC-1)*R rows): out_boxes [.][4], out_scores, out_labels (i64), out_cnt (device int)
-extern "C" size_t mega_postprocess_workspace_bytes(int R, int NC) {
-  const size_t m = (size_t)(NC - 1) * R;
-  return align_up(m * 16, 256) * 2 + align_up(m * 4, 256) * 4 + align_up(m, 256) + 256 * 2 +
-         mega_nms_workspace_bytes(NC - 1, R);
+extern "C" size_t mega_postprocess_batched_workspace_bytes(int B, int R, int NC) {
+  const size_t m = (size_t)B * (NC - 1) * R;
+  return 2 * align_up(m * 16, 256) + 4 * align_up(m * 4, 256) + align_up(m, 256) +
+         2 * align_up((size_t)B * (NC - 1) * 4, 256) + mega_nms_workspace_bytes(B * (NC - 1), R);
 }
 
-extern "C" int mega_postprocess(const float* logits, const float* deltas, const float* props, const int* nprop, int R,
-                                int NC, float wx, float wy, float ww, float wh, float im_w, float im_h,
-                                float score_thresh, float nms_thresh, int strict_gt, int max_det, float* out_boxes,
-                                float* out_scores, long long* out_labels, int* out_cnt, float* probs_out, void* ws,
-                                size_t ws_bytes, void* stream) {
+extern "C" size_t mega_postprocess_workspace_bytes(int R, int NC) {
+  return mega_postprocess_batched_workspace_bytes(1, R, NC);
+}
+
+extern "C" int mega_postprocess_batched(const float* logits, const float* deltas, const float* props, const int* nprop,
+                                        int B, int R, int NC, float wx, float wy, float ww, float wh, float im_w,
+                                        float im_h, float score_thresh, float nms_thresh, int strict_gt, int max_det,
+                                        float* out_boxes, float* out_scores, long long* out_labels, int* out_cnt,
+                                        float* probs_out, void* ws, size_t ws_bytes, void* stream) {
   mega_clear_error();
-  if (!logits || !deltas || !props || !out_boxes || !out_scores || !out_labels || !out_cnt || !ws || R <= 0 || NC < 2)
+  if (!logits || !deltas || !props || !out_boxes || !out_scores || !out_labels || !out_cnt || !ws || R <= 0 || NC < 2 ||
+      B <= 0 || B > 65535)
     return MEGA_ERR_ARG;
   if (R > 1024) return MEGA_ERR_ARG;
-  if (ws_bytes < mega_postprocess_workspace_bytes(R, NC)) return MEGA_ERR_WS;
+  if (ws_bytes < mega_postprocess_batched_workspace_bytes(B, R, NC)) return MEGA_ERR_WS;
   hipStream_t st = (hipStream_t)stream;
   const int C1 = NC - 1;
-  const size_t m = (size_t)C1 * R;
+  const int P = B * C1;                      // (image, class) problems, image-major: the layout of every array below
+  const size_t m = (size_t)P * R;
   unsigned char* w = (unsigned char*)ws;
   float4* cboxes = (float4*)w; w += align_up(m * 16, 256);
   float4* sboxes = (float4*)w; w += align_up(m * 16, 256);
@@ -712,18 +731,28 @@ extern "C" int mega_postprocess(const float* logits, const float* deltas, const 
   int* keep_pos = (int*)w; w += align_up(m * 4, 256);
   int* tmp_idx = (int*)w; w += align_up(m * 4, 256);
   unsigned char* flags = w; w += align_up(m, 256);
-  int* counts = (int*)w; w += 256;
-  int* keep_cnt = (int*)w; w += 256;
+  int* counts = (int*)w; w += align_up((size_t)P * 4, 256);
+  int* keep_cnt = (int*)w; w += align_up((size_t)P * 4, 256);
   void* mws = w;
   (void)hipMemsetAsync(flags, 0, m, st);
-  hipLaunchKernelGGL(post_prepare_kernel, dim3(cdiv(R, 64)), dim3(64), 0, st, logits, deltas, (const float4*)props,
+  hipLaunchKernelGGL(post_prepare_kernel, dim3(cdiv(R, 64), B), dim3(64), 0, st, logits, deltas, (const float4*)props,
                      nprop, R, NC, wx, wy, ww, wh, logf(1000.f / 16.f), im_w, im_h, score_thresh, cboxes, cscores,
                      probs_out);
-  hipLaunchKernelGGL(post_sort_kernel, dim3(C1), dim3(256), 0, st, cboxes, cscores, R, sboxes, order, counts);
-  int rc = mega_nms_sorted((const float*)sboxes, counts, nullptr, order, C1, R, nms_thresh, strict_gt, R, keep_pos,
-                           keep_cnt, flags, mws, mega_nms_workspace_bytes(C1, R), stream);
+  hipLaunchKernelGGL(post_sort_kernel, dim3(P), dim3(256), 0, st, cboxes, cscores, R, sboxes, order, counts);
+  int rc = mega_nms_sorted((const float*)sboxes, counts, nullptr, order, P, R, nms_thresh, strict_gt, R, keep_pos,
+                           keep_cnt, flags, mws, mega_nms_workspace_bytes(P, R), stream);
   if (rc != MEGA_OK) return rc;
-  hipLaunchKernelGGL(post_finalize_kernel, dim3(1), dim3(1024), 0, st, flags, cboxes, cscores, C1, R, max_det,
+  hipLaunchKernelGGL(post_finalize_kernel, dim3(B), dim3(1024), 0, st, flags, cboxes, cscores, C1, R, max_det,
                      (float4*)out_boxes, out_scores, out_labels, out_cnt, tmp_idx);
   return mega_check_launch();
+}
+
+extern "C" int mega_postprocess(const float* logits, const float* deltas, const float* props, const int* nprop, int R,
+                                int NC, float wx, float wy, float ww, float wh, float im_w, float im_h,
+                                float score_thresh, float nms_thresh, int strict_gt, int max_det, float* out_boxes,
+                                float* out_scores, long long* out_labels, int* out_cnt, float* probs_out, void* ws,
+                                size_t ws_bytes, void* stream) {
+  return mega_postprocess_batched(logits, deltas, props, nprop, 1, R, NC, wx, wy, ww, wh, im_w, im_h, score_thresh,
+                                  nms_thresh, strict_gt, max_det, out_boxes, out_scores, out_labels, out_cnt, probs_out,
+                                  ws, ws_bytes, stream);
 }

@@ -830,6 +830,17 @@ class PostProcessor(nn.Module):
                                bl.bbox.float().contiguous(), None, self.weights, im_w, im_h,
                                self.score_thresh, self.nms, self.detections_per_img, self.strict_gt)
 
+    def run_batch(self, x, boxes, size):
+        """run() for several images with the same number of rows (x = the concatenated logits / deltas, boxes = the
+        list of their [R,4] proposal boxes): one launch chain; returns one run()-style tuple per image."""
+        class_logits, box_regression = x
+        B = len(boxes)
+        ob, os_, ol, oc = ops.postprocess_batched(class_logits.float().contiguous(), box_regression.float().contiguous(),
+                                                  torch.cat([b.float() for b in boxes], dim=0), B, self.weights,
+                                                  size[0], size[1], self.score_thresh, self.nms,
+                                                  self.detections_per_img, self.strict_gt)
+        return [(ob[b], os_[b], ol[b], oc[b:b + 1]) for b in range(B)]
+
     @staticmethod
     def materialize(padded, n, size):
         ob, os_, ol, _ = padded
@@ -1095,6 +1106,8 @@ class GeneralizedRCNNMEGA(nn.Module):
                            "dis_key": nsj, "glob": globs[j]})
         return frames
 
+    batched_postprocess = True      # post-processing of a step-batch's key frames as one launch chain
+
     @torch.no_grad()
     def step_batch(self, frames, im_size, shard=None):
         """Aggregation + predictor + post-processing of the key frames prepared by prepare_step(), stage by stage over
@@ -1112,11 +1125,14 @@ class GeneralizedRCNNMEGA(nn.Module):
             logits, deltas = self.roi_heads.box.predictor(torch.cat([xs[t] for t in own], dim=0) if len(own) > 1
                                                           else xs[own[0]].contiguous())
             o = 0
+            same = len(own) > 1 and len(set(n)) == 1 and self.batched_postprocess
+            if same:       # the usual case (every key frame has all its proposals): one launch chain for all
+                res = pp.run_batch((logits, deltas), [frames[t]["rois_key"] for t in own], im_size)
             for j, t in enumerate(own):
                 lg, dl = logits[o:o + n[j]], deltas[o:o + n[j]]
                 o += n[j]
                 self.last_logits_batch[t] = lg
-                outs[t] = pp.run((lg, dl), BoxList(frames[t]["rois_key"], im_size, "xyxy"))
+                outs[t] = res[j] if same else pp.run((lg, dl), BoxList(frames[t]["rois_key"], im_size, "xyxy"))
             self.last_logits = self.last_logits_batch[own[-1]]
         if shard is not None:
             outs = shard.gather_detections(outs, len(frames), pp.detections_per_img, frames[0]["rois_key"].device)

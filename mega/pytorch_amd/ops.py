@@ -290,6 +290,41 @@ def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh,
     return (ob, os_, ol, oc, probs) if want_probs else (ob, os_, ol, oc)
 
 
+def postprocess_batched(logits, deltas, props, B, weights, im_w, im_h, score_thresh, nms_thresh, max_det,
+                        strict_gt=True):
+    """B images of R = rows / B proposals each (logits [B*R,NC], deltas [B*R,NC*4], props [B*R,4]) in one launch chain.
+    Returns (boxes [B,cap,4], scores [B,cap], labels [B,cap] i64, counts [B] i32 device); image b has the bits of
+    postprocess() on its own rows."""
+    _gpu(logits, deltas, props)
+    lib = _lib.load()
+    NC = logits.shape[1]
+    assert logits.shape[0] % B == 0
+    R = logits.shape[0] // B
+    if R > 1024:
+        raise ValueError("postprocess: %d proposals; the per-class sort takes at most 1024 per image "
+                         "(MODEL.RPN.POST_NMS_TOP_N_TEST)" % R)
+    cap = (NC - 1) * R
+    dev = logits.device
+    ob = torch.empty((B, cap, 4), dtype=torch.float32, device=dev)
+    os_ = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    ol = torch.empty((B, cap), dtype=torch.int64, device=dev)
+    oc = torch.zeros((B,), dtype=torch.int32, device=dev)
+    nb = lib.mega_postprocess_batched_workspace_bytes(B, R, NC)
+    ws = _ws(nb, dev)
+    assert logits.dtype == torch.float32 and deltas.dtype == torch.float32 and props.dtype == torch.float32
+    assert logits.is_contiguous() and deltas.is_contiguous() and props.is_contiguous()
+    assert deltas.shape == (B * R, NC * 4) and props.shape == (B * R, 4)
+    wx, wy, ww, wh = weights
+    _tok = _pb("postprocess", 0.0, (logits.numel() + deltas.numel()) * 4)
+    rc = lib.mega_postprocess_batched(_ptr(logits), _ptr(deltas), _ptr(props), None, B, R, NC, wx, wy, ww, wh,
+                                      float(im_w), float(im_h), float(score_thresh), float(nms_thresh), int(strict_gt),
+                                      int(max_det), _ptr(ob), _ptr(os_), _ptr(ol), _ptr(oc), None, _ptr(ws), nb,
+                                      _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_postprocess_batched")
+    return ob, os_, ol, oc
+
+
 # ------------------------------------------------------------------------------------------------ relation module
 def position_logits(rois_q, rois_k, wg_t, bg, dim_mat, precise=True, tiled=False):
     """-> [16, Nq, ldp] f32 with ldp = roundup(Nk, 32).  precise=False: fast sin/cos (bf16 mode).

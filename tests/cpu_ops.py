@@ -94,6 +94,13 @@ def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh,
     return ob, os_, ol, torch.tensor([n], dtype=torch.int32)
 
 
+def postprocess_batched(logits, deltas, props, B, weights, im_w, im_h, score_thresh, nms_thresh, max_det, strict_gt=True):
+    R = logits.shape[0] // B
+    res = [postprocess(logits[b * R:(b + 1) * R], deltas[b * R:(b + 1) * R], props[b * R:(b + 1) * R], None, weights,
+                       im_w, im_h, score_thresh, nms_thresh, max_det, strict_gt) for b in range(B)]
+    return tuple(torch.stack([r[i] for r in res]) for i in range(3)) + (torch.cat([r[3] for r in res]),)
+
+
 def position_logits(rois_q, rois_k, wg_t, bg, dim_mat, precise=True, tiled=False):   # the twin always returns f32 rows
     pe = mo.cal_position_embedding(rois_q, rois_k)
     w = wg_t.t().contiguous().view(16, 64, 1, 1)
@@ -149,7 +156,7 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
 
 ALL = ["pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames", "position_logits_batched",
-       "relation_attention_batched"]
+       "relation_attention_batched", "postprocess_batched"]
 
 
 def dff_warp_scale(feats, flow, scale):

@@ -219,6 +219,29 @@ def test_postprocess(dev, R):
     assert (os_[:n].cpu() - ws).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("B,R", [(10, 300), (3, 77), (2, 1024)])
+def test_postprocess_batched_equals_per_image(dev, B, R):
+    """the image is a grid dimension of the same kernels: every image has the bits of its own mega_postprocess call"""
+    ops = _ops()
+    from oracle import mega_oracle as mo
+    g = torch.Generator().manual_seed(B * 1000 + R)
+    NC = 31
+    logits = (torch.randn((B * R, NC), generator=g) * 1.5).to(dev)
+    deltas = (torch.randn((B * R, NC * 4), generator=g) * 0.5).to(dev)
+    ctr = torch.rand((B * R, 2), generator=g) * torch.tensor([900., 500.])
+    wh = torch.rand((B * R, 2), generator=g) * 200 + 10
+    props = torch.cat([ctr - wh / 2, ctr + wh / 2], dim=1).clamp(min=0).to(dev)
+    cfg = mo.OracleCfg()
+    args = (cfg.bbox_reg_weights, 1000, 600, cfg.score_thresh, cfg.nms, cfg.detections_per_img, True)
+    ob, os_, ol, oc = ops.postprocess_batched(logits, deltas, props, B, *args)
+    for b in range(B):
+        sl = slice(b * R, (b + 1) * R)
+        wb, ws, wl, wc = ops.postprocess(logits[sl].contiguous(), deltas[sl].contiguous(), props[sl].contiguous(), None, *args)
+        n = int(wc.item())
+        assert int(oc[b].item()) == n and n > 0
+        assert torch.equal(ob[b, :n], wb[:n]) and torch.equal(os_[b, :n], ws[:n]) and torch.equal(ol[b, :n], wl[:n])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(300, 750, True), (675, 1111, True), (70, 33, False), (129, 64, True)])
 def test_relation_attention(dev, dtype, shape):

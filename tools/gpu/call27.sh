@@ -1,0 +1,6 @@
+mkdir -p gpurun_out/c27
+timeout 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "postprocess" > gpurun_out/c27/pytest_k.log 2>&1; tail -3 gpurun_out/c27/pytest_k.log
+timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/c27/b20.json 2> gpurun_out/c27/b20.err
+timeout 200 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/c27/b100.json 2> gpurun_out/c27/b100.err
+grep -h "timed region\|host ms\|Error\|error" gpurun_out/c27/*.err
+timeout 900 python -m pytest tests/test_e2e_gpu.py -m gpu -x -q > gpurun_out/c27/pytest.log 2>&1; tail -3 gpurun_out/c27/pytest.log
