@@ -12,6 +12,8 @@
 //
 // Ordering rule (documented deviation-free refinement): wherever the reference sorts scores with an
 // unspecified tie order (torch.topk / sort, nms.cu:74), these kernels sort by (score desc, index asc).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -55,6 +57,30 @@ __device__ __forceinline__ float dev_iou(const float4 a, const float4 b) {
   return interS / (Sa + Sb - interS);
 }
 
+// The decision `dev_iou(a, b) > thr` (strict_gt) or `>= thr` WITHOUT the division in all but borderline cases:
+// iou <> thr  <=>  interS <> thr * union; when the two sides differ by more than 1e-5 relative -- 40x the worst
+// rounding error of the quotient (<= 2.5 ulp for the device's f32 division) plus that of the product -- the answer
+// cannot depend on how the quotient rounds, otherwise the quotient is evaluated exactly as dev_iou does.
+__device__ __forceinline__ bool dev_suppresses_areas(const float4 a, const float Sa, const float4 b, const float Sb,
+                                                     float thr, int strict_gt) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+  const float interS = width * height;
+  const float uni = Sa + Sb - interS;
+  if (thr > 0.f && uni > 0.f) {
+    const float rhs = thr * uni;
+    if (interS > rhs * 1.00001f) return true;
+    if (interS < rhs * 0.99999f) return false;
+  }
+  const float iou = interS / uni;
+  return strict_gt ? (iou > thr) : (iou >= thr);
+}
+__device__ __forceinline__ bool dev_suppresses(const float4 a, const float4 b, float thr, int strict_gt) {
+  return dev_suppresses_areas(a, (a.z - a.x + 1.f) * (a.w - a.y + 1.f), b, (b.z - b.x + 1.f) * (b.w - b.y + 1.f), thr,
+                              strict_gt);
+}
+
 // ---------------------------------------------------------------------------------------------- NMS mask
 // boxes: [P][nmax][4] score-sorted; counts[P]; mask: [P][nmax][cbmax] u64 (only col-block >= row-block written)
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes, const int* __restrict__ counts,
@@ -76,9 +102,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
     u64 t = 0;
     const int start = (rb == cb) ? lane + 1 : 0;
     for (int c = start; c < col_size; ++c) {
-      const float iou = dev_iou(cur, cbox[c]);
-      const bool sup = strict_gt ? (iou > thr) : (iou >= thr);
-      if (sup) t |= 1ULL << c;
+      if (dev_suppresses(cur, cbox[c], thr, strict_gt)) t |= 1ULL << c;
     }
     mask[((size_t)p * nmax + i) * cbmax + cb] = t;
   }
@@ -154,6 +178,146 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ ma
     }
   }
   if (lane == 0) keep_cnt[p] = nkeep < max_keep ? nkeep : max_keep;
+}
+
+// ---------------------------------------------------------------------------------------------- NMS, lazy form
+// The mask form above evaluates all n^2/2 pairs although greedy NMS only ever needs the rows of the KEPT boxes, and
+// the RPN stops after post_nms_top_n (300) of its 6000 candidates.  One 1024-thread block per problem keeps the
+// score-sorted boxes in LDS (16 B x 8192 max) and walks them in windows of 1024 boxes (one box per thread, in
+// registers), each window in 64-box blocks:
+//   window entry   : every box of the window is tested against the boxes kept so far (boxes of windows the walk
+//                    never reaches are never tested at all)
+//   A  all threads : the 64 x 64 suppression bits inside the block (4 pairs per thread)
+//   B  wave 0      : the serial scan of nms.cu:97-113 over those bits -> this block's kept boxes
+//   C  all threads : the rest of the window against the block's kept boxes
+// and stops as soon as max_keep boxes are kept.  Same IoU arithmetic, same comparison, same visiting order: the kept
+// set is the mask form's, bit for bit (tests/test_kernels_gpu.py::test_nms_golden_and_random, test_rpn_select).
+__global__ __launch_bounds__(1024) void nms_lazy_kernel(const float4* __restrict__ boxes, const int* __restrict__ counts,
+                                                        const unsigned char* __restrict__ valid,
+                                                        const int* __restrict__ order, int nmax, float thr,
+                                                        int strict_gt, int max_keep, int* __restrict__ keep_pos,
+                                                        int* __restrict__ keep_cnt, unsigned char* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lz_smem[];
+  float4* sb = reinterpret_cast<float4*>(lz_smem);                       // [nmax] boxes
+  unsigned char* rem = lz_smem + (size_t)nmax * 16;                       // [nmax] 1 = suppressed / invalid
+  unsigned short* klist = reinterpret_cast<unsigned short*>(rem + (((size_t)nmax + 15) & ~(size_t)15));   // kept, in order
+  __shared__ float4 kb[64];
+  __shared__ unsigned diag_lo[2][64], diag_hi[2][64];
+  __shared__ int s_nk, s_total;
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(counts[p], nmax);
+  const float4* bx = boxes + (size_t)p * nmax;
+  for (int j = tid; j < n; j += 1024) {
+    sb[j] = bx[j];
+    rem[j] = (valid && !valid[(size_t)p * nmax + j]) ? 1 : 0;
+  }
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  const int nblk = (n + 63) >> 6;
+  // A(blk): bit c of row r = box b0+r suppresses box b0+c (c > r); double-buffered so that A(blk+1) shares an
+  // epoch (one barrier interval) with C(blk)
+  auto phase_a = [&](int blk) {
+    const int b0 = blk * 64, bsz = min(64, n - b0);
+    const int r = tid >> 4, c0 = (tid & 15) * 4;
+    unsigned bits = 0;
+    if (r < bsz) {
+      const float4 me = sb[b0 + r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        if (c > r && c < bsz) {
+          if (dev_suppresses(me, sb[b0 + c], thr, strict_gt)) bits |= 1u << (c & 31);
+        }
+      }
+    }
+    // the 16 threads of a row are consecutive lanes: OR their 4-bit groups, one writer per row
+    unsigned lo = c0 < 32 ? bits : 0u, hi = c0 < 32 ? 0u : bits;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      lo |= __shfl_xor(lo, d);
+      hi |= __shfl_xor(hi, d);
+    }
+    if ((tid & 15) == 0) { diag_lo[blk & 1][r] = lo; diag_hi[blk & 1][r] = hi; }
+  };
+  if (nblk > 0) phase_a(0);
+  __syncthreads();
+  bool done = false;
+  for (int ws = 0; ws < n && !done; ws += 1024) {
+    // ---- window entry: this thread's box against everything kept so far
+    const int j = ws + tid;
+    float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool alive = false;
+    if (j < n) {
+      mine = sb[j];
+      alive = !rem[j];
+    }
+    const float my_area = (mine.z - mine.x + 1.f) * (mine.w - mine.y + 1.f);
+    if (ws > 0) {
+      const int K = s_total;
+      for (int k = 0; k < K; ++k) {
+        if (!__ballot(alive)) break;                      // the whole wavefront is dead
+        const float4 kbx = sb[klist[k]];
+        const float ka = (kbx.z - kbx.x + 1.f) * (kbx.w - kbx.y + 1.f);
+        if (alive && dev_suppresses_areas(kbx, ka, mine, my_area, thr, strict_gt)) alive = false;
+      }
+      if (j < n && !alive) rem[j] = 1;
+      __syncthreads();
+    }
+    const int blk_end = min(nblk, (ws >> 6) + 16);
+    for (int blk = ws >> 6; blk < blk_end; ++blk) {
+      const int b0 = blk * 64, bsz = min(64, n - b0);
+      // ---- B: serial scan (one wavefront; the 64-bit words of nms.cu map onto wave64 ballots); one step per KEPT box
+      if (wave == 0) {
+        const int i = b0 + lane;
+        const bool ok = lane < bsz && !rem[i];
+        u64 cand = __ballot(ok);
+        const unsigned dlo = diag_lo[blk & 1][lane], dhi = diag_hi[blk & 1][lane];
+        u64 kept = 0;
+        while (cand) {
+          const int t = __ffsll((long long)cand) - 1;
+          kept |= 1ULL << t;
+          const u64 sup = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, t) << 32) |
+                          (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, t);
+          cand &= ~(sup | (1ULL << t));
+        }
+        const int base = s_total;
+        if ((kept >> lane) & 1ULL) {
+          const int k = __popcll(kept & ((1ULL << lane) - 1ULL));
+          kb[k] = sb[i];
+          klist[base + k] = (unsigned short)i;            // (global results are written once, after the walk: a store
+        }                                                  //  here would put a memory round trip into every step)
+        if (lane == 0) {
+          s_nk = __popcll(kept);
+          s_total = base + __popcll(kept);
+        }
+      }
+      __syncthreads();
+      const int nk = s_nk;
+      if (s_total >= max_keep) { done = true; break; }
+      // ---- C: the kept boxes of this block against the later boxes of the window;  A of the next block
+      if (__ballot(alive && j >= b0 + 64)) {
+        for (int k = 0; k < nk; ++k) {
+          const float4 kbx = kb[k];
+          const float ka = (kbx.z - kbx.x + 1.f) * (kbx.w - kbx.y + 1.f);
+          if (alive && j >= b0 + 64 && dev_suppresses_areas(kbx, ka, mine, my_area, thr, strict_gt)) {
+            alive = false;
+            rem[j] = 1;
+          }
+        }
+      }
+      if (blk + 1 < nblk) phase_a(blk + 1);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  // ---- results: kept positions (ascending = score-descending), flags
+  const int total = min(s_total, max_keep);
+  for (int k = tid; k < total; k += 1024) {
+    const int i = klist[k];
+    keep_pos[(size_t)p * max_keep + k] = i;
+    if (flags) flags[(size_t)p * nmax + (order ? order[(size_t)p * nmax + i] : i)] = 1;
+  }
+  if (tid == 0) keep_cnt[p] = total;
 }
 
 // ---------------------------------------------------------------------------------------------- generic sort
@@ -605,6 +769,15 @@ extern "C" int mega_nms_sorted(const float* boxes, const int* counts, const unsi
   if (ws_bytes < mega_nms_workspace_bytes(P, nmax)) return MEGA_ERR_WS;
   hipStream_t st = (hipStream_t)stream;
   const int cb = cdiv(nmax, 64);
+  static const int lazy_min = getenv("MEGA_NMS_LAZY_MIN") ? atoi(getenv("MEGA_NMS_LAZY_MIN")) : 1024;
+  if (nmax >= lazy_min) {        // long candidate lists (the RPN's 6000): only the kept boxes' rows are evaluated
+    const size_t lds = (((size_t)nmax * 17 + 15) & ~(size_t)15) + (size_t)nmax * 2 + 16;
+    if (hipFuncSetAttribute((const void*)nms_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return MEGA_ERR_LAUNCH;
+    hipLaunchKernelGGL(nms_lazy_kernel, dim3(P), dim3(1024), lds, st, (const float4*)boxes, counts, valid, order, nmax,
+                       thr, strict_gt, max_keep, keep_pos, keep_cnt, flags);
+    return mega_check_launch();
+  }
   u64* mask = (u64*)ws;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, P), dim3(64), 0, st, (const float4*)boxes, counts, mask, nmax, cb,
                      thr, strict_gt);

@@ -152,7 +152,8 @@ def test_nms_golden_and_random(dev):
             keep = ops.nms(b, s, thr, strict_gt=strict).cpu().tolist()
             assert keep == want, (thr, strict, keep)
     rng = np.random.RandomState(0)
-    for n, thr in [(1, 0.5), (63, 0.5), (64, 0.3), (65, 0.7), (300, 0.5), (1000, 0.7), (6000, 0.7)]:
+    for n, thr in [(1, 0.5), (63, 0.5), (64, 0.3), (65, 0.7), (300, 0.5), (1000, 0.7), (1024, 0.5), (2500, 0.3),
+                   (6000, 0.7), (8192, 0.6)]:   # >= 1024: the lazy one-block-per-problem kernel
         ctr = rng.rand(n, 2) * 500
         wh = rng.rand(n, 2) * 120 + 4
         boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], axis=1).astype(np.float32)

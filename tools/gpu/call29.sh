@@ -1,0 +1,5 @@
+mkdir -p gpurun_out/c29
+timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_edge_cases_gpu.py -m gpu -x -q -k "nms or rpn or postprocess" > gpurun_out/c29/pytest_k.log 2>&1; tail -3 gpurun_out/c29/pytest_k.log
+timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/c29/b20.json 2> gpurun_out/c29/b20.err
+timeout 200 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/c29/b100.json 2> gpurun_out/c29/b100.err
+grep -h "timed region\|Error\|error" gpurun_out/c29/*.err
