@@ -69,10 +69,10 @@ int mega_conv2d_nhwc_ws(const void* in, const void* w, const float* scale, const
  * out: NHWC [N][Ho][Wo][64], Ho = (H-1)/2+1. */
 int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, const float* scale, const float* bias, void* out,
                            int N, int H, int W, int out_dtype, void* stream);
-/* The same stem on the matrix cores (bf16 path): w_n160_bf16 = bf16 [64][160], row n = output channel, column
- * k = (c*7+r)*7+s for k < 147 and zero for the 13 pad columns; out: NHWC bf16.  Image pixels and weights are rounded
- * to bf16, accumulation is f32. */
-int mega_stem_conv_bn_relu_bf16(const float* in, const void* w_n160_bf16, const float* scale, const float* bias,
+/* The same stem on the matrix cores (bf16 path): w_n176_bf16 = bf16 [64][176], row n = output channel, column
+ * k = (c*7+r)*8+s for the 7 taps s of kernel row (c, r), zero for s = 7 and for the 8 pad columns; out: NHWC bf16.
+ * Image pixels and weights are rounded to bf16, accumulation is f32. */
+int mega_stem_conv_bn_relu_bf16(const float* in, const void* w_n176_bf16, const float* scale, const float* bias,
                                 void* out, int N, int H, int W, void* stream);
 
 /* F.max_pool2d(kernel 3, stride 2, padding 1) on NHWC (resnet.py:365). */

@@ -425,19 +425,20 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_sep_kernel(const T* __rest
 }
 
 // ------------------------------------------------------------------------------------ stem conv on the matrix cores
-// bf16 path: the same 7x7/2 conv as a GEMM  out[pixel][n] = sum_k A[pixel][k] * W[n][k],  k = (c*7 + r)*7 + s padded
-// 147 -> 160 = 10 MFMA steps of 16.  A block owns an 8 x 32 tile of output pixels: its 3 x 21 x 69 input patch sits in
-// LDS as bf16, and a lane builds its A fragment (one pixel, 8 consecutive k) with eight 2-byte LDS reads whose
-// addresses differ between lanes only by the pixel's column (stride 4 B: conflict-free).  W (bf16 [64][160], packed
-// once on the host) is staged with a 336-B row stride (conflict-free ds_read_b128).  3 GF per frame: the kernel is
-// bound by reading the f32 image and writing the 64-channel map, not by the MFMAs.
+// bf16 path: the same 7x7/2 conv as a GEMM  out[pixel][n] = sum_k A[pixel][k] * W[n][k].  K is laid out as 21 (c, r)
+// groups of 8 = the 7 taps of one kernel row + one zero-weight tap: k = (c*7 + r)*8 + s, 168 padded to 176 = 11 MFMA
+// steps of 16.  A block owns an 8 x 32 tile of output pixels: its 3 x 21 x 69 input patch sits in LDS as bf16, and a
+// lane's A fragment (one pixel, 8 consecutive k = one kernel row) is 16 contiguous, 4-byte-aligned bytes of the patch:
+// four ds_read_b32 whose addresses differ between lanes only by the pixel's column (stride 4 B: conflict-free).
+// W (bf16 [64][176], packed once on the host) is staged with a 368-B row stride (conflict-free ds_read_b128).
+// 3 GF per frame: the kernel is bound by reading the f32 image and writing the 64-channel map, not by the MFMAs.
 constexpr int SM_TY = 8, SM_TX = 32;
 constexpr int SM_PH = 2 * SM_TY + 5, SM_PW = 2 * SM_TX + 5, SM_PS = 72;   // patch rows / cols / row stride (elements)
-constexpr int SM_K = 160, SM_WS = 168;                                    // padded K, LDS weight row stride (elements)
+constexpr int SM_K = 176, SM_WS = 184;                                    // padded K, LDS weight row stride (elements)
 
-__host__ __device__ constexpr int stem_patch_off(int k) {   // LDS element offset of tap k relative to the pixel's origin
-  const int kk = k < 147 ? k : 146;                       // taps 147..159 meet zero weights: any valid address will do
-  return (kk / 49) * (SM_PH * SM_PS) + ((kk % 49) / 7) * SM_PS + (kk % 7);
+__host__ __device__ constexpr int stem_group_off(int g) {   // LDS element offset of (c, r) group g relative to the pixel
+  const int gg = g < 21 ? g : 20;                           // group 21 meets zero weights: any valid address will do
+  return (gg / 7) * (SM_PH * SM_PS) + (gg % 7) * SM_PS;
 }
 
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ in, const bf16_t* __restrict__ w,
@@ -450,18 +451,42 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
   const int n = blockIdx.z;
   const int oy0 = blockIdx.y * SM_TY, ox0 = blockIdx.x * SM_TX;
   const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
-  for (int e = tid; e < 3 * SM_PH * SM_PW; e += 256) {
+  // all of a thread's patch elements (17) and weight vectors (5) are REQUESTED before the first one is used: written
+  // as load-then-store per element the loop serialised 17 global-memory round trips per block (0.49 ms per 20 frames,
+  // 5 % of it MFMA time)
+  constexpr int NPL = (3 * SM_PH * SM_PW + 255) / 256, NWL = (64 * (SM_K / 8) + 255) / 256;
+  float pv[NPL];
+  uint4 wv[NWL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int e = tid + 256 * i;
     const int c = e / (SM_PH * SM_PW);
     const int rem = e - c * (SM_PH * SM_PW);
     const int y = rem / SM_PW, x = rem - y * SM_PW;
     const int iy = iy0 + y, ix = ix0 + x;
-    float v = 0.f;
-    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = in[((size_t)(n * 3 + c) * H + iy) * W + ix];
-    patch[(c * SM_PH + y) * SM_PS + x] = f32_to_bf16(v);
+    pv[i] = 0.f;
+    if (e < 3 * SM_PH * SM_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+      pv[i] = in[((size_t)(n * 3 + c) * H + iy) * W + ix];
   }
-  for (int e = tid; e < 64 * (SM_K / 8); e += 256) {
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    const int e = tid + 256 * i;
     const int row = e / (SM_K / 8), v = e - row * (SM_K / 8);
-    *reinterpret_cast<uint4*>(&wl[row * SM_WS + v * 8]) = *reinterpret_cast<const uint4*>(w + row * SM_K + v * 8);
+    if (e < 64 * (SM_K / 8)) wv[i] = *reinterpret_cast<const uint4*>(w + row * SM_K + v * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int e = tid + 256 * i;
+    const int c = e / (SM_PH * SM_PW);
+    const int rem = e - c * (SM_PH * SM_PW);
+    const int y = rem / SM_PW, x = rem - y * SM_PW;
+    if (e < 3 * SM_PH * SM_PW) patch[(c * SM_PH + y) * SM_PS + x] = f32_to_bf16(pv[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    const int e = tid + 256 * i;
+    const int row = e / (SM_K / 8), v = e - row * (SM_K / 8);
+    if (e < 64 * (SM_K / 8)) *reinterpret_cast<uint4*>(&wl[row * SM_WS + v * 8]) = wv[i];
   }
   __syncthreads();
 
@@ -478,12 +503,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     uint4 a[2], b[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const unsigned short* base = patch + (2 * (2 * wave + i)) * SM_PS + 2 * p;
-      unsigned v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        v[e] = base[half ? stem_patch_off(ks * 16 + 8 + e) : stem_patch_off(ks * 16 + e)];
-      a[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+      const unsigned* base = reinterpret_cast<const unsigned*>(
+          patch + (2 * (2 * wave + i)) * SM_PS + 2 * p + (half ? stem_group_off(2 * ks + 1) : stem_group_off(2 * ks)));
+      a[i] = make_uint4(base[0], base[1], base[2], base[3]);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -515,13 +537,13 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int mega_stem_conv_bn_relu_bf16(const float* in, const void* w_n160_bf16, const float* scale,
+extern "C" int mega_stem_conv_bn_relu_bf16(const float* in, const void* w_n176_bf16, const float* scale,
                                            const float* bias, void* out, int N, int H, int W, void* stream) {
   mega_clear_error();
-  if (!in || !w_n160_bf16 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
+  if (!in || !w_n176_bf16 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   dim3 grid(cdiv(Wo, SM_TX), cdiv(Ho, SM_TY), N);
-  hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)w_n160_bf16, scale,
+  hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)w_n176_bf16, scale,
                      bias, (bf16_t*)out, N, H, W, Ho, Wo);
   return mega_check_launch();
 }

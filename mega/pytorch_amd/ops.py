@@ -146,7 +146,7 @@ def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=Non
 
 def stem(x_nchw, w_tap64, scale, bias, out_dtype, w_n160=None):
     """x [N,3,H,W] f32 -> conv7x7 s2 + BN + ReLU -> NHWC [N,Ho,Wo,64].  f32: direct conv with w_tap64 [147,64] f32;
-    bf16: matrix-core kernel with w_n160 = bf16 [64,160] (see pack_stem_weight_bf16)."""
+    bf16: matrix-core kernel with w_n160 = bf16 [64,176] (see pack_stem_weight_bf16)."""
     _gpu(x_nchw, w_tap64, scale, bias)
     lib = _lib.load()
     N, C, H, W = x_nchw.shape
@@ -156,7 +156,7 @@ def stem(x_nchw, w_tap64, scale, bias, out_dtype, w_n160=None):
     _tok = _pb("stem", 2.0 * N * Ho * Wo * 64 * 147, x_nchw.numel() * 4 + out.numel() * out.element_size())
     if out_dtype == torch.bfloat16 and w_n160 is not None:
         _gpu(w_n160)
-        assert w_n160.dtype == torch.bfloat16 and tuple(w_n160.shape) == (64, 160) and w_n160.is_contiguous()
+        assert w_n160.dtype == torch.bfloat16 and tuple(w_n160.shape) == (64, 176) and w_n160.is_contiguous()
         rc = lib.mega_stem_conv_bn_relu_bf16(_ptr(x_nchw), _ptr(w_n160), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
                                              _stream())
     else:
@@ -168,9 +168,11 @@ def stem(x_nchw, w_tap64, scale, bias, out_dtype, w_n160=None):
 
 
 def pack_stem_weight_bf16(w_oihw):
-    """conv1.weight [64,3,7,7] -> bf16 [64,160]: column k = (c*7+r)*7+s, 13 zero pad columns."""
-    w = torch.zeros((64, 160), dtype=torch.float32, device=w_oihw.device)
-    w[:, :147] = w_oihw.detach().float().reshape(64, 147)
+    """conv1.weight [64,3,7,7] -> bf16 [64,176]: column k = ((c*7+r)*8 + s for the 7 taps s of kernel row (c, r); the
+    8th column of every group and columns 168..175 are zero (the kernel reads 8 consecutive patch pixels per group)."""
+    w = torch.zeros((64, 22, 8), dtype=torch.float32, device=w_oihw.device)
+    w[:, :21, :7] = w_oihw.detach().float().reshape(64, 21, 7)
+    w = w.reshape(64, 176)
     return w.to(torch.bfloat16).contiguous()
 
 
