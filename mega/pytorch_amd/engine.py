@@ -251,7 +251,9 @@ class ClipEngine(object):
             g = torch.cuda.CUDAGraph()
             if self._graph_pool is None:          # all frame-stage graphs replay one after the other on one stream:
                 self._graph_pool = torch.cuda.graph_pool_handle()    # they can share one activation pool
-            with torch.cuda.graph(g, pool=self._graph_pool):
+            # thread-local capture mode: the RCCL watchdog thread of a multi-GPU run polls its events with
+            # hipEventQuery, which the default (global) mode forbids on ANY thread while a capture is open
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
                 ent["st"] = m.frame_stage_async(ent["static_in"], want)
             ent["graph"] = g
             self.graph_stats["captured"] += 1
@@ -716,7 +718,7 @@ class StaticAggregation(object):
         if self.graph == "armed":                   # second: capture (records the launches, executes nothing) ...
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # (see ClipEngine._frame_stage)
                 self._out = self._body(im_size)
             self.graph = g
         self.graph.replay()                         # ... and every step from then on is one replay

@@ -26,3 +26,7 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ${EXTRA_
 done
 # keep only what the reducers need (the kernel-trace CSVs are large)
 rm -f $out/pmc_*/pmc_kernel_trace.csv $out/prof/bench_kernel_trace.csv
+# the RCCL collectives of the sharded aggregation on ONE GPU (world 1, every key frame owned by rank 0)
+MEGA_FORCE_SHARDED=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $out/bench_n1_forced_sharded.json 2> $out/bench_n1_forced_sharded.err
+timeout 300 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-roofline > $out/bench_n1_100step_blocks.json 2> $out/bench_n1_100step_blocks.err
+grep -h "timed region:" $out/*.err
