@@ -445,8 +445,13 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                         int N, int H, int W, int Ho, int Wo) {
-  __shared__ __attribute__((aligned(16))) unsigned short patch[3 * SM_PH * SM_PS];
-  __shared__ __attribute__((aligned(16))) unsigned short wl[64 * SM_WS];
+  // one buffer: [patch | weights] while the MFMAs run, then the block's 8 x 32 x 64 output tile (144-B pixel stride)
+  constexpr int SM_PATCH_B = (3 * SM_PH * SM_PS * 2 + 15) / 16 * 16, SM_OUT_PS = 144;
+  constexpr int SM_LDS_B = SM_TY * SM_TX * SM_OUT_PS > SM_PATCH_B + 64 * SM_WS * 2 ? SM_TY * SM_TX * SM_OUT_PS
+                                                                                   : SM_PATCH_B + 64 * SM_WS * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM_LDS_B];
+  unsigned short* patch = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* wl = reinterpret_cast<unsigned short*>(smem + SM_PATCH_B);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.z;
   const int oy0 = blockIdx.y * SM_TY, ox0 = blockIdx.x * SM_TX;
@@ -454,18 +459,20 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
   // all of a thread's patch elements (17) and weight vectors (5) are REQUESTED before the first one is used: written
   // as load-then-store per element the loop serialised 17 global-memory round trips per block (0.49 ms per 20 frames,
   // 5 % of it MFMA time)
-  constexpr int NPL = (3 * SM_PH * SM_PW + 255) / 256, NWL = (64 * (SM_K / 8) + 255) / 256;
+  // (the patch is filled over its whole 72-element row stride: the zero-weight 8th tap of a kernel row reads one
+  //  column past the 69 real ones, and 0 x whatever-LDS-held is NaN when that happens to be a NaN pattern)
+  constexpr int NPL = (3 * SM_PH * SM_PS + 255) / 256, NWL = (64 * (SM_K / 8) + 255) / 256;
   float pv[NPL];
   uint4 wv[NWL];
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int e = tid + 256 * i;
-    const int c = e / (SM_PH * SM_PW);
-    const int rem = e - c * (SM_PH * SM_PW);
-    const int y = rem / SM_PW, x = rem - y * SM_PW;
+    const int c = e / (SM_PH * SM_PS);
+    const int rem = e - c * (SM_PH * SM_PS);
+    const int y = rem / SM_PS, x = rem - y * SM_PS;
     const int iy = iy0 + y, ix = ix0 + x;
     pv[i] = 0.f;
-    if (e < 3 * SM_PH * SM_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+    if (e < 3 * SM_PH * SM_PS && x < SM_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
       pv[i] = in[((size_t)(n * 3 + c) * H + iy) * W + ix];
   }
 #pragma unroll
@@ -477,10 +484,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int e = tid + 256 * i;
-    const int c = e / (SM_PH * SM_PW);
-    const int rem = e - c * (SM_PH * SM_PW);
-    const int y = rem / SM_PW, x = rem - y * SM_PW;
-    if (e < 3 * SM_PH * SM_PW) patch[(c * SM_PH + y) * SM_PS + x] = f32_to_bf16(pv[i]);
+    if (e < 3 * SM_PH * SM_PS) patch[e] = f32_to_bf16(pv[i]);
   }
 #pragma unroll
   for (int i = 0; i < NWL; ++i) {
@@ -517,21 +521,33 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]),
                                                             __builtin_bit_cast(bf16x8_t, b[j]), acc[i][j], 0, 0, 0);
   }
-  // lane owns channel (lane & 31) + 32 j and the pixels (r&3) + 8 (r>>2) + 4 half of output row 2*wave + i
+  // lane owns channel (lane & 31) + 32 j and the pixels (r&3) + 8 (r>>2) + 4 half of output row 2*wave + i: written
+  // straight to memory that is 2 bytes per lane, 64 contiguous bytes per half-wave (PMC: 2x write amplification).
+  // The tile goes through LDS instead and leaves as whole 128-byte pixels, 4 KB contiguous per tile row.
+  __syncthreads();                       // every wave is done with the patch / weights
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int ch = j * 32 + p;
     const float sc = scale[ch], bi = bias[ch];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int oy = oy0 + 2 * wave + i;
-      if (oy >= Ho) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (ox < Wo) out[(((size_t)n * Ho + oy) * Wo + ox) * 64 + ch] = f32_to_bf16(fmaxf(acc[i][j][r] * sc + bi, 0.f));
+        const int px = (r & 3) + 8 * (r >> 2) + 4 * half;
+        *reinterpret_cast<unsigned short*>(smem + ((2 * wave + i) * SM_TX + px) * SM_OUT_PS + ch * 2) =
+            f32_to_bf16(fmaxf(acc[i][j][r] * sc + bi, 0.f));
       }
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < SM_TY * SM_TX * 8 / 256; ++i) {
+    const int v = tid + 256 * i;
+    const int pl = v >> 3, cv = v & 7;
+    const int oy = oy0 + pl / SM_TX, ox = ox0 + pl % SM_TX;
+    if (oy < Ho && ox < Wo)
+      *reinterpret_cast<uint4*>(out + (((size_t)n * Ho + oy) * Wo + ox) * 64 + cv * 8) =
+          *reinterpret_cast<const uint4*>(smem + pl * SM_OUT_PS + cv * 16);
   }
 }
 

@@ -408,6 +408,9 @@ def test_stem_mfma_bf16(dev):
     assert w160.shape == (64, 176) and not w160.view(64, 22, 8)[:, :, 7].any() and not w160[:, 168:].any()
     for (N, H, W) in [(2, 75, 101), (1, 600, 1000), (3, 33, 70)]:
         x = torch.randn((N, 3, H, W), generator=g) * 60
+        # leave NaN patterns behind in the CUs' LDS (block-wide sorts stage their keys there): the kernel's zero-weight
+        # taps read patch padding, which must have been written (0 x NaN is NaN)
+        torch.full((1 << 22,), float("nan"), device=dev).sort()
         got = ops.stem(x.to(dev), w_tap.to(dev), scale.to(dev), bias.to(dev), torch.bfloat16, w_n160=w160.to(dev))
         got = got.float().cpu().permute(0, 3, 1, 2)
         conv = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), stride=2, padding=3)
