@@ -61,7 +61,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--arch", default="R-101")
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
-    ap.add_argument("--steps-per-batch", type=int, default=10)
+    ap.add_argument("--steps-per-batch", type=int, default=0,
+                    help="key frames per engine step-batch; default 10 on one GPU, and on N GPUs the largest divisor of "
+                         "--steps that is <= 10 N (the per-rank frame-stage batch stays near 20 frames: a 2-5 frame "
+                         "launch leaves most of a rank's CUs idle)")
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,6 +171,9 @@ def main():
     cfg, model, sd = build_model(args.arch, args.dtype, device)
     log("model ready")
     K = args.steps
+    if args.steps_per_batch <= 0:
+        cap = 10 * max(world, 1)
+        args.steps_per_batch = 10 if world == 1 else max(d for d in range(1, K + 1) if K % d == 0 and d <= cap)
     spb = args.steps_per_batch
     afi = cfg.MODEL.VID.MEGA.ALL_FRAME_INTERVAL
     # pre-roll (untimed): cold start + enough key frames to fill the 25-entry memory deques (frames >= 37)

@@ -30,3 +30,8 @@ rm -f $out/pmc_*/pmc_kernel_trace.csv $out/prof/bench_kernel_trace.csv
 MEGA_FORCE_SHARDED=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $out/bench_n1_forced_sharded.json 2> $out/bench_n1_forced_sharded.err
 timeout 300 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-roofline > $out/bench_n1_100step_blocks.json 2> $out/bench_n1_100step_blocks.err
 grep -h "timed region:" $out/*.err
+# kernel timeline of the steady state (per-kernel busy time of one step-batch: tools/trace_summary.py)
+bash tools/gpu/trace.sh $tag/trace > /dev/null 2>&1; python tools/trace_summary.py $out/trace/tail.csv > $out/trace_summary.txt 2>&1; head -3 $out/trace_summary.txt
+# the other BASELINE configurations
+for c in 1 2 5; do timeout 300 python tools/bench_configs.py --config $c > $out/config$c.json 2> $out/config$c.err; cut -c1-160 $out/config$c.json; done
+timeout 300 python tools/bench_configs.py --config 1 --dtype float32 > $out/config1_f32.json 2> $out/config1_f32.err; cut -c1-160 $out/config1_f32.json
