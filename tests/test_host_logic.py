@@ -355,6 +355,90 @@ def test_batched_aggregation_equals_per_frame_steps(monkeypatch):
         assert (outs[0][1][i] - outs[1][1][i]).abs().max() < 1e-4
 
 
+def test_cat_rows_is_free_for_consecutive_row_blocks():
+    """relation.cat_rows: consecutive row blocks of one buffer come back as a view (no copy); anything else as torch.cat"""
+    from mega.pytorch_amd.relation import cat_rows
+    base = torch.arange(40 * 6, dtype=torch.float32).view(40, 6)
+    parts = [base[3:10], base[10:11], base[11:25]]
+    v = cat_rows(parts)
+    assert v.data_ptr() == parts[0].data_ptr() and torch.equal(v, base[3:25])
+    parts = [base[3:10], base[12:25]]                        # a gap
+    v = cat_rows(parts)
+    assert v.data_ptr() != parts[0].data_ptr() and torch.equal(v, torch.cat(parts))
+    parts = [base[3:10], base[10:25, :4]]                    # different widths are the caller's error ...
+    with pytest.raises(RuntimeError):
+        cat_rows(parts)
+    parts = [base[3:10], base[10:10], base[10:25]]           # ... empty blocks are skipped
+    assert cat_rows(parts).data_ptr() == parts[0].data_ptr()
+    other = base.clone()
+    assert torch.equal(cat_rows([base[0:5], other[5:9]]), torch.cat([base[0:5], other[5:9]]))
+    assert cat_rows([base[2:4]]) is not None and cat_rows([base[2:4]]).shape == (2, 6)
+
+
+def test_tapes_equal_per_frame_bookkeeping(monkeypatch):
+    """prepare_batch / _push_memory_batch (one tape + views per step-batch) leave the model in the state, and hand out the
+    tensors, of the per-key-frame forms they replace (prepare_step / _push_memory), including ragged records (frames with
+    fewer proposals than base_num), a window that is still filling and pools that wrap."""
+    cpu_ops.install(monkeypatch)
+    cfg = _small_cfg()
+    cfg.merge_from_list(["MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 7, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 3,
+                         "MODEL.VID.MEGA.MIN_OFFSET", -3, "MODEL.VID.MEGA.MAX_OFFSET", 3, "MODEL.VID.MEGA.GLOBAL.SIZE", 3])
+    g = torch.Generator().manual_seed(11)
+
+    def record(n):
+        return {"boxes": torch.rand((n, 4), generator=g) * 90, "scores": torch.rand((n,), generator=g),
+                "feats": torch.randn((n, 1024), generator=g)}
+    models = []
+    for _ in range(2):
+        m = modeling.build_detection_model(cfg)
+        m._reset(100)
+        models.append(m)
+    bn, an = models[0].base_num, models[0].advanced_num
+    sizes = [models[0].key_num] * 30
+    sizes[5], sizes[9], sizes[17] = bn - 3, an - 2, bn + 1               # ragged records
+    recs = [record(n) for n in sizes]
+    globs = [[record(bn + 2)] if i % 3 else [record(bn), record(bn - 1)] for i in range(30)]
+    for m in models:                                                      # cold start: the window holds 4 records
+        for r in recs[:4]:
+            m.records.append(r)
+    a, b = models
+    pos = 4
+    for S in (1, 3, 4, 2, 5):
+        steps = [(recs[pos + j], globs[pos + j]) for j in range(S)]
+        pos += S
+        want = [a.prepare_step(l, gl) for l, gl in steps]
+        got = b.prepare_batch(steps)
+        assert len(got) == S
+        for w, q in zip(want, got):
+            assert w["dis_key"] == q["dis_key"]
+            for k in ("x", "rois_key", "scores", "rois", "rois_dis", "x_ref", "dis_index", "glob"):
+                assert torch.equal(w[k], q[k]), k
+        assert len(a.records) == len(b.records) and all(x is y for x, y in zip(a.records, b.records))
+        fa, fb = a.roi_heads.box.feature_extractor, b.roi_heads.box.feature_extractor
+        assert torch.equal(fa.global_cache[0]["feats"], fb.global_cache[0]["feats"])
+        assert len(fa.global_queue_list[0]["feats"]) == len(fb.global_queue_list[0]["feats"])
+        # memory pushes of the same S frames (entry sizes vary), stage 0 and 1
+        for i in (0, 1):
+            n_push = bn if i == 0 else an
+            rois = [torch.rand((min(n_push, 4 + 3 * j), 4), generator=g) for j in range(S)]
+            ks = [torch.randn((r.shape[0], 1024), generator=g) for r in rois]
+            vts = [torch.randn((1024, r.shape[0]), generator=g) for r in rois]
+            snaps_a = {}
+            for t in range(S):
+                if fa.mem[i]:
+                    snaps_a[t] = dict(fa.mem[i])
+                fa._push_memory(i, rois[t], ks[t], vts[t])
+            snaps_b = fb._push_memory_batch(i, rois, ks, vts)
+            assert sorted(snaps_a) == sorted(snaps_b)
+            for t in snaps_a:
+                for k in ("rois", "k", "vt"):
+                    assert torch.equal(snaps_a[t][k], snaps_b[t][k]), (i, t, k)
+            for k in ("rois", "k", "vt"):
+                assert torch.equal(fa.mem[i][k], fb.mem[i][k])
+                qa, qb = fa.mem_queue_list[i][k], fb.mem_queue_list[i][k]
+                assert len(qa) == len(qb) and all(torch.equal(x, y) for x, y in zip(qa, qb))
+
+
 def test_fgfa_window_override_matches_oracle(monkeypatch):
     """BASELINE config 5 changes the FGFA window through config overrides (21 frames there; 5 here to stay cheap):
     ALL_FRAME_INTERVAL / KEY_FRAME_LOCATION / offsets are honoured by GeneralizedRCNNFGFA exactly as by the oracle."""
