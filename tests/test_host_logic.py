@@ -355,6 +355,37 @@ def test_batched_aggregation_equals_per_frame_steps(monkeypatch):
         assert (outs[0][1][i] - outs[1][1][i]).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("nms_thresh", [0.2, 0.35])
+def test_batched_aggregation_with_ragged_proposal_counts(monkeypatch, nms_thresh):
+    """The same equality when frames have FEWER proposals than the nominal row counts and different ones from frame to
+    frame (RPN NMS threshold 0.2: 5-6 proposals per frame, below base_num = 10; 0.35: 12-16, below key_num = 40): ragged
+    window / memory tapes, the per-image post-processing fallback of step_batch, one gather index per count signature."""
+    from mega.pytorch_amd import engine
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    cfg = _small_cfg()
+    cfg.merge_from_list(["MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 7, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 3,
+                         "MODEL.VID.MEGA.MIN_OFFSET", -3, "MODEL.VID.MEGA.MAX_OFFSET", 3, "MODEL.VID.MEGA.GLOBAL.SIZE", 3,
+                         "MODEL.RPN.POST_NMS_TOP_N_TEST", 40, "MODEL.VID.RPN.REF_POST_NMS_TOP_N", 10,
+                         "MODEL.RPN.NMS_THRESH", nms_thresh])
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    T, nkey = 16, 11
+    frames = synth.preprocess_cpu(synth.make_clip(T, 96, 128, seed=2))
+    outs, counts = [], []
+    for batched in (False, True):
+        model = modeling.build_detection_model(cfg)
+        model.load_state_dict(sd)
+        eng = engine.ClipEngine(model, steps_per_batch=4, overlap=False, graphs=False, batch_aggregation=batched,
+                                keep_logits=True)
+        outs.append((eng.run(frames, T, last=nkey), eng.logits_log))
+        counts.append([b.shape[0] for b in eng.key_boxes_log])          # proposals of every key frame of the run
+    assert counts[0] == counts[1] and len(set(counts[0])) > 1 and max(counts[0]) < 40, counts
+    for i, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels")), i
+        assert (a.bbox - b.bbox).abs().max() < 1e-3 and (a.get_field("scores") - b.get_field("scores")).abs().max() < 1e-5
+        assert outs[0][1][i].shape == outs[1][1][i].shape and (outs[0][1][i] - outs[1][1][i]).abs().max() < 1e-4
+
+
 def test_cat_rows_is_free_for_consecutive_row_blocks():
     """relation.cat_rows: consecutive row blocks of one buffer come back as a view (no copy); anything else as torch.cat"""
     from mega.pytorch_amd.relation import cat_rows
