@@ -464,7 +464,8 @@ int launch8(const ConvParams& p, hipStream_t st) {
 }  // namespace
 
 int mega_igemm8_supports(const ConvParams& p) {
-  return p.Cin % 64 == 0 && p.in_bytes < 0x7FF00000u && p.w_bytes < 0x7FF00000u && (p.K >> 6) >= 2;
+  static const int min_kt = getenv("MEGA_IGEMM8_MIN_KTILES") ? atoi(getenv("MEGA_IGEMM8_MIN_KTILES")) : 1;
+  return p.Cin % 64 == 0 && p.in_bytes < 0x7FF00000u && p.w_bytes < 0x7FF00000u && (p.K >> 6) >= min_kt;
 }
 
 int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st) {

@@ -29,6 +29,11 @@ CASES = [
     (375, 1, 1, 100352, 1024, 1, 1, 0, 1, 1, False, False),   # fc0: split-K
     (5, 9, 13, 192, 512, 4, 1, 3, 1, 2, False, False),        # 4x4 conv pad 3 (zero-stuffed deconv style)
 ]
+CASES += [                                                     # K = 64: ONE K-tile (the ring's second tile is all zeros)
+    (3, 150, 250, 64, 256, 1, 1, 0, 1, 1, True, False),       # layer1 conv3 + residual
+    (3, 150, 250, 64, 256, 1, 1, 0, 1, 0, False, False),      # layer1 downsample
+    (1, 13, 15, 64, 320, 1, 1, 0, 1, 1, False, True),         # N tail, f32 out, M < one tile
+]
 
 
 def run(case, force, reps=1):
