@@ -464,8 +464,9 @@ int launch8(const ConvParams& p, hipStream_t st) {
 }  // namespace
 
 int mega_igemm8_supports(const ConvParams& p) {
-  static const int min_kt = getenv("MEGA_IGEMM8_MIN_KTILES") ? atoi(getenv("MEGA_IGEMM8_MIN_KTILES")) : 1;
-  return p.Cin % 64 == 0 && p.in_bytes < 0x7FF00000u && p.w_bytes < 0x7FF00000u && (p.K >> 6) >= min_kt;
+  // capability (a single K-tile works: the ring's second tile is then all zeros); which shapes are SENT here by default
+  // is choose_tile's policy (igemm.hip)
+  return p.Cin % 64 == 0 && p.in_bytes < 0x7FF00000u && p.w_bytes < 0x7FF00000u && (p.K >> 6) >= 1;
 }
 
 int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st) {
