@@ -84,6 +84,15 @@ def parse():
     return ap.parse_args()
 
 
+def default_steps_per_batch(steps, world):
+    """Key frames per engine step-batch when --steps-per-batch is not given: 10 on one GPU (a 20-frame frame stage fills
+    the 256 CUs once per layer-3 launch); on N GPUs the largest divisor of --steps that is <= 10 N, so that the
+    per-rank slice of the frame stage stays near 20 frames (a 2-5 frame launch leaves most of a rank's CUs idle)."""
+    if world <= 1:
+        return 10
+    return max(d for d in range(1, steps + 1) if steps % d == 0 and d <= 10 * world)
+
+
 def build_model(arch, dtype, device):
     from mega.pytorch_amd import config, modeling, synth
     cfg = config.get_cfg(arch)
@@ -172,8 +181,7 @@ def main():
     log("model ready")
     K = args.steps
     if args.steps_per_batch <= 0:
-        cap = 10 * max(world, 1)
-        args.steps_per_batch = 10 if world == 1 else max(d for d in range(1, K + 1) if K % d == 0 and d <= cap)
+        args.steps_per_batch = default_steps_per_batch(K, world)
     spb = args.steps_per_batch
     afi = cfg.MODEL.VID.MEGA.ALL_FRAME_INTERVAL
     # pre-roll (untimed): cold start + enough key frames to fill the 25-entry memory deques (frames >= 37)

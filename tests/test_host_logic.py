@@ -386,6 +386,18 @@ def test_batched_aggregation_with_ragged_proposal_counts(monkeypatch, nms_thresh
         assert outs[0][1][i].shape == outs[1][1][i].shape and (outs[0][1][i] - outs[1][1][i]).abs().max() < 1e-4
 
 
+def test_bench_default_steps_per_batch():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = bench.default_steps_per_batch
+    assert [f(20, w) for w in (1, 2, 4, 8)] == [10, 20, 20, 20]
+    assert [f(48, w) for w in (1, 2, 4, 8)] == [10, 16, 24, 48]
+    assert f(7, 2) == 7 and f(100, 2) == 20 and f(100, 8) == 50
+
+
 def test_cat_rows_is_free_for_consecutive_row_blocks():
     """relation.cat_rows: consecutive row blocks of one buffer come back as a view (no copy); anything else as torch.cat"""
     from mega.pytorch_amd.relation import cat_rows
