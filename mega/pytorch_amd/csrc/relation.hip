@@ -339,6 +339,7 @@ struct AttnParams {
   int Nq, Nk, G;
   float scale;
   int nsplit, tiles_per_split;
+  int vmask_always;           // experiments: mask the V^T tail in every tile (the pre-round-3 form) instead of the last one
   float* part_o;              // [nsplit][Nq][G*64] un-normalised partial outputs (nsplit > 1)
   float* part_ml;             // [nsplit][2][G][Nq]   running max / sum of each partial
 };
@@ -392,9 +393,11 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
         const unsigned off = ((unsigned)(head * 64 + row) * (unsigned)p.ldv + (unsigned)key) * (unsigned)sizeof(T);
         const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs_v, key < p.Nk ? off : 0xFFFFFFFFu, 0, 0);
         uint4 v = make_uint4(r.x, r.y, r.z, r.w);
-        T* e = reinterpret_cast<T*>(&v);   // zero the tail keys (pad columns of Vt are not guaranteed finite)
+        if (p.vmask_always || k0 + 32 > p.Nk) {   // only a tile that reaches past Nk has tail keys (wave-uniform branch):
+          T* e = reinterpret_cast<T*>(&v);         // zero them (pad columns of Vt are not guaranteed finite)
 #pragma unroll
-        for (int t = 0; t < VE; ++t) e[t] = (key + t < p.Nk) ? e[t] : (T)0;
+          for (int t = 0; t < VE; ++t) e[t] = (key + t < p.Nk) ? e[t] : (T)0;
+        }
         vreg[i] = v;
       }
     }
@@ -748,6 +751,7 @@ static int attn_fill(AttnParams& p, const void* q, int ldq, const void* k, int l
   if (nsplit > 1 && (!ws || ws_bytes < mega_relation_attention_workspace_bytes(Nq, Nk, groups))) nsplit = 1;
   const int ntiles = cdiv(Nk, 32);
   p.tiles_per_split = cdiv(ntiles, nsplit);
+  { const char* e = getenv("MEGA_ATTN_VMASK_ALWAYS"); p.vmask_always = (e && e[0] == '1') ? 1 : 0; }
   nsplit = cdiv(ntiles, p.tiles_per_split);   // no empty splits
   p.nsplit = nsplit;
   p.part_o = (float*)ws;
