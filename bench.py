@@ -2,7 +2,13 @@
 """MEGA R-101 per-key-frame inference benchmark on MI355X (BASELINE.json metric: frames/sec, synthetic
 1000x600 VID clip, MEGA R-101 25 local / 10 global / 25-frame memory, bf16).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N`: WORLD_SIZE is set and must equal --gpus) or, when WORLD_SIZE is not set, bench.py launches them
+itself by re-executing under torch.distributed.run on 127.0.0.1 (the reference starts one process per GPU the same way:
+tools/test_net.py:69-75).  A box with fewer than N devices, or a WORLD_SIZE that differs from --gpus, is an error
+(exit code 2): the line never reports an N that did not run.
 
 A "step" is one steady-state key frame: one new local frame + one new global-pool frame through
 backbone/RPN/res5/ROIAlign/fc0 (preprocessing included, uint8 frames resident in HBM), then the relation
@@ -16,8 +22,10 @@ steady frame-stage / aggregation hipGraphs have been captured AND replayed; --wa
 region is then R blocks of EXACTLY --steps key frames, each block bracketed by barrier + synchronize on both sides
 (R chosen so that the blocks cover >= ~1 s); `value` / `ms_per_step` are the MEDIAN block (all block times are in
 `config.timed_blocks_ms`).  The engine's graph statistics must not change inside the timed region (asserted).
-N>1: the frame stage of each batch of steps is sharded over the ranks and the fixed-size frame records are
-exchanged with one RCCL all-gather ("strong" scaling: the clip is the same for every N).
+N>1: a step is N key frames of the video (one per rank: "weak" scaling, per-GPU work fixed); the frame stage of each
+step-batch (10 N key frames = 20 N frames, 20 per rank) is sharded over the ranks and the fixed-size frame records are
+exchanged with one RCCL all-gather per row-count group; the key frames' aggregation is dealt to the ranks, the memory
+entries all-gathered once per stage (engine.KeyFrameShard).  `value` = all key frames of a block / its time.
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract fields it carries
   roofline     -- the dominant kernel family (implicit-GEMM conv/linear on MFMA): algorithmic FLOPs of its launches
@@ -62,9 +70,9 @@ def parse():
     ap.add_argument("--arch", default="R-101")
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--steps-per-batch", type=int, default=0,
-                    help="key frames per engine step-batch; default 10 on one GPU, and on N GPUs the largest divisor of "
-                         "--steps that is <= 10 N (the per-rank frame-stage batch stays near 20 frames: a 2-5 frame "
-                         "launch leaves most of a rank's CUs idle)")
+                    help="key frames per engine step-batch; default 10 N on N GPUs (a timed block is --steps x N key "
+                         "frames, so a rank's frame-stage launch always holds 20 frames: a 2-5 frame launch leaves most of "
+                         "a rank's CUs idle)")
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,18 +87,106 @@ def parse():
     ap.add_argument("--ramp", action="store_true",
                     help="short first / last step-batch inside a timed block (ClipEngine ramp; measured slower: 555 vs 585 FPS)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="steady key frames timed by the CPU baseline (memory full)")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed blocks cover at least this long")
-    ap.add_argument("--max-blocks", type=int, default=60)
+    ap.add_argument("--min-seconds", type=float, default=5.0, help="the timed blocks cover at least this long")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / reporting only (no model, no kernels; gloo when there is no HIP device): "
+                         "proves the --gpus N self-launch and the n_gpus bookkeeping on a CPU box (tests/test_bench_cli.py)")
+    ap.add_argument("--max-blocks", type=int, default=300)
     return ap.parse_args()
 
 
+def key_frames_per_block(steps, world):
+    """A step is `world` key frames (one per rank): a timed block of --steps steps covers steps x world key frames."""
+    return steps * max(world, 1)
+
+
 def default_steps_per_batch(steps, world):
-    """Key frames per engine step-batch when --steps-per-batch is not given: 10 on one GPU (a 20-frame frame stage fills
-    the 256 CUs once per layer-3 launch); on N GPUs the largest divisor of --steps that is <= 10 N, so that the
-    per-rank slice of the frame stage stays near 20 frames (a 2-5 frame launch leaves most of a rank's CUs idle)."""
-    if world <= 1:
-        return 10
-    return max(d for d in range(1, steps + 1) if steps % d == 0 and d <= 10 * world)
+    """Key frames per engine step-batch when --steps-per-batch is not given: the largest divisor of the block's key
+    frames (steps x world) that is <= 10 x world.  One GPU: 10 (a 20-frame frame stage fills the 256 CUs once per layer-3
+    launch).  N GPUs: 10 N whenever --steps is a multiple of 10 -- every rank's slice of the frame stage is then the same
+    20 frames as on one GPU, and it never drops below 2 x (largest divisor of --steps <= 10) frames."""
+    world = max(world, 1)
+    kf = key_frames_per_block(steps, world)
+    return max(d for d in range(1, kf + 1) if kf % d == 0 and d <= 10 * world)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 and no launcher around us: start one rank per GPU under torch.distributed.run (rendezvous on
+    127.0.0.1) and hand on its exit code.  stdout is inherited, so rank 0's JSON line is this process's JSON line."""
+    import subprocess
+    if not args.dry_run:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but this box has %d HIP device(s); refusing to report a smaller N\n"
+                             % (args.gpus, have))
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    log("self-launch: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank, local_rank, json_fd):
+    """The launch / rendezvous / reporting skeleton without model or kernels: process group (nccl when every rank has a
+    device, else gloo), the barrier + MAX-over-ranks timing bracket, the sharded frame-stage plan of one steady
+    step-batch, and the JSON line with n_gpus taken from the LIVE process group."""
+    import torch.distributed as dist
+    from mega.pytorch_amd import engine as eng
+    live = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        use_nccl = torch.cuda.is_available() and torch.cuda.device_count() >= world
+        if use_nccl:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl" if use_nccl else "gloo")
+        live = dist.get_world_size()
+    assert live == args.gpus, "process group has %d ranks, --gpus %d" % (live, args.gpus)
+    K = args.steps
+    KF = key_frames_per_block(K, live)
+    spb = args.steps_per_batch if args.steps_per_batch > 0 else default_steps_per_batch(K, live)
+
+    class _M(object):        # the schedule only needs these constants (MEGA R-101 defaults)
+        all_frame_interval, key_frame_location, key_num, base_num, global_enable = 25, 12, 300, 75, True
+        cfg = type("C", (), {"INPUT": type("I", (), {"PIXEL_MEAN": (0, 0, 0), "TO_BGR255": True})})
+    e = eng.ClipEngine(_M())
+    e.rank, e.world = rank, live
+    T = 64 + 2 * KF
+    gfor = eng.global_schedule(T, 10, seed=0)
+    jobs = [j for i in range(40, 40 + spb) for j in e.jobs_for_step(i, T, gfor)]
+    mine = e.shard_plan(jobs)[1] if live > 1 else list(range(len(jobs)))
+    t0 = time.perf_counter()
+    if live > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if live > 1:
+        t = torch.tensor([dt, float(len(mine))], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        mx = t.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dt, most = float(mx[0]), int(mx[1])
+    else:
+        most = len(mine)
+    if rank == 0:
+        line = {"metric": "frames/sec MEGA %s inference, %dx%d VID clip" % (args.arch, args.width, args.height),
+                "value": None, "unit": "frames/s", "n_gpus": live, "steps": K, "warmup": args.warmup, "ms_per_step": None,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dry_run": True,
+                "config": {"key_frames_per_step": live, "key_frames_per_block": KF, "steps_per_batch": spb,
+                           "frames_per_batch": len(jobs), "frames_per_rank_per_batch": most,
+                           "backend": dist.get_backend() if live > 1 else None}}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if live > 1:
+        dist.destroy_process_group()
 
 
 def build_model(arch, dtype, device):
@@ -152,17 +248,27 @@ def cpu_baseline(arch, sd, H, W, n_timed):
 
 
 def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:        # no launcher around us: start the ranks ourselves
+        sys.exit(self_launch(args, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: launched with WORLD_SIZE=%d but --gpus %d; they must agree\n" % (world, args.gpus))
+        sys.exit(2)
     # stdout carries exactly ONE line (the JSON): everything else any library writes to fd 1 -- RCCL prints a
     # version banner there at exit -- is sent to stderr.
     json_fd = os.dup(1)
     sys.stdout.flush()
     os.dup2(2, 1)
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank, local_rank, json_fd)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (the MEGA hot path has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d has no HIP device (%d visible)\n" % (local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
@@ -174,12 +280,14 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
         group = dist.group.WORLD
+        assert dist.get_world_size() == world, "process group has %d ranks, WORLD_SIZE %d" % (dist.get_world_size(), world)
     from mega.pytorch_amd import engine as eng, ops
 
     log("building model")
     cfg, model, sd = build_model(args.arch, args.dtype, device)
     log("model ready")
     K = args.steps
+    KF = key_frames_per_block(K, world)           # key frames per timed block (a step = `world` key frames)
     if args.steps_per_batch <= 0:
         args.steps_per_batch = default_steps_per_batch(K, world)
     spb = args.steps_per_batch
@@ -189,10 +297,10 @@ def main():
     # lengthen it.  Rounded so that the timed region starts on a batch boundary.
     pre = max(args.warmup, afi + 12 + 1, 3 * spb + 1)
     pre = 1 + -(-(pre - 1) // spb) * spb
-    extra_cap = 6 * max(spb, K)                   # further pre-roll blocks if the engine is not yet in steady state
-    max_blocks = max(1, min(args.max_blocks, -(-1200 // K)))
-    prof_steps = 0 if args.no_roofline else 8
-    T = pre + K + extra_cap + K * max_blocks + prof_steps + 1 + K + 13
+    extra_cap = 6 * max(spb, KF)                  # further pre-roll blocks if the engine is not yet in steady state
+    max_blocks = max(1, min(args.max_blocks, -(-6000 // KF)))
+    prof_steps = 0 if args.no_roofline else spb       # the instrumented pass runs the steady batch shape
+    T = pre + KF + extra_cap + KF * max_blocks + 2 * prof_steps + 1 + KF + 13
     clip = make_clip(T, args.height, args.width, device)
     gfor = eng.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
     runner = eng.ClipEngine(model, steps_per_batch=spb, dist_group=group, overlap=not args.no_overlap,
@@ -220,15 +328,15 @@ def main():
     log("cold start done")
     pos = 1
     while pos < pre:                       # same call pattern as the timed blocks: the same batch shapes get captured
-        runner.run(clip, T, gfor, first=pos, last=pos + K)
+        runner.run(clip, T, gfor, first=pos, last=pos + KF)
         barrier()
-        pos += K
+        pos += KF
     prev_stats = None
     while pos < pre + extra_cap:           # until a whole block runs without an eager batch or a capture
         before = dict(runner.graph_stats)
-        runner.run(clip, T, gfor, first=pos, last=pos + K)
+        runner.run(clip, T, gfor, first=pos, last=pos + KF)
         barrier()
-        pos += K
+        pos += KF
         after = runner.graph_stats
         if runner.steady_state()["steady"] and (args.no_graphs or (after["eager"] == before["eager"] and
                                                                    after["captured"] == before["captured"])):
@@ -245,7 +353,7 @@ def main():
     def timed_block(first):
         barrier()
         t0 = time.perf_counter()
-        d = runner.run(clip, T, gfor, first=first, last=first + K)
+        d = runner.run(clip, T, gfor, first=first, last=first + KF)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -257,7 +365,7 @@ def main():
     blocks = []
     dt, dets = timed_block(pos)
     blocks.append(dt)
-    pos += K
+    pos += KF
     nblk = max(1, min(max_blocks, int(-(-args.min_seconds // dt))))
     if world > 1:      # every rank must run the same number of blocks
         t = torch.tensor([nblk], dtype=torch.int64, device=device)
@@ -266,14 +374,14 @@ def main():
     for _ in range(nblk - 1):
         dt, dets = timed_block(pos)
         blocks.append(dt)
-        pos += K
+        pos += KF
     st1 = engine_state()
     runner_frames_after = runner.frames_computed
     srt = sorted(blocks)
     elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
-    fps = K / elapsed
-    log("timed region: %d blocks of %d steps, median %.4fs (%.2f frames/s), min %.4f max %.4f, total %.2fs" % (
-        len(blocks), K, elapsed, fps, srt[0], srt[-1], sum(blocks)))
+    fps = KF / elapsed
+    log("timed region: %d blocks of %d steps (%d key frames), median %.4fs (%.2f frames/s), min %.4f max %.4f, total %.2fs" % (
+        len(blocks), K, KF, elapsed, fps, srt[0], srt[-1], sum(blocks)))
     captures_in_region = (st1["graph_stats"]["captured"] - st0["graph_stats"]["captured"]
                           + st1["graph_stats"]["eager"] - st0["graph_stats"]["eager"])
     log("engine state after the timed region: %s" % (st1,))
@@ -284,19 +392,28 @@ def main():
     log("host ms/step: frame-stage enqueue %.3f, aggregation enqueue %.3f (of which waiting for the frame stage %.3f), "
         "waiting for results %.3f" % tuple(1e3 * ht[k] / max(ht["steps"], 1)
                                             for k in ("frame_enqueue", "aggregate_enqueue", "frame_wait", "finish_wait")))
-    Wm = pos - K * len(blocks)       # key frames processed before the first timed block
+    Wm = pos - KF * len(blocks)       # key frames processed before the first timed block
 
     roofline = None
+    roofline_hbm = []
     fam = {}
     if prof_steps:
-        p = ops.Profiler()
-        ops.set_profiler(p)
+        # Instrumented pass: kernel by kernel (no hipGraph replays, one stream), every launch between a HIP event pair on
+        # the launch stream.  One UNTIMED eager batch of the same shape goes first: the first eager launches after the
+        # graphs are switched off pay one-time costs (allocator growth, kernel attribute calls) that belong to no kernel.
         runner.use_graphs = False
-        runner.use_static = False  # the instrumented pass launches kernel by kernel: no hipGraph replays
+        runner.use_static = False
         runner.overlap = False     # per-kernel event pairs are only meaningful without cross-stream concurrency
         runner.run(clip, T, gfor, first=pos, last=pos + prof_steps)
+        barrier()
+        pos += prof_steps
+        p = ops.Profiler()
+        ops.set_profiler(p)
+        runner.run(clip, T, gfor, first=pos, last=pos + prof_steps)
         summ = p.summary()
+        detail = p.summary(by_detail=True)
         ops.set_profiler(None)
+        pos += prof_steps
         tot_ms = sum(v["ms"] for v in summ.values())
         for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
             fam[k] = {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": round(v["launches"] / prof_steps, 1),
@@ -313,15 +430,17 @@ def main():
         ach = d["flops"] / (d["ms"] * 1e9)
         fam_ms = sum(v["ms"] for v in igemms.values())
         fam_fl = sum(v["flops"] for v in igemms.values())
-        # HBM traffic per launch of the dominant variant, from the committed rocprofv3 PMC passes of this same
-        # command (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read correction; tools/pmc_summary.py)
+        # HBM traffic per launch of the dominant variant: the rocprofv3 PMC passes of this same command (FETCH_SIZE and
+        # WRITE_SIZE in separate passes, gfx950 x2 read correction; tools/pmc_summary.py) cannot run inside bench.py, so
+        # the number is read from the newest committed summary and labelled with its source -- it is a property of that
+        # profiled run of this code, not of this run.
         traffic, traffic_src = None, None
         if is8:       # igemm8_kernel<OT, MF1>: MF1 = 2 (256-row tile) or 1 (192-row tile)
             sym = "igemm8_kernel<bf16, %d>" % (2 if tile[0] == "256" else 1)
         else:
             sym = "igemm_kernel<%s, %s, %s, %s>" % (tag if tag == "bf16" else "float", tag if tag == "bf16" else "float",
                                                     tile[0], tile[1])
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
             if os.path.exists(pmc):
                 ks = json.load(open(pmc))["kernels"]
@@ -334,12 +453,47 @@ def main():
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                     "flops_per_launch": round(d["flops"] / d["launches"], 0),
+                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 0),
                     "share_of_gpu_time": round(d["ms"] / tot_ms, 3),
                     "all_igemm_variants": {"achieved": round(fam_fl / (fam_ms * 1e9), 2),
                                            "frac": round(fam_fl / (fam_ms * 1e9) / peak, 4),
                                            "share_of_gpu_time": round(fam_ms / tot_ms, 3)},
                     "whole_path_frac": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / (peak * 1e12), 5)
                     if args.arch == "R-101" else None}
+
+        # the HBM-bound sub-steps SURVEY 8d asks for separately: algorithmic bytes / event time against 8 TB/s
+        def hbm_entry(name, sel):
+            rows = [v for k, v in detail.items() if sel(k[0], k[1] or "")]
+            ms = sum(v["ms"] for v in rows)
+            n = sum(v["launches"] for v in rows)
+            if not n or ms <= 0:
+                return
+            by = sum(v["bytes"] for v in rows)
+            roofline_hbm.append({"kernel": name, "bound": "hbm", "achieved": round(by / (ms * 1e6), 1), "peak": 8000.0,
+                                 "unit": "GB/s", "frac": round(by / (ms * 1e6) / 8000.0, 4), "launches": n,
+                                 "algorithmic_bytes_per_launch": round(by / n), "avg_launch_us": round(1e3 * ms / n, 2),
+                                 "ms_per_key_frame": round(ms / prof_steps, 4)})
+
+        def shape_of(det):       # "MxCoutxK (RxS)" -> (M, Cout, K, R)
+            try:
+                a, b2 = det.split(" ")
+                M_, C_, K_ = (int(x) for x in a.split("x"))
+                return M_, C_, K_, int(b2[1])
+            except Exception:    # noqa: BLE001
+                return None
+        conv = lambda f: f.startswith("igemm")      # noqa: E731
+        hbm_entry("stem 7x7/2 conv + BN + ReLU", lambda f, d_: f == "stem")
+        hbm_entry("max-pool 3x3/2", lambda f, d_: f == "maxpool")
+        hbm_entry("layer1 convs (Cin or Cout = 64)", lambda f, d_: conv(f) and shape_of(d_) is not None
+                  and (shape_of(d_)[2] in (64, 576) or shape_of(d_)[1] == 64))
+        hbm_entry("layer3 1x1 256->1024 + residual", lambda f, d_: conv(f) and shape_of(d_) is not None
+                  and shape_of(d_)[1:] == (1024, 256, 1))
+        hbm_entry("layer3 1x1 1024->256", lambda f, d_: conv(f) and shape_of(d_) is not None
+                  and shape_of(d_)[1:] == (256, 1024, 1) and shape_of(d_)[0] > 10000)
+        hbm_entry("ROIAlign (gather + [K,49,C] write)", lambda f, d_: f == "roi_align")
+        hbm_entry("fc0 (K = 100352 weight + activation stream)", lambda f, d_: conv(f) and shape_of(d_) is not None
+                  and shape_of(d_)[2] >= 50000)
+        hbm_entry("position logits (write of the [16,Nq,Nk] bf16 logits)", lambda f, d_: f == "pos_logits")
 
     # whole-clip rate (SURVEY 8d ii): a fresh video -- cold start (13 local + 10 global frames, eager aggregation
     # while the pools fill) plus the same K steady key frames -- on the warmed-up engine.  Reported beside `value`.
@@ -349,15 +503,15 @@ def main():
         runner.use_static = True
         barrier()
         t0 = time.perf_counter()
-        runner.run(clip, T, gfor, first=0, last=1 + K)
+        runner.run(clip, T, gfor, first=0, last=1 + KF)
         barrier()
         wc = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([wc], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wc = float(t.item())
-        whole_clip = {"key_frames": 1 + K, "seconds": round(wc, 4), "frames_per_s": round((1 + K) / wc, 2)}
-        log("whole clip incl. cold start: %d key frames in %.3fs (%.1f frames/s)" % (1 + K, wc, (1 + K) / wc))
+        whole_clip = {"key_frames": 1 + KF, "seconds": round(wc, 4), "frames_per_s": round((1 + KF) / wc, 2)}
+        log("whole clip incl. cold start: %d key frames in %.3fs (%.1f frames/s)" % (1 + KF, wc, (1 + KF) / wc))
     except Exception as e:  # noqa: BLE001  (an optional extra must never cost the headline line)
         log("whole-clip measurement skipped: %r" % (e,))
 
@@ -365,17 +519,22 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.arch, sd, args.height, args.width, args.cpu_frames)
 
+    live_world = dist.get_world_size() if group is not None else 1
     if rank == 0:
         ndet = sum(len(d) for d in dets) / max(len(dets), 1)
         line = {
             "metric": "frames/sec MEGA %s inference, %dx%d VID clip" % (args.arch, args.width, args.height),
-            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "strong",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": live_world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": "MEGA %s-C4, %dx%d frames, 25 local + 10 global frames + 25-frame memory, "
                                    "300 key / 75 ref proposals, 3 attention stages (BASELINE configs[2]%s)"
                                    % (args.arch, args.width, args.height, "" if world == 1 else " sharded = configs[3]"),
-                       "steps_per_batch": args.steps_per_batch, "batch_sizes_in_a_block": runner.batch_sizes(K),
+                       "step": "%d key frame%s" % (world, "" if world == 1 else "s of the video (one per rank; the frame stage of "
+                                                   "a step-batch is sharded, its records all-gathered over RCCL)"),
+                       "key_frames_per_block": KF, "ms_per_key_frame": round(1e3 * elapsed / KF, 4),
+                       "steps_per_batch": args.steps_per_batch, "batch_sizes_in_a_block": runner.batch_sizes(KF),
+                       "frames_per_rank_per_batch": -(-2 * args.steps_per_batch // world),
                        "parallelism": "frame-sharded x%d" % world,
                        "frame_record_reuse": bool(args.reuse_records),
                        "aggregation": args.aggregation,
@@ -383,13 +542,14 @@ def main():
                        "graph_captures_in_timed_region": captures_in_region,
                        "engine_state_before": st0, "engine_state_after": st1,
                        "timed_blocks": len(blocks), "timed_blocks_ms": [round(1e3 * b, 2) for b in blocks],
-                       "value_is": "median block (each block = exactly --steps key frames between barrier+synchronize)",
-                       "clip": "16 unique synthetic frames repeated (timing does not depend on frame content)",
-                       "frames_through_frame_stage_per_step": round((runner_frames_after - fc_before) / (K * len(blocks)), 2),
+                       "value_is": "median block (each block = exactly --steps steps between barrier+synchronize)",
+                       "clip": "16 unique synthetic frames repeated (only the RPN NMS's early stop depends on frame content)",
+                       "frames_through_frame_stage_per_key_frame": round(
+                           (runner_frames_after - fc_before) / (KF * len(blocks)), 2),
                        "avg_detections": round(ndet, 1),
                        "key_proposals_last_frame": int(model.records[model.key_frame_location]["boxes"].shape[0]),
                        "whole_clip_incl_cold_start": whole_clip},
-            "roofline": roofline, "cpu_baseline": cpu, "kernel_families": fam,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu, "kernel_families": fam,
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1 or os.environ.get("MEGA_FORCE_SHARDED") == "1":

@@ -82,7 +82,10 @@ class KeyFrameShard(object):
     def gather_detections(self, outs, S, max_det, device):
         """outs[t] = PostProcessor.run output of my key frames (None elsewhere) -> the same for all S key frames.
         A frame travels as [cap2 + 1, 6] f32 rows (box, score, label; last row = count), cap2 = 2 * DETECTIONS_PER_IMG
-        (the reference's cut keeps at most DETECTIONS_PER_IMG plus score ties, box_head/inference.py:139-148)."""
+        (the reference's cut keeps at most DETECTIONS_PER_IMG plus score ties, box_head/inference.py:139-148).  A frame
+        with more than cap2 detections (> DETECTIONS_PER_IMG exact score ties at the cut) cannot travel whole: its true
+        count is sent, and ClipEngine.run raises when it reads a count larger than the rows it holds -- never a silent
+        truncation.  Note the padded shape differs from the single-GPU path's [(NC-1) * R] rows; only [:count] is used."""
         W = self.world
         per, cap2 = (S + W - 1) // W, 2 * max_det
         buf = torch.zeros((per, cap2 + 1, 6), dtype=torch.float32, device=device)
@@ -94,7 +97,7 @@ class KeyFrameShard(object):
             buf[t // W, :n, :4] = ob[:n]
             buf[t // W, :n, 4] = os_[:n]
             buf[t // W, :n, 5] = ol[:n].float()
-            buf[t // W, cap2, 0] = oc.float().clamp(max=cap2)[0]
+            buf[t // W, cap2, 0] = oc.float()[0]      # the TRUE count: finish() raises if it exceeds the rows sent
         out = torch.empty((W * per, cap2 + 1, 6), dtype=torch.float32, device=device)
         self.dist.all_gather_into_tensor(out, buf, group=self.group)
         res = []
@@ -265,6 +268,25 @@ class ClipEngine(object):
         return {"props": st["props"].clone(), "scores": st["scores"].clone(), "cnt": st["cnt"].clone(),
                 "feats": st["feats"].clone(), "want": st["want"]}
 
+    def shard_plan(self, jobs, rank=None, world=None):
+        """How a frame-stage batch is dealt to the ranks.  Jobs are grouped by their row count (local-window frames:
+        key_num rows, global-pool frames: base_num rows); each group, largest rows first, is cut into `world` contiguous
+        slices (padded by repeating its last job).  -> (plan, mine): plan = [(want, positions of the group's jobs, slice
+        length, offset of this rank's slice in its launch)], mine = positions (into jobs) this rank computes, in launch
+        order.  The ONE definition of the slicing: records_async and the host-side prefetch both use it."""
+        rank = self.rank if rank is None else rank
+        world = self.world if world is None else world
+        groups = {}
+        for pos, j in enumerate(jobs):
+            groups.setdefault(int(j[1]), []).append(pos)
+        plan, mine = [], []
+        for want, poss in sorted(groups.items(), reverse=True):
+            per = (len(poss) + world - 1) // world
+            padded = poss + [poss[-1]] * (per * world - len(poss))
+            plan.append((want, poss, per, len(mine)))
+            mine += padded[rank * per:(rank + 1) * per]
+        return plan, mine
+
     def records_async(self, clip, jobs):
         """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
         records_resolve()."""
@@ -275,17 +297,9 @@ class ClipEngine(object):
         # contiguous slices (padded by repeating its last job); a rank runs ONE frame-stage launch over its slices of
         # all groups and the records of a group travel in ONE all-gather of a packed byte buffer
         # [boxes+score f32 | feats | count], fixed size per frame.
-        groups = {}
-        for pos, j in enumerate(jobs):
-            groups.setdefault(int(j[1]), []).append(pos)
-        plan, mine_ids, mine_want = [], [], []
-        for want, poss in sorted(groups.items(), reverse=True):
-            per = (len(poss) + self.world - 1) // self.world
-            padded = poss + [poss[-1]] * (per * self.world - len(poss))
-            sl = padded[self.rank * per:(self.rank + 1) * per]
-            plan.append((want, poss, per, len(mine_ids)))
-            mine_ids += [jobs[p][0] for p in sl]
-            mine_want += [want] * per
+        plan, mine = self.shard_plan(jobs)
+        mine_ids = [jobs[p][0] for p in mine]
+        mine_want = [int(jobs[p][1]) for p in mine]
         st = self._frame_stage(self._frames(clip, mine_ids), mine_want)
         dev, D, fdt = st["props"].device, st["feats"].shape[1], st["feats"].dtype
         esz = st["feats"].element_size()
@@ -368,9 +382,8 @@ class ClipEngine(object):
         def prefetch(bi):      # host decodes of a later batch start while this one is being enqueued
             if hasattr(clip, "prefetch") and bi < len(batches):
                 jobs = [j for i in range(*batches[bi]) for j in self.jobs_for_step(i, T, gfor)]
-                if self.world > 1:     # only this rank's slice of the frame stage (same slicing as records_async)
-                    per = (len(jobs) + self.world - 1) // self.world
-                    jobs = (jobs + [jobs[-1]] * (per * self.world - len(jobs)))[self.rank * per:(self.rank + 1) * per]
+                if self.world > 1 and jobs:     # only this rank's slices of the frame stage (records_async's own plan)
+                    jobs = [jobs[p] for p in self.shard_plan(jobs)[1]]
                 clip.prefetch([j[0] for j in jobs])
 
         if first == 0:
@@ -538,6 +551,9 @@ class ClipEngine(object):
             else:
                 counts = torch.cat([pd[3] for _, pd in pending]).tolist()
             for (i, pd), n in zip(pending, counts):
+                if int(n) > pd[0].shape[0]:
+                    raise RuntimeError("key frame %d: %d detections but only %d rows travelled (KeyFrameShard cap)"
+                                       % (i, int(n), pd[0].shape[0]))
                 det = pp.materialize(pd, int(n), (W, H))
                 out.append(det)
                 if on_step is not None:

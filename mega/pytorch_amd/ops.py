@@ -48,10 +48,10 @@ class Profiler(object):
     def __init__(self):
         self.items = []
 
-    def begin(self, family, flops=0.0, nbytes=0.0):
+    def begin(self, family, flops=0.0, nbytes=0.0, detail=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        return [family, float(flops), float(nbytes), e0]
+        return [family, float(flops), float(nbytes), e0, detail]
 
     def end(self, tok):
         e1 = torch.cuda.Event(enable_timing=True)
@@ -59,11 +59,13 @@ class Profiler(object):
         tok.append(e1)
         self.items.append(tok)
 
-    def summary(self):
+    def summary(self, by_detail=False):
+        """{family: launches, ms, flops, bytes}; by_detail=True keys on (family, detail) -- detail = the GEMM shape
+        "M x Cout x K (RxS)" of a conv / linear launch -- so that one layer can be told from another of the same tile."""
         torch.cuda.synchronize()
         out = {}
-        for fam, fl, nb, e0, e1 in self.items:
-            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for fam, fl, nb, e0, det, e1 in self.items:
+            d = out.setdefault((fam, det) if by_detail else fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
@@ -79,8 +81,8 @@ def set_profiler(p):
     _PROF = p
 
 
-def _pb(family, flops=0.0, nbytes=0.0):
-    return None if _PROF is None else _PROF.begin(family, flops, nbytes)
+def _pb(family, flops=0.0, nbytes=0.0, detail=None):
+    return None if _PROF is None else _PROF.begin(family, flops, nbytes, detail)
 
 
 def _pe(tok):
@@ -120,7 +122,9 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
     if _PROF is not None:      # family = the kernel symbol rocprofv3 would report for this launch
         _tok = _pb(_igemm_family(lib, N * Ho * Wo, Cout, R * S * Cin, x.dtype),
                    2.0 * N * Ho * Wo * Cout * R * S * Cin,
-                   x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size())
+                   x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size()
+                   + (0 if residual is None else residual.numel() * residual.element_size()),
+                   detail="%dx%dx%d (%dx%d)" % (N * Ho * Wo, Cout, R * S * Cin, R, S))
     if x.numel() * x.element_size() >= 0x7FF00000 or w.numel() * w.element_size() >= 0x7FF00000:
         raise ValueError("conv2d_nhwc: operand of %.2f GiB; the kernels use 32-bit buffer offsets (< 2 GiB per operand): "
                          "lower the frame-stage batch (ClipEngine steps_per_batch) or split the call over M"

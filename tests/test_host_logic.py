@@ -392,10 +392,17 @@ def test_bench_default_steps_per_batch():
     spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    f = bench.default_steps_per_batch
-    assert [f(20, w) for w in (1, 2, 4, 8)] == [10, 20, 20, 20]
-    assert [f(48, w) for w in (1, 2, 4, 8)] == [10, 16, 24, 48]
-    assert f(7, 2) == 7 and f(100, 2) == 20 and f(100, 8) == 50
+    f, kf = bench.default_steps_per_batch, bench.key_frames_per_block
+    # a step is `world` key frames: a block of --steps steps covers steps x world key frames, and the default step-batch
+    # is 10 key frames per rank whenever --steps is a multiple of 10 (a rank's frame-stage launch keeps its 20 frames)
+    assert [kf(20, w) for w in (1, 2, 4, 8)] == [20, 40, 80, 160]
+    assert [f(20, w) for w in (1, 2, 4, 8)] == [10, 20, 40, 80]
+    assert [f(100, w) for w in (1, 2, 8)] == [10, 20, 80]
+    assert [f(48, w) for w in (1, 2, 4, 8)] == [8, 16, 32, 64]        # 48 = 6 x 8: 8 key frames per rank
+    assert f(7, 1) == 7 and f(7, 2) == 14
+    for steps in (5, 20, 48):
+        for w in (1, 2, 4, 8):
+            assert kf(steps, w) % f(steps, w) == 0 and f(steps, w) <= 10 * w
 
 
 def test_cat_rows_is_free_for_consecutive_row_blocks():
