@@ -116,6 +116,13 @@ int mega_rpn_select(const float* rpn_out, const float* cell_anchors, int B, int 
                     int anchor_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int strict_gt,
                     float min_size, float im_w, float im_h, float* proposals, float* prop_scores, int* prop_cnt,
                     void* ws, size_t ws_bytes, void* stream);
+/* The same with prop_index [B][post_nms_top_n] (NULL allowed): the flat anchor index (y * Wf + x) * A + a of every
+ * kept proposal (-1 in unused rows) = the reference's index into permute_and_flatten's (N, H*W*A) order
+ * (rpn/utils.py:10-14, rpn/inference.py:93-104) after NMS: what "bit-exact proposal indices" is checked on. */
+int mega_rpn_select_idx(const float* rpn_out, const float* cell_anchors, int B, int Hf, int Wf, int A, int ldc,
+                        int anchor_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int strict_gt,
+                        float min_size, float im_w, float im_h, float* proposals, float* prop_scores, int* prop_cnt,
+                        int* prop_index, void* ws, size_t ws_bytes, void* stream);
 
 /* Box-head post-processor for one image.  Replaces PostProcessor.forward / filter_results
  * (modeling/roi_heads/box_head/inference.py:45-149): softmax, per-class decode with (wx,wy,ww,wh), clip,

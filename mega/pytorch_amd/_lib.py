@@ -30,6 +30,8 @@ SIGNATURES = {
     "mega_rpn_select_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mega_rpn_select": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_float, c_float, c_float] +
                         [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "mega_rpn_select_idx": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_float, c_float, c_float] +
+                            [c_void_p] * 5 + [c_size_t, c_void_p]),
     "mega_postprocess_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mega_postprocess": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_float] * 8 + [c_int, c_int] + [c_void_p] * 6 +
                          [c_size_t, c_void_p]),

@@ -18,12 +18,16 @@ SOURCES = {
     "igemm8.hip": [],
     "spatial.hip": [],
     "boxes.hip": ["-ffp-contract=off"],
-    "relation.hip": [],
+    # MFMA results in VGPRs: the attention loop otherwise keeps its O accumulators in AGPRs and moves them to VGPRs and
+    # back around every (usually skipped) rescale -- 400 v_accvgpr moves in the kernel, 160 per loop iteration
+    "relation.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "frames.hip": ["-ffp-contract=off"],      # (x / 255) * 255 - mean must round like the reference's three torch ops
     "fgfa.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+if os.environ.get("MEGA_BUILD_EXPERIMENTS") == "1":      # tools/gpu/ablate8.py: igemm8 ablation / timeline variants
+    BASE_FLAGS.append("-DMEGA_EXPERIMENTS")
 
 
 def _digest():
@@ -33,6 +37,7 @@ def _digest():
             h.update(fn.encode())
             h.update(open(os.path.join(CSRC, fn), "rb").read())
     h.update(" ".join(BASE_FLAGS).encode())
+    h.update(repr(sorted(SOURCES.items())).encode())
     return h.hexdigest()
 
 

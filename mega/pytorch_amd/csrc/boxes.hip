@@ -388,6 +388,7 @@ struct RpnParams {
   float4* boxes;          // [B][kmax][4]  decoded, clipped, score-sorted
   float* scores;          // [B][kmax]     sigmoid(logit)
   unsigned char* valid;   // [B][kmax]     remove_small_boxes result
+  int* anchor_idx;        // [B][kmax] or null: flat anchor index (y * Wf + x) * A + a of each sorted candidate
   int* counts;            // [B]           = k
   int B, Hf, Wf, A, ldc, stride;
   int k;                  // pre_nms_top_n (already min'ed with the anchor count)
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_decode_kernel(RpnParams p) {
     p.scores[o] = 1.f / (1.f + expf(-logit));
     // remove_small_boxes (boxlist_ops.py:34-50): xywh widths with TO_REMOVE = 1
     p.valid[o] = ((x2 - x1 + 1.f) >= p.min_size) && ((y2 - y1 + 1.f) >= p.min_size);
+    if (p.anchor_idx) p.anchor_idx[o] = e;
   }
   if (tid == 0) p.counts[b] = p.k;
 }
@@ -526,19 +528,23 @@ __global__ __launch_bounds__(1024) void rpn_topk_decode_kernel(RpnParams p) {
 // proposals[b][r] = boxes[b][keep_pos[b][r]] for r < keep_cnt[b], zero rows after
 __global__ void gather_kept_kernel(const float4* __restrict__ boxes, const float* __restrict__ scores,
                                    const int* __restrict__ keep_pos, const int* __restrict__ keep_cnt, int nmax,
-                                   int max_keep, float4* __restrict__ out_boxes, float* __restrict__ out_scores) {
+                                   int max_keep, float4* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                   const int* __restrict__ idx_in, int* __restrict__ idx_out) {
   const int b = blockIdx.x;
   const int cnt = keep_cnt[b];
   for (int r = threadIdx.x; r < max_keep; r += blockDim.x) {
     float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
     float sc = 0.f;
+    int ix = -1;
     if (r < cnt) {
       const int pos = keep_pos[(size_t)b * max_keep + r];
       bx = boxes[(size_t)b * nmax + pos];
       sc = scores[(size_t)b * nmax + pos];
+      if (idx_in) ix = idx_in[(size_t)b * nmax + pos];
     }
     out_boxes[(size_t)b * max_keep + r] = bx;
     out_scores[(size_t)b * max_keep + r] = sc;
+    if (idx_out) idx_out[(size_t)b * max_keep + r] = ix;
   }
 }
 
@@ -770,7 +776,11 @@ extern "C" int mega_nms_sorted(const float* boxes, const int* counts, const unsi
   hipStream_t st = (hipStream_t)stream;
   const int cb = cdiv(nmax, 64);
   static const int lazy_min = getenv("MEGA_NMS_LAZY_MIN") ? atoi(getenv("MEGA_NMS_LAZY_MIN")) : 1024;
-  if (nmax >= lazy_min) {        // long candidate lists (the RPN's 6000): only the kept boxes' rows are evaluated
+  // Lazy form: one block per problem walks the sorted list and evaluates only the kept boxes' rows, stopping at
+  // max_keep -- it pays when few boxes are kept out of many (the RPN: 300 of 6000) or the list is long; many small
+  // problems that keep everything (post-processing with R = 1024: 30 classes x B images, max_keep = R) are better
+  // served by the mask + scan pair, whose work is spread over nmax^2 / 4096 blocks per problem.
+  if (nmax >= lazy_min && (4 * max_keep <= nmax || nmax > 2048)) {
     const size_t lds = (((size_t)nmax * 17 + 15) & ~(size_t)15) + (size_t)nmax * 2 + 16;
     if (hipFuncSetAttribute((const void*)nms_lazy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return MEGA_ERR_LAUNCH;
@@ -825,14 +835,17 @@ extern "C" int mega_nms(const float* dets, const float* scores, int n, float thr
 // RPN proposal selection for B frames (rpn/inference.py:76-123).
 //   rpn_out [B][Hf*Wf][ldc] f32; cell_anchors [A][4]; outputs proposals [B][post_nms][4], prop_scores, prop_cnt[B]
 extern "C" size_t mega_rpn_select_workspace_bytes(int B, int pre_nms) {
-  return align_up((size_t)B * pre_nms * 16, 256) + align_up((size_t)B * pre_nms * 4, 256) * 2 +
+  return align_up((size_t)B * pre_nms * 16, 256) + align_up((size_t)B * pre_nms * 4, 256) * 3 +
          align_up((size_t)B * pre_nms, 256) + align_up((size_t)B * 4, 256) + mega_nms_workspace_bytes(B, pre_nms);
 }
 
-extern "C" int mega_rpn_select(const float* rpn_out, const float* cell_anchors, int B, int Hf, int Wf, int A, int ldc,
-                               int anchor_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh,
-                               int strict_gt, float min_size, float im_w, float im_h, float* proposals,
-                               float* prop_scores, int* prop_cnt, void* ws, size_t ws_bytes, void* stream) {
+// prop_index [B][post_nms_top_n] (optional): the flat anchor index (y * Wf + x) * A + a of every kept proposal, -1 in
+// the unused rows -- the "proposal indices after NMS" in the reference's (N, H, W, A) flattening (rpn/utils.py:10-14).
+extern "C" int mega_rpn_select_idx(const float* rpn_out, const float* cell_anchors, int B, int Hf, int Wf, int A, int ldc,
+                                   int anchor_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh,
+                                   int strict_gt, float min_size, float im_w, float im_h, float* proposals,
+                                   float* prop_scores, int* prop_cnt, int* prop_index, void* ws, size_t ws_bytes,
+                                   void* stream) {
   mega_clear_error();
   if (!rpn_out || !cell_anchors || !proposals || !prop_scores || !prop_cnt || !ws || B <= 0 || Hf <= 0 || Wf <= 0 ||
       A <= 0 || ldc < 5 * A || pre_nms_top_n <= 0 || post_nms_top_n <= 0)
@@ -846,10 +859,12 @@ extern "C" int mega_rpn_select(const float* rpn_out, const float* cell_anchors, 
   float4* sboxes = (float4*)w; w += align_up((size_t)B * k * 16, 256);
   float* sscores = (float*)w; w += align_up((size_t)B * k * 4, 256);
   int* keep_pos = (int*)w; w += align_up((size_t)B * k * 4, 256);
+  int* aidx = (int*)w; w += align_up((size_t)B * k * 4, 256);
   unsigned char* valid = w; w += align_up((size_t)B * k, 256);
   int* counts = (int*)w; w += align_up((size_t)B * 4, 256);
   void* mws = w;
   RpnParams p;
+  p.anchor_idx = prop_index ? aidx : nullptr;
   p.rpn_out = rpn_out; p.cell_anchors = cell_anchors; p.boxes = sboxes; p.scores = sscores; p.valid = valid;
   p.counts = counts; p.B = B; p.Hf = Hf; p.Wf = Wf; p.A = A; p.ldc = ldc; p.stride = anchor_stride; p.k = k;
   p.kmax = k; p.im_w = im_w; p.im_h = im_h; p.min_size = min_size; p.clip = logf(1000.f / 16.f);
@@ -864,8 +879,17 @@ extern "C" int mega_rpn_select(const float* rpn_out, const float* cell_anchors, 
   if (rc != MEGA_OK) return rc;
   // keep_pos rows are post_nms_top_n wide
   hipLaunchKernelGGL(gather_kept_kernel, dim3(B), dim3(256), 0, st, sboxes, sscores, keep_pos, prop_cnt, k,
-                     post_nms_top_n, (float4*)proposals, prop_scores);
+                     post_nms_top_n, (float4*)proposals, prop_scores, (const int*)p.anchor_idx, prop_index);
   return mega_check_launch();
+}
+
+extern "C" int mega_rpn_select(const float* rpn_out, const float* cell_anchors, int B, int Hf, int Wf, int A, int ldc,
+                               int anchor_stride, int pre_nms_top_n, int post_nms_top_n, float nms_thresh,
+                               int strict_gt, float min_size, float im_w, float im_h, float* proposals,
+                               float* prop_scores, int* prop_cnt, void* ws, size_t ws_bytes, void* stream) {
+  return mega_rpn_select_idx(rpn_out, cell_anchors, B, Hf, Wf, A, ldc, anchor_stride, pre_nms_top_n, post_nms_top_n,
+                             nms_thresh, strict_gt, min_size, im_w, im_h, proposals, prop_scores, prop_cnt, nullptr, ws,
+                             ws_bytes, stream);
 }
 
 // Box-head post-processor for one image (roi_heads/box_head/inference.py:45-149).

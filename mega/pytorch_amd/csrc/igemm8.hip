@@ -50,7 +50,8 @@ struct KPos {
 };
 
 // ABL != 0: timing-only ablations for tools/gpu (1: no fragment ds_reads in the loop, 2: no DMA in the loop, 3: no MFMA);
-// results are garbage by construction.
+// results are garbage by construction.  Only ABL = 0 is instantiated unless the library is built with
+// -DMEGA_EXPERIMENTS (see mega_igemm8_launch).
 template <typename OT, int MF1, int ABL = 0>
 __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   constexpr int BM = 128 + 64 * MF1;
@@ -470,7 +471,11 @@ int mega_igemm8_supports(const ConvParams& p) {
 }
 
 int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st) {
-  static const int abl = getenv("MEGA_IGEMM8_ABLATE") ? atoi(getenv("MEGA_IGEMM8_ABLATE")) : 0;   // timing experiments only
+#ifdef MEGA_EXPERIMENTS
+  // Timing ablations / s_memtime timeline (tools/gpu/ablate8.py).  NOT part of the product library: this block
+  // allocates, synchronises and prints, and its kernels return garbage by construction -- it only exists in a library
+  // built with MEGA_BUILD_EXPERIMENTS=1 (mega/pytorch_amd/build.py adds -DMEGA_EXPERIMENTS).
+  static const int abl = getenv("MEGA_IGEMM8_ABLATE") ? atoi(getenv("MEGA_IGEMM8_ABLATE")) : 0;
   if (abl && bm == 256 && !out_f32) {
     if (abl == 1) return launch8<bf16_t, 2, 1>(p, st);
     if (abl == 2) return launch8<bf16_t, 2, 2>(p, st);
@@ -500,6 +505,7 @@ int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st)
       return rc;
     }
   }
+#endif
   if (bm == 256) return out_f32 ? launch8<float, 2>(p, st) : launch8<bf16_t, 2>(p, st);
   if (bm == 192) return out_f32 ? launch8<float, 1>(p, st) : launch8<bf16_t, 1>(p, st);
   return MEGA_ERR_ARG;

@@ -120,6 +120,15 @@ __device__ __forceinline__ float sin_shifted(float a, float shift_rev) {
   return __builtin_amdgcn_sinf(fmaf(r, INV2PI, shift_rev));
 }
 
+// The same value with the argument already in REVOLUTIONS: sin(2 pi (x_rev + shift_rev)).  The position arguments are
+// 100 * log-ratio / 1000^(i/8) with |log-ratio| <= 6.91 (the 1e-3 floor and a 1000-pixel image), i.e. |x_rev| <= 110:
+// an f32 at that magnitude resolves 7.6e-6 revolutions = 4.8e-5 rad, the same as the radian argument the Cody-Waite
+// form starts from (ulp of 690 rad = 6.1e-5), so v_fract + v_sin loses nothing -- and costs 3 VALU per value (fma,
+// fract, sin) instead of 7.  (gfx9+ v_sin_f32 wants its argument pre-reduced to [0, 1).)
+__device__ __forceinline__ float sin_rev(float x_rev) {
+  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x_rev));
+}
+
 // fast-mode (bf16 path) logarithm / division: v_log_f32 (1 ulp in log2) and v_rcp_f32 -- the position arguments are
 // 100 x log(ratio): an absolute error of ~1e-6 in the log moves the phase by 1e-4 rad, far below the bf16 rounding
 // of the embedding that follows.
@@ -147,9 +156,9 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int e = 0; e < 8; ++e) bw[s][e] = (__bf16)wgt[(32 * s + 8 * g + e) * 16 + row];
-  float rdim[8];
+  float crev[8];                                       // 100 / (2 pi dim[i]): log-ratio -> revolutions
 #pragma unroll
-  for (int i = 0; i < 8; ++i) rdim[i] = 1.0f / dim_mat[i];
+  for (int i = 0; i < 8; ++i) crev[i] = (100.0f * 0.15915494309189535f) / dim_mat[i];
   const float bias = bg[row];
   const float4 bq = rois_q[q];
   const float wq = bq.z - bq.x + 1.f, hq = bq.w - bq.y + 1.f;
@@ -175,10 +184,9 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
     f32x4_t acc = {bias, bias, bias, bias};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const float pv = pm[s] * 100.0f;
       bf16x8_t a;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] = (__bf16)sin_shifted(pv * rdim[i], shift);
+      for (int i = 0; i < 8; ++i) a[i] = (__bf16)sin_rev(fmaf(pm[s], crev[i], shift));
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[s], acc, 0, 0, 0);
     }
     // D: head = lane & 15, pairs k0 + 4 g + r
@@ -219,9 +227,9 @@ __device__ __forceinline__ void pos_logits_tiled_body(const float4* __restrict__
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int e = 0; e < 8; ++e) bw[s][e] = (__bf16)wgt[(32 * s + 8 * g + e) * 16 + row];
-  float rdim[8];
+  float crev[8];                                       // 100 / (2 pi dim[i]): log-ratio -> revolutions
 #pragma unroll
-  for (int i = 0; i < 8; ++i) rdim[i] = 1.0f / dim_mat[i];
+  for (int i = 0; i < 8; ++i) crev[i] = (100.0f * 0.15915494309189535f) / dim_mat[i];
   const float bias = bg[row];
   const float shift = (g & 1) ? 0.25f : 0.f;        // odd k-groups hold cosines
 #pragma unroll 1
@@ -245,10 +253,9 @@ __device__ __forceinline__ void pos_logits_tiled_body(const float4* __restrict__
     f32x4_t acc = {bias, bias, bias, bias};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const float pv = pm[s] * 100.0f;
       bf16x8_t a;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] = (__bf16)sin_shifted(pv * rdim[i], shift);
+      for (int i = 0; i < 8; ++i) a[i] = (__bf16)sin_rev(fmaf(pm[s], crev[i], shift));
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[s], acc, 0, 0, 0);
     }
     // D: head = row, keys kb + 4 g + r of the block's 64
@@ -625,8 +632,10 @@ struct AttnBatch {
   AttnParams p[ATTN_MAXB];
 };
 
-template <typename T, bool POS_TILED>
-__global__ __launch_bounds__(256) void attn_batched_kernel(AttnBatch b) {
+// MINB = blocks per CU the register allocation aims at: 2 (174 VGPRs) or 3 (168 VGPRs; the tiled-position variant then
+// spills 6 dwords) -- an A/B pair, selected by MEGA_ATTN_OCC3 until one of them is measured to win.
+template <typename T, bool POS_TILED, int MINB>
+__global__ __launch_bounds__(256, MINB) void attn_batched_kernel(AttnBatch b) {
   const int z = blockIdx.z;
   const AttnParams& p = b.p[b.zprob[z]];
   if ((int)blockIdx.x * 128 >= p.Nq) return;          // (block-uniform: the grid is sized for the largest problem)
@@ -751,7 +760,8 @@ static int attn_fill(AttnParams& p, const void* q, int ldq, const void* k, int l
   if (nsplit > 1 && (!ws || ws_bytes < mega_relation_attention_workspace_bytes(Nq, Nk, groups))) nsplit = 1;
   const int ntiles = cdiv(Nk, 32);
   p.tiles_per_split = cdiv(ntiles, nsplit);
-  { const char* e = getenv("MEGA_ATTN_VMASK_ALWAYS"); p.vmask_always = (e && e[0] == '1') ? 1 : 0; }
+  static const int vmask_always = (getenv("MEGA_ATTN_VMASK_ALWAYS") && getenv("MEGA_ATTN_VMASK_ALWAYS")[0] == '1') ? 1 : 0;
+  p.vmask_always = vmask_always;      // (experiments; read once: not on the per-launch path)
   nsplit = cdiv(ntiles, p.tiles_per_split);   // no empty splits
   p.nsplit = nsplit;
   p.part_o = (float*)ws;
@@ -821,9 +831,12 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
   b.nz = nz;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(max_q, 128), groups, nz);
-  if (dtype == MEGA_BF16 && tiled) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, true>), grid, dim3(256), 0, st, b);
-  else if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, false>), grid, dim3(256), 0, st, b);
-  else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_batched_kernel<float, false>), grid, dim3(256), 0, st, b);
+  static const bool occ3 = getenv("MEGA_ATTN_OCC3") != nullptr && getenv("MEGA_ATTN_OCC3")[0] == '1';
+  if (dtype == MEGA_BF16 && tiled && occ3) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, true, 3>), grid, dim3(256), 0, st, b);
+  else if (dtype == MEGA_BF16 && tiled) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, true, 2>), grid, dim3(256), 0, st, b);
+  else if (dtype == MEGA_BF16 && occ3) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, false, 3>), grid, dim3(256), 0, st, b);
+  else if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, false, 2>), grid, dim3(256), 0, st, b);
+  else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_batched_kernel<float, false, 2>), grid, dim3(256), 0, st, b);
   else return MEGA_ERR_ARG;
   if (any_split) {
     const int blocks = (int)((max_total + 255) / 256 > 4096 ? 4096 : (max_total + 255) / 256);

@@ -300,39 +300,72 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __rest
 }
 
 
-// bf16-mode variant with SEPARABLE weights, computed ONCE per block.  A bin's value is (1/count) sum over its
+// bf16-mode variant with SEPARABLE weights, computed ONCE per ROI.  A bin's value is (1/count) sum over its
 // grid_h x grid_w samples of the bilinear blend of 4 pixels; the blend weights factor into (hy | ly) x (hx | lx), so
 //   bin = (1/count) sum_y sum_x Wy[y] Wx[x] f(y, x),   Wy[y] = sum of hy over samples whose lower row is y + ly over
-// those whose upper row is y (same for x).  Adjacent samples are at most one pixel apart (grid = ceil(roi / bins)), so
-// the touched pixels form a dense (<= grid_h + 1) x (<= grid_w + 1) patch: 16 loads instead of 36 for a 3 x 3 grid.
-// The per-lane form of this kernel is VALU-bound on the sample-position arithmetic that all 64 lanes of a wave (the
-// channel vectors of one bin) repeat identically (~1400 VALU instructions per output vector).  Here a block owns one
-// ROW of bins of one ROI (pooled_w bins, all channels): one wave's lanes build the row's Wy and the pooled_w Wx tables
-// in LDS, then every thread only does (load, 8 fma) per patch pixel with broadcast LDS reads of the weights.
+// those whose upper row is y (same for x).  With the adaptive grid (sampling_ratio 0: grid = ceil(roi / bins)) adjacent
+// samples are at most one pixel apart, so the touched pixels form a dense (<= grid_h + 1) x (<= grid_w + 1) patch:
+// 16 loads instead of 36 for a 3 x 3 grid.
+// A block owns ONE ROI (all pooled_h x pooled_w bins) and one slice of the channels: 140 threads build the pooled_h row
+// tables and the pooled_w column tables once (the column tables are shared by all rows of bins), then every thread runs
+// (load, 8 fma) per patch pixel over ~6 (bin, channel vector) items with broadcast LDS reads of the weights.  Round 2's
+// form had one block per ROW of bins: the per-block latency chain (ROI read -> tables -> barrier) was paid 7 times per
+// ROI and dominated (630 us for 3750 ROIs).  The patch loops are branch-free: rows / columns run to the BLOCK's maximum
+// count at clamped (valid) addresses -- unused slots carry weight 0 in the tables -- so a row's loads issue back to back
+// instead of under one exec-mask branch and wait per column.
 // The sum is re-associated, hence bf16 mode only: the exact-f32 path keeps the reference's term order
-// (roi_align_nhwc_vec_kernel).
-constexpr int RS_MAXP = 10;     // patch rows / columns (grid <= 9)
-constexpr int RS_MAXPW = 8;     // pooled_w <= 8
+// (roi_align_nhwc_vec_kernel).  A ROI whose patch does not fit the tables (grid > 9: a box larger than the map) takes
+// the sample-by-sample loop in the same kernel; sampling_ratio > 0 (sparse samples) never comes here.
+constexpr int RS_MAXP = 10;     // patch rows / columns per bin (grid <= 9)
+constexpr int RS_MAXPW = 8;     // pooled_h, pooled_w <= 8
+
+template <typename T, int NC, int RU>
+__device__ __forceinline__ void roi_patch_accumulate(const T* __restrict__ base, int W, int H, int C, int y0, int x0,
+                                                     int NR, const float* __restrict__ wy, const float* __restrict__ wx,
+                                                     float (&acc)[Elem<T>::VE]) {
+  constexpr int VE = Elem<T>::VE;
+  int xo[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) xo[c] = min(x0 + c, W - 1) * C;
+  for (int r = 0; r < NR; r += RU) {
+    uint4 rv[RU][NC];                       // RU patch rows are requested before the first FMA
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const T* rowp = base + (size_t)min(y0 + r + u, H - 1) * W * C;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) rv[u][c] = *reinterpret_cast<const uint4*>(rowp + xo[c]);
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const float wyr = r + u < RS_MAXP ? wy[r + u] : 0.f;      // (RU = 2 may look one slot past an odd NR: weight 0)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const T* ev = reinterpret_cast<const T*>(&rv[u][c]);
+        const float wgt = wyr * wx[c];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] = fmaf(wgt, Elem<T>::ld(ev + e), acc[e]);
+      }
+    }
+  }
+}
 
 template <typename T, int NSLICE>
-__global__ __launch_bounds__(256) void roi_align_nhwc_sep_kernel(const T* __restrict__ feat,
+__global__ __launch_bounds__(256, 4) void roi_align_nhwc_sep_kernel(const T* __restrict__ feat,
                                                                  const float* __restrict__ rois, T* __restrict__ out,
                                                                  int K, int C, int H, int W, float spatial_scale,
-                                                                 int PH, int PW, int sampling_ratio) {
+                                                                 int PH, int PW) {
   constexpr int VE = Elem<T>::VE;
-  __shared__ float s_wy[RS_MAXP];
+  __shared__ float s_wy[RS_MAXPW][RS_MAXP + 2];   // (+2: the two-row unroll reads one slot past an odd row count)
   __shared__ float s_wx[RS_MAXPW][RS_MAXP];
-  __shared__ int s_y[2];                    // first row, number of rows
-  __shared__ int s_x[RS_MAXPW][2];          // per bin: first column, number of columns
+  __shared__ int s_y[RS_MAXPW][2];          // per bin row: first patch row, number of rows
+  __shared__ int s_x[RS_MAXPW][2];          // per bin column: first patch column, number of columns
   const int CV = C / VE;
   // NSLICE == 8: the block handles one eighth of the channels, slice = blockIdx.x & 7 = the XCD the block runs on
   // (consecutive blocks go to consecutive XCDs): each XCD's private L2 then only ever sees its own 1/8 of every
-  // feature map (1.2 MB per frame at 2048 channels) instead of all of it (PMC: 4.6 GB fetched per 20-frame launch
-  // for 196 MB of maps in the unsliced form).  Placement is a speed heuristic only.
+  // feature map (1.2 MB per frame at 2048 channels) instead of all of it.  Placement is a speed heuristic only.
   const int slice = NSLICE == 8 ? (int)(blockIdx.x & 7) : 0;
-  const int rowid = NSLICE == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int k = NSLICE == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int cvs = CV / NSLICE;                 // channel vectors of this block
-  const int k = rowid / PH, ph = rowid - k * PH;
   const float* roi = rois + (size_t)k * 5;
   const int b = (int)roi[0];
   const float roi_start_w = roi[1] * spatial_scale;
@@ -343,8 +376,8 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_sep_kernel(const T* __rest
   const float roi_height = fmaxf(roi_end_h - roi_start_h, 1.f);
   const float bin_size_h = roi_height / (float)PH;
   const float bin_size_w = roi_width / (float)PW;
-  const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)PH);
-  const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)PW);
+  const int grid_h = (int)ceilf(roi_height / (float)PH);
+  const int grid_w = (int)ceilf(roi_width / (float)PW);
   const float count = (float)(grid_h * grid_w);
   // one axis sample -> (low index, high index, weight of low, weight of high); weights 0 when the sample is skipped
   auto axis = [](float p, int n, int& lo, int& hi, float& wl, float& wh) {
@@ -367,60 +400,90 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_sep_kernel(const T* __rest
     for (int i = 0; i < grid; ++i) {
       int lo, hi; float wl, wh;
       axis(start + bin_index * bin_size + (i + .5f) * bin_size / (float)grid, n, lo, hi, wl, wh);
-      if (lo - f == slot) w += wl;
-      if (hi - f == slot) w += wh;
+      if (wl + wh > 0.f) {
+        if (lo - f == slot) w += wl;
+        if (hi - f == slot) w += wh;
+      }
     }
+    if (l < f) { f = 0; l = -1; }           // every sample of the bin lies outside the map: an empty patch
     first = f;
     cnt = l - f + 1;
     return w;
   };
   const int tid = threadIdx.x;
-  if (tid < RS_MAXP) {
+  if (tid < PH * (RS_MAXP + 2)) {
+    const int ph = tid / (RS_MAXP + 2), slot = tid - ph * (RS_MAXP + 2);
     int first, cnt;
-    s_wy[tid] = table(roi_start_h, bin_size_h, ph, grid_h, H, tid, first, cnt);
-    if (tid == 0) { s_y[0] = first; s_y[1] = cnt; }
-  } else if (tid >= 64 && tid < 64 + PW * RS_MAXP) {
-    const int pw = (tid - 64) / RS_MAXP, slot = (tid - 64) - pw * RS_MAXP;
+    const float w = table(roi_start_h, bin_size_h, ph, grid_h, H, slot, first, cnt);
+    s_wy[ph][slot] = slot < RS_MAXP ? w : 0.f;
+    if (slot == 0) { s_y[ph][0] = first; s_y[ph][1] = cnt; }
+  } else if (tid >= 128 && tid < 128 + PW * RS_MAXP) {
+    const int pw = (tid - 128) / RS_MAXP, slot = (tid - 128) - pw * RS_MAXP;
     int first, cnt;
     s_wx[pw][slot] = table(roi_start_w, bin_size_w, pw, grid_w, W, slot, first, cnt);
     if (slot == 0) { s_x[pw][0] = first; s_x[pw][1] = cnt; }
   }
   __syncthreads();
-  const int y_first = s_y[0], nrow = s_y[1];
+  int NR = 0, NCm = 0;                       // block-uniform patch extents
+  for (int i = 0; i < PH; ++i) NR = max(NR, s_y[i][1]);
+  for (int i = 0; i < PW; ++i) NCm = max(NCm, s_x[i][1]);
   const float inv_count = 1.f / count;
   const T* fb = feat + (size_t)b * H * W * C;
-  for (int item = tid; item < PW * cvs; item += 256) {      // (bin of the row, channel vector of the slice)
-    const int pw = item / cvs;
-    const int cv = slice * cvs + (item - pw * cvs);
-    const int x_first = s_x[pw][0], ncol = s_x[pw][1];
-    {
+  const int nitem = PH * PW * cvs;
+  if (NR > RS_MAXP || NCm > RS_MAXP) {
+    // a patch wider than the tables (a ROI larger than the map): sample by sample, any grid
+    for (int item = tid; item < nitem; item += 256) {
+      const int bin = item / cvs, ph = bin / PW, pw = bin - ph * PW;
+      const int cv = slice * cvs + (item - bin * cvs);
       float acc[VE];
 #pragma unroll
       for (int e = 0; e < VE; ++e) acc[e] = 0.f;
-      for (int r = 0; r < nrow; ++r) {
-        const float wy = s_wy[r];
-        if (wy == 0.f) continue;
-        const T* rowp = fb + ((size_t)(y_first + r) * W + x_first) * C + (size_t)cv * VE;
-        uint4 rv[RS_MAXP];                    // the whole patch row is requested before the first FMA
+      for (int iy = 0; iy < grid_h; ++iy) {
+        int ylo, yhi; float wyl, wyh;
+        axis(roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / (float)grid_h, H, ylo, yhi, wyl, wyh);
+        for (int ix = 0; ix < grid_w; ++ix) {
+          int xlo, xhi; float wxl, wxh;
+          axis(roi_start_w + pw * bin_size_w + (ix + .5f) * bin_size_w / (float)grid_w, W, xlo, xhi, wxl, wxh);
+          if (wyl + wyh == 0.f || wxl + wxh == 0.f) continue;
+          const int ys[2] = {ylo, yhi}, xs[2] = {xlo, xhi};
+          const float wys[2] = {wyl, wyh}, wxs[2] = {wxl, wxh};
 #pragma unroll
-        for (int c = 0; c < RS_MAXP; ++c)
-          if (c < ncol) rv[c] = *reinterpret_cast<const uint4*>(rowp + (size_t)c * C);
+          for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < RS_MAXP; ++c) {
-          if (c < ncol) {
-            const T* ev = reinterpret_cast<const T*>(&rv[c]);
-            const float wgt = wy * s_wx[pw][c];
+            for (int c = 0; c < 2; ++c) {
+              const uint4 v = *reinterpret_cast<const uint4*>(fb + ((size_t)ys[a] * W + xs[c]) * C + (size_t)cv * VE);
+              const T* ev = reinterpret_cast<const T*>(&v);
+              const float wgt = wys[a] * wxs[c];
 #pragma unroll
-            for (int e = 0; e < VE; ++e) acc[e] = fmaf(wgt, Elem<T>::ld(ev + e), acc[e]);
-          }
+              for (int e = 0; e < VE; ++e) acc[e] = fmaf(wgt, Elem<T>::ld(ev + e), acc[e]);
+            }
         }
       }
       uint4 o;
       T* oe = reinterpret_cast<T*>(&o);
 #pragma unroll
       for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] * inv_count);
-      *reinterpret_cast<uint4*>(out + ((size_t)(k * PH + ph) * PW + pw) * C + (size_t)cv * VE) = o;
+      *reinterpret_cast<uint4*>(out + ((size_t)k * PH * PW + bin) * C + (size_t)cv * VE) = o;
     }
+    return;
+  }
+  for (int item = tid; item < nitem; item += 256) {          // (bin, channel vector of the slice)
+    const int bin = item / cvs, ph = bin / PW, pw = bin - ph * PW;
+    const int cv = slice * cvs + (item - bin * cvs);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    const T* base = fb + (size_t)cv * VE;
+    const int y0 = s_y[ph][0], x0 = s_x[pw][0];
+    if (NCm <= 3) roi_patch_accumulate<T, 3, 2>(base, W, H, C, y0, x0, NR, s_wy[ph], s_wx[pw], acc);
+    else if (NCm <= 4) roi_patch_accumulate<T, 4, 2>(base, W, H, C, y0, x0, NR, s_wy[ph], s_wx[pw], acc);
+    else if (NCm <= 6) roi_patch_accumulate<T, 6, 2>(base, W, H, C, y0, x0, NR, s_wy[ph], s_wx[pw], acc);
+    else roi_patch_accumulate<T, RS_MAXP, 1>(base, W, H, C, y0, x0, NR, s_wy[ph], s_wx[pw], acc);
+    uint4 o;
+    T* oe = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] * inv_count);
+    *reinterpret_cast<uint4*>(out + ((size_t)k * PH * PW + bin) * C + (size_t)cv * VE) = o;
   }
 }
 
@@ -622,17 +685,15 @@ extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out
     if (nb > 131072) nb = 131072;
     dim3 vgrid((unsigned)(sliced ? nb * 8 : nb));
     static const bool no_sep = getenv("MEGA_ROI_NO_SEPARABLE") != nullptr;         // A/B switch (experiments)
-    // grid = ceil(roi / bins) <= ceil(max(H, W) / min(ph, pw)): the register patch of the separable form holds 10 columns
-    const int max_grid = sampling_ratio > 0 ? sampling_ratio : (max(H, W) + min(pooled_h, pooled_w) - 1) / min(pooled_h, pooled_w);
-    if (dtype == MEGA_BF16 && !no_sep && max_grid <= 9 && pooled_w <= RS_MAXPW) {
+    // the separable per-ROI form: adaptive grid only (sampling_ratio > 0 spreads a bin's samples over a sparse patch);
+    // ROIs whose patch exceeds its tables fall back inside the kernel, so no bound on the boxes is assumed here
+    if (dtype == MEGA_BF16 && !no_sep && sampling_ratio <= 0 && pooled_w <= RS_MAXPW && pooled_h <= RS_MAXPW) {
       if (!no_slice && CV % 8 == 0 && CV / 8 >= 16)
-        hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<bf16_t, 8>), dim3((unsigned)(K * pooled_h * 8)), dim3(256), 0, st,
-                           (const bf16_t*)feat, rois, (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w,
-                           sampling_ratio);
+        hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<bf16_t, 8>), dim3((unsigned)(K * 8)), dim3(256), 0, st,
+                           (const bf16_t*)feat, rois, (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w);
       else
-        hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<bf16_t, 1>), dim3((unsigned)(K * pooled_h)), dim3(256), 0, st,
-                           (const bf16_t*)feat, rois, (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w,
-                           sampling_ratio);
+        hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<bf16_t, 1>), dim3((unsigned)K), dim3(256), 0, st,
+                           (const bf16_t*)feat, rois, (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w);
       return mega_check_launch();
     }
     if (dtype == MEGA_BF16 && sliced)

@@ -109,7 +109,7 @@ class KeyFrameShard(object):
 
 class ClipEngine(object):
     def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True, graphs=True, reuse_records=False,
-                 static_aggregation=False, keep_logits=False, batch_aggregation=True, ramp=False):
+                 static_aggregation=False, keep_logits=False, batch_aggregation=True, ramp=False, frame_model=None):
         """steps_per_batch: key-frame steps whose frame jobs are computed in one frame-stage batch
         (steady state: 2 frames per step).  dist_group: torch.distributed group to shard the frame stage over
         (None = single process).  overlap: use the two-stream pipeline (see module docstring).
@@ -120,6 +120,10 @@ class ClipEngine(object):
         use can take the stored one (first 75 rows for the global role).  Identical detections, ~half the frame-stage
         work over a whole video.  Off by default: the benchmark's headline keeps the reference's two passes."""
         self.model = model
+        # frame_model: a second detector with the same weights in another compute dtype that runs the frame stage
+        # (backbone .. fc0); `model` then only aggregates, on records cast to its dtype.  Mixed-precision runs: which
+        # half of the path a bf16 deviation comes from (tests/test_e2e_gpu.py::test_r101_bf16_attribution).
+        self.frame_model = model if frame_model is None else frame_model
         self.steps_per_batch = steps_per_batch
         self.group = dist_group
         if dist_group is not None:
@@ -239,7 +243,7 @@ class ClipEngine(object):
         The frame stage is ~130 launches of static shape per batch: as a graph the host pays one replay
         (microseconds) instead of ~35 us of Python + ctypes per launch.  First occurrence of a shape runs eagerly
         (warm-up: packs weights, sets kernel attributes, fills the allocator), the second is captured."""
-        m = self.model
+        m = self.frame_model
         if not (self.use_graphs and imgs.is_cuda):
             return m.frame_stage_async(imgs, want)
         key = (tuple(imgs.shape), tuple(int(w) for w in want), imgs.dtype)
@@ -334,7 +338,13 @@ class ClipEngine(object):
         """handle -> list of frame records.  counts: host list of the per-frame proposal counts (default: read
         them from the device, one host sync)."""
         if "st" in h:
-            return self.model.frame_stage_resolve(h["st"], counts)
+            recs = self.model.frame_stage_resolve(h["st"], counts)
+            if self.frame_model is not self.model:
+                from .modeling import compute_dtype
+                dt = compute_dtype(self.model.cfg)
+                for r in recs:
+                    r["feats"] = r["feats"].to(dt)
+            return recs
         g = h["gathered"]
         if counts is None:
             counts = g["cnt"].tolist()

@@ -239,8 +239,9 @@ def nms(dets, scores, thr, strict_gt=True):
 
 
 def rpn_select(rpn_out, cell_anchors, Hf, Wf, anchor_stride, pre_nms, post_nms, nms_thresh, min_size, im_w, im_h,
-               strict_gt=True):
-    """rpn_out [B,Hf*Wf,5A] f32 -> proposals [B,post_nms,4], scores [B,post_nms], counts [B] (all on device)."""
+               strict_gt=True, want_index=False):
+    """rpn_out [B,Hf*Wf,5A] f32 -> proposals [B,post_nms,4], scores [B,post_nms], counts [B] (all on device).
+    want_index: also the kept proposals' flat anchor indices (y*Wf + x)*A + a, [B,post_nms] i32, -1 past the count."""
     _gpu(rpn_out, cell_anchors)
     lib = _lib.load()
     B = rpn_out.shape[0]
@@ -257,12 +258,13 @@ def rpn_select(rpn_out, cell_anchors, Hf, Wf, anchor_stride, pre_nms, post_nms, 
     nb = lib.mega_rpn_select_workspace_bytes(B, k)
     ws = _ws(nb, rpn_out.device)
     _tok = _pb("rpn_select", 0.0, rpn_out.numel() * 4)
-    rc = lib.mega_rpn_select(_ptr(rpn_out), _ptr(cell_anchors), B, Hf, Wf, A, ldc, anchor_stride, pre_nms, post_nms,
-                             float(nms_thresh), int(strict_gt), float(min_size), float(im_w), float(im_h),
-                             _ptr(props), _ptr(scores), _ptr(cnt), _ptr(ws), nb, _stream())
+    index = torch.empty((B, post_nms), dtype=torch.int32, device=rpn_out.device) if want_index else None
+    rc = lib.mega_rpn_select_idx(_ptr(rpn_out), _ptr(cell_anchors), B, Hf, Wf, A, ldc, anchor_stride, pre_nms, post_nms,
+                                 float(nms_thresh), int(strict_gt), float(min_size), float(im_w), float(im_h),
+                                 _ptr(props), _ptr(scores), _ptr(cnt), _ptr(index), _ptr(ws), nb, _stream())
     _pe(_tok)
     _lib.check(rc, "mega_rpn_select")
-    return props, scores, cnt
+    return (props, scores, cnt, index) if want_index else (props, scores, cnt)
 
 
 def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh, nms_thresh, max_det,
@@ -439,7 +441,13 @@ def relation_attention_batched(items, groups=16):
     for it in items:
         q, k, vt, pos = it["q"], it["k"], it["vt"], it.get("pos")
         _gpu(q, k, vt, pos, it.get("resid"), it.get("bias_v"))
-        assert q.dtype == k.dtype == vt.dtype == dt and q.is_contiguous() and k.is_contiguous()
+        # q / k / resid: row blocks (or column-complete views) of wider buffers are fine -- unit column stride, the row
+        # stride is what the kernel gets as the leading dimension, 16-byte aligned rows
+        resid = it.get("resid")
+        for t_ in (q, k, resid):
+            assert t_ is None or (t_.dtype == dt and t_.stride(1) == 1 and t_.data_ptr() % 16 == 0 and
+                                  (t_.stride(0) * t_.element_size()) % 16 == 0)
+        assert q.dtype == k.dtype == vt.dtype == dt
         # vt: [G*64, >= ceil32(Nk)] with unit column stride; a column block of a wider matrix is fine (16-B aligned)
         assert vt.stride(1) == 1 and vt.shape[1] >= (it["Nk"] + 31) // 32 * 32 and vt.data_ptr() % 16 == 0 and \
             (vt.stride(0) * vt.element_size()) % 16 == 0
@@ -457,8 +465,8 @@ def relation_attention_batched(items, groups=16):
             q, k, vt, pos, resid = it["q"], it["k"], it["vt"], it.get("pos"), it.get("resid")
             Nq, Nk = q.shape[0], it["Nk"]
             d.q, d.k, d.vt, d.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), outs[o + i].data_ptr()
-            d.ldq, d.ldk, d.ldv, d.ldo, d.Nq, d.Nk = q.shape[1], k.shape[1], vt.stride(0), groups * 64, Nq, Nk
-            d.resid, d.ldr = _ptr(resid), 0 if resid is None else resid.shape[1]
+            d.ldq, d.ldk, d.ldv, d.ldo, d.Nq, d.Nk = q.stride(0), k.stride(0), vt.stride(0), groups * 64, Nq, Nk
+            d.resid, d.ldr = _ptr(resid), 0 if resid is None else resid.stride(0)
             d.bias_v = _ptr(it.get("bias_v"))
             if pos is not None and pos.dtype == torch.bfloat16:
                 assert pos.is_contiguous() and tuple(pos.shape) == (groups, (Nk + 31) // 32, Nq, 32)

@@ -139,6 +139,55 @@ def test_roi_align(dev, dtype, layouts):
     assert _relerr(out, ref) < tol
 
 
+def test_roi_align_bf16_hot_shape(dev):
+    """The frame stage's ROIAlign as it runs in the benchmark: res5 maps of 2048 channels at 38 x 63, bf16, the
+    per-ROI separable kernel with XCD channel slicing -- against native_oracle.c (pinned to the compiled reference
+    csrc/cpu ROIAlign) on 640 ROIs over 4 images; and at the full launch size (6000 ROIs = 20 frames x 300) every ROI's
+    rows must equal the rows the same ROI gets in the small launch (block-independence: bit equality)."""
+    ops = _ops()
+    from oracle import native
+    g = torch.Generator().manual_seed(21)
+    B, C, H, W = 4, 2048, 38, 63
+    feat = torch.randn((B, H, W, C), generator=g).to(torch.bfloat16)
+    rois = _random_rois(g, 640, B, W * 16, H * 16)
+    rois[2] = torch.tensor([1, 0.0, 0.0, 15.9, 15.9])               # one cell
+    rois[3] = torch.tensor([2, 500.0, 0.0, 999.0, 599.0])           # right half, full height: grid 5 x 6
+    ref = torch.from_numpy(native.roi_align(feat.float().permute(0, 3, 1, 2).contiguous().numpy(), rois.numpy(), 1 / 16., 7, 7, 0))
+    out = ops.roi_align(feat.to(dev), rois.to(dev), 1 / 16., (7, 7), 0).float().cpu()           # [K,49,C]
+    got = out.view(-1, 7, 7, C).permute(0, 3, 1, 2)
+    err = (got - ref).abs()
+    print("roi_align bf16 C=2048: max |err| %.3g, rel %.3g" % (err.max(), _relerr(got, ref)))
+    assert _relerr(got, ref) < 1e-2 and err.max() < 0.08          # bf16 inputs, f32 sums, one bf16 rounding at the end
+    big = rois[torch.arange(6000) % 640].contiguous()
+    out6 = ops.roi_align(feat.to(dev), big.to(dev), 1 / 16., (7, 7), 0)
+    assert torch.equal(out6[:640].cpu().float(), out) and torch.equal(out6[5120:5760].cpu().float(), out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_roi_align_unclipped_rois_and_fixed_sampling_ratio(dev, dtype):
+    """the public op with ROIs the MEGA path never produces.  (a) boxes larger than the map /
+    partly outside it with the adaptive grid: grid = ceil(roi / 7) exceeds the separable kernel's 10-pixel patch
+    tables (it must fall back, not read past them); (b) sampling_ratio = 2 on a 200-wide map: a bin's two samples lie
+    bin_size / 2 apart, i.e. a sparse patch.  Both against the oracle."""
+    ops = _ops()
+    from oracle import native
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 64, 40, 200
+    feat = torch.randn((B, C, H, W), generator=g).to(dtype)
+    rois = torch.tensor([[0, -400.0, -300.0, 4000.0, 900.0],          # far larger than the 3200 x 640 image
+                         [1, 0.0, 0.0, 3199.0, 639.0],                # the whole map: grid 29 x 6
+                         [0, 2500.0, -200.0, 3600.0, 300.0],          # sticking out at the top right
+                         [1, -50.0, 100.0, 30.0, 500.0],
+                         [0, 100.0, 100.0, 400.0, 300.0]])
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    f_in = feat.permute(0, 2, 3, 1).contiguous().to(dev)
+    for ratio in (0, 2):
+        ref = torch.from_numpy(native.roi_align(feat.float().numpy(), rois.numpy(), 1 / 16., 7, 7, ratio))
+        out = ops.roi_align(f_in, rois.to(dev), 1 / 16., (7, 7), ratio).float().cpu().view(-1, 7, 7, C).permute(0, 3, 1, 2)
+        assert torch.isfinite(out).all()
+        assert _relerr(out, ref) < tol, (ratio, _relerr(out, ref))
+
+
 def test_nms_golden_and_random(dev):
     ops = _ops()
     from oracle import native
@@ -186,12 +235,18 @@ def test_rpn_select(dev, shape):
     im_w, im_h = Wf * 16 - 8, Hf * 16 - 8
     anchors = mo.grid_anchors(cell, Hf, Wf, 16)
     rpn_out = torch.cat([obj, reg], dim=1).permute(0, 2, 3, 1).reshape(B, Hf * Wf, 5 * A).contiguous()
-    props, scores, cnt = ops.rpn_select(rpn_out.to(dev), cell.to(dev), Hf, Wf, 16, pre, post, 0.7, 0, im_w, im_h, True)
-    props, scores, cnt = props.cpu(), scores.cpu(), cnt.cpu()
+    props, scores, cnt, index = ops.rpn_select(rpn_out.to(dev), cell.to(dev), Hf, Wf, 16, pre, post, 0.7, 0, im_w, im_h, True,
+                                               want_index=True)
+    props, scores, cnt, index = props.cpu(), scores.cpu(), cnt.cpu(), index.cpu()
+    p2, s2, c2 = ops.rpn_select(rpn_out.to(dev), cell.to(dev), Hf, Wf, 16, pre, post, 0.7, 0, im_w, im_h, True)
+    assert torch.equal(p2.cpu(), props) and torch.equal(s2.cpu(), scores) and torch.equal(c2.cpu(), cnt)
     for b in range(B):
-        wb, ws = mo.rpn_select(obj[b], reg[b], anchors, im_w, im_h, pre, post, 0.7, 0, True)
+        wb, ws, wi = mo.rpn_select(obj[b], reg[b], anchors, im_w, im_h, pre, post, 0.7, 0, True, want_index=True)
         n = int(cnt[b])
         assert n == wb.shape[0], "frame %d: kept %d vs oracle %d" % (b, n, wb.shape[0])
+        # the proposal INDICES after NMS, bit for bit (north_star), incl. the tie order (lower anchor index first)
+        assert torch.equal(index[b, :n].long(), wi), "frame %d: kept anchor indices differ" % b
+        assert (index[b, n:] == -1).all()
         assert (props[b, :n] - wb).abs().max() < 1e-3, (props[b, :n] - wb).abs().max()
         assert (scores[b, :n] - ws).abs().max() < 1e-6
         assert props[b, n:].abs().max() == 0 if n < post else True

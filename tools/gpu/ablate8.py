@@ -1,5 +1,12 @@
-"""Timing-only ablations of igemm8 on the RPN conv shape (256-row tile): where does the K-loop time go?"""
+"""Timing-only ablations of igemm8 on the RPN conv shape (256-row tile): where does the K-loop time go?
+
+The ablation / timeline variants are not in the product library: this script first rebuilds libmega_hip.so with
+MEGA_BUILD_EXPERIMENTS=1 (-DMEGA_EXPERIMENTS), runs, and rebuilds the product library afterwards (the GPU box has hipcc).
+"""
 import os, sys, subprocess
+_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_build = "import sys; sys.path.insert(0, %r); from mega.pytorch_amd import build; build.build(force=True)" % _root
+subprocess.run([sys.executable, "-c", _build], env=dict(os.environ, MEGA_BUILD_EXPERIMENTS="1"), check=True)
 code = r'''
 import sys, torch, os
 sys.path.insert(0, sys.argv[1])
@@ -23,3 +30,4 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for abl in ("0", "1", "2", "3", "4"):
     env = dict(os.environ, MEGA_IGEMM8_ABLATE=abl)
     subprocess.run([sys.executable, "-c", code, root], env=env)
+subprocess.run([sys.executable, "-c", _build], env={k: v for k, v in os.environ.items() if k != "MEGA_BUILD_EXPERIMENTS"}, check=True)
