@@ -213,6 +213,13 @@ int mega_fgfa_warp_aggregate(const void* feats, const float* flow, void* out, fl
 int mega_dff_warp_scale(const void* feats, const float* flow, const void* scale, void* out, int H, int W, int C,
                         int dtype, void* stream);
 
+/* Pool / key-set assembly of the batched relation aggregation: n block copies (rows x row_bytes bytes, independent
+ * source / destination row strides) in one launch -- replaces the reference's per-key-frame torch.cat of its pools
+ * (roi_box_feature_extractors.py:676,:687-688,:812-814; generalized_rcnn_mega.py:213-216).  segs = array of
+ *   struct { const void* src; void* dst; long long src_stride, dst_stride; int rows, row_bytes; }
+ * Destinations must not overlap; addresses / strides / row lengths 2-byte aligned at least.  Bit-exact data movement. */
+int mega_copy_segments(const void* segs, int n, void* stream);
+
 /* hipGetErrorString of the last launch failure any entry point of this library reported (MEGA_ERR_LAUNCH). */
 const char* mega_last_error_string(void);
 

@@ -1,0 +1,103 @@
+// Pool / key-set assembly for the relation aggregation: many small 2-D block copies in ONE launch.
+//
+// The reference re-concatenates its pools with torch.cat on every key frame (roi_box_feature_extractors.py:676,
+// :687-688, :812-814; detector/generalized_rcnn_mega.py:213-216).  The batched aggregation lays the windows, memory pools
+// and key sets of a whole step-batch out as a few "tapes" -- but each tape was still one torch.cat launch (53 per
+// step-batch, 5-8 us of GPU time each, the largest launch family of the aggregation).  Here every concatenation is a
+// list of (source block -> destination block) segments, and all segments of all concatenations that do not depend on
+// each other travel in one kernel argument: one launch instead of 3-6.
+//
+// A segment is a [rows][row_bytes] byte block with independent source / destination row strides, so both row
+// concatenation (dim 0) and column concatenation (dim 1: the key-contiguous V^T blocks, whose 150-byte rows are only
+// 2-byte aligned) are the same thing.  The copy width (16 / 8 / 4 / 2 bytes per thread) is the largest that divides
+// every segment's addresses, strides and row length; pure data movement, bit-exact by construction.
+#include "common.h"
+
+namespace {
+
+constexpr int COPY_MAXSEG = 56;
+
+struct CopySeg {
+  const unsigned char* src;
+  unsigned char* dst;
+  long long src_stride, dst_stride;   // bytes
+  int rows, units_per_row;            // units of W bytes
+};
+struct CopyBatch {
+  int n;
+  unsigned ubase[COPY_MAXSEG + 1];    // first unit of each segment in the launch's flat unit index
+  CopySeg s[COPY_MAXSEG];
+};
+
+template <typename V>
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopyBatch b) {
+  const unsigned total = b.ubase[b.n];
+  for (unsigned unit = blockIdx.x * 256u + threadIdx.x; unit < total; unit += gridDim.x * 256u) {
+    int lo = 0, hi = b.n;               // segment of this unit: ubase[lo] <= unit < ubase[lo + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (b.ubase[mid] <= unit) lo = mid; else hi = mid;
+    }
+    const CopySeg& s = b.s[lo];
+    const unsigned u = unit - b.ubase[lo];
+    const unsigned r = u / (unsigned)s.units_per_row, c = u - r * (unsigned)s.units_per_row;
+    *reinterpret_cast<V*>(s.dst + (long long)r * s.dst_stride + (size_t)c * sizeof(V)) =
+        *reinterpret_cast<const V*>(s.src + (long long)r * s.src_stride + (size_t)c * sizeof(V));
+  }
+}
+
+}  // namespace
+
+struct MegaCopySegC {
+  const void* src; void* dst; long long src_stride, dst_stride; int rows, row_bytes;
+};
+
+// segs[n]: copy rows x row_bytes bytes from src (+ r * src_stride) to dst (+ r * dst_stride).  Segments must not
+// overlap each other's destinations.  Any n (launched in groups of 56 segments).
+extern "C" int mega_copy_segments(const void* segs, int n, void* stream) {
+  mega_clear_error();
+  if (n == 0) return MEGA_OK;
+  if (!segs || n < 0) return MEGA_ERR_ARG;
+  const MegaCopySegC* d = (const MegaCopySegC*)segs;
+  hipStream_t st = (hipStream_t)stream;
+  for (int o = 0; o < n; o += COPY_MAXSEG) {
+    const int m = n - o < COPY_MAXSEG ? n - o : COPY_MAXSEG;
+    unsigned long long align = 16;
+    for (int i = 0; i < m; ++i) {
+      const MegaCopySegC& g = d[o + i];
+      if (g.rows < 0 || g.row_bytes < 0 || (g.rows > 0 && g.row_bytes > 0 && (!g.src || !g.dst))) return MEGA_ERR_ARG;
+      if (g.rows == 0 || g.row_bytes == 0) continue;
+      unsigned long long bits = (unsigned long long)(size_t)g.src | (unsigned long long)(size_t)g.dst |
+                                (unsigned long long)g.row_bytes;
+      if (g.rows > 1) bits |= (unsigned long long)g.src_stride | (unsigned long long)g.dst_stride;
+      while (align > 1 && (bits & (align - 1))) align >>= 1;
+    }
+    if (align < 2) return MEGA_ERR_ARG;   // (every tensor this serves is bf16 / f32 / i32: 2-byte granularity at worst)
+    CopyBatch b;
+    b.n = 0;
+    unsigned long long units = 0;
+    for (int i = 0; i < m; ++i) {
+      const MegaCopySegC& g = d[o + i];
+      if (g.rows == 0 || g.row_bytes == 0) continue;
+      CopySeg& s = b.s[b.n];
+      s.src = (const unsigned char*)g.src; s.dst = (unsigned char*)g.dst;
+      s.src_stride = g.src_stride; s.dst_stride = g.dst_stride;
+      s.rows = g.rows; s.units_per_row = (int)(g.row_bytes / align);
+      b.ubase[b.n] = (unsigned)units;
+      units += (unsigned long long)s.rows * s.units_per_row;
+      if (units >= 0xFFFFFFFFull) return MEGA_ERR_ARG;
+      ++b.n;
+    }
+    if (b.n == 0) continue;
+    b.ubase[b.n] = (unsigned)units;
+    unsigned long long nb = (units + 1023) / 1024;        // ~4 units per thread
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    const dim3 grid((unsigned)nb);
+    if (align == 16) hipLaunchKernelGGL((copy_segments_kernel<uint4>), grid, dim3(256), 0, st, b);
+    else if (align == 8) hipLaunchKernelGGL((copy_segments_kernel<uint2>), grid, dim3(256), 0, st, b);
+    else if (align == 4) hipLaunchKernelGGL((copy_segments_kernel<unsigned>), grid, dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((copy_segments_kernel<unsigned short>), grid, dim3(256), 0, st, b);
+  }
+  return mega_check_launch();
+}

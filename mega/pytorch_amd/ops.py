@@ -485,6 +485,58 @@ def relation_attention_batched(items, groups=16):
     return outs
 
 
+class _CopySeg(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("src_stride", ctypes.c_longlong),
+                ("dst_stride", ctypes.c_longlong), ("rows", ctypes.c_int), ("row_bytes", ctypes.c_int)]
+
+
+def copy_blocks(pairs):
+    """[(dst, src)]: 2-D tensors of equal shape / dtype with unit column stride (row / column blocks of wider buffers
+    are fine) -> all copies in ONE launch (mega_copy_segments)."""
+    pairs = [(d, s_) for d, s_ in pairs if d.numel() > 0]
+    if not pairs:
+        return
+    lib = _lib.load()
+    arr = (_CopySeg * len(pairs))()
+    nbytes = 0
+    for i, (d, s_) in enumerate(pairs):
+        _gpu(d, s_)
+        assert d.dim() == 2 and d.shape == s_.shape and d.dtype == s_.dtype, (d.shape, s_.shape, d.dtype, s_.dtype)
+        assert (d.shape[1] == 1 or (d.stride(1) == 1 and s_.stride(1) == 1))
+        es = d.element_size()
+        arr[i].src, arr[i].dst = s_.data_ptr(), d.data_ptr()
+        arr[i].src_stride, arr[i].dst_stride = s_.stride(0) * es, d.stride(0) * es
+        arr[i].rows, arr[i].row_bytes = d.shape[0], d.shape[1] * es
+        nbytes += 2 * d.numel() * es
+    _tok = _pb("assemble", 0.0, nbytes)
+    rc = lib.mega_copy_segments(ctypes.addressof(arr), len(pairs), _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_copy_segments")
+
+
+def multi_cat(groups):
+    """Several independent torch.cat calls as ONE launch: groups = [(pieces, dim)], pieces = 2-D tensors (same dtype and
+    device, unit column stride, equal sizes along the other dimension) -> [torch.cat(pieces, dim) for each group], same
+    bits.  The concatenations must not depend on each other's results."""
+    outs, pairs = [], []
+    for pieces, dim in groups:
+        pieces = list(pieces)
+        p0 = pieces[0]
+        if dim == 0:
+            out = torch.empty((sum(p.shape[0] for p in pieces), p0.shape[1]), dtype=p0.dtype, device=p0.device)
+        else:
+            out = torch.empty((p0.shape[0], sum(p.shape[1] for p in pieces)), dtype=p0.dtype, device=p0.device)
+        o = 0
+        for p in pieces:
+            assert p.dtype == p0.dtype and p.shape[1 - dim] == p0.shape[1 - dim]
+            n = p.shape[dim]
+            pairs.append((out.narrow(dim, o, n), p))
+            o += n
+        outs.append(out)
+    copy_blocks(pairs)
+    return outs
+
+
 def resize_bilinear_u8(frames_u8, out_hw, tables):
     """uint8 [N,Hi,Wi,3] -> [N,Ho,Wo,3], Pillow-exact BILINEAR.  tables = feed.ResizeTables (device coefficient tables)."""
     _gpu(frames_u8)

@@ -394,15 +394,15 @@ def test_bench_default_steps_per_batch():
     spec.loader.exec_module(bench)
     f, kf = bench.default_steps_per_batch, bench.key_frames_per_block
     # a step is `world` key frames: a block of --steps steps covers steps x world key frames, and the default step-batch
-    # is 10 key frames per rank whenever --steps is a multiple of 10 (a rank's frame-stage launch keeps its 20 frames)
+    # is 20 key frames per rank whenever --steps is a multiple of 20 (a rank's frame-stage launch keeps its 40 frames)
     assert [kf(20, w) for w in (1, 2, 4, 8)] == [20, 40, 80, 160]
-    assert [f(20, w) for w in (1, 2, 4, 8)] == [10, 20, 40, 80]
-    assert [f(100, w) for w in (1, 2, 8)] == [10, 20, 80]
-    assert [f(48, w) for w in (1, 2, 4, 8)] == [8, 16, 32, 64]        # 48 = 6 x 8: 8 key frames per rank
+    assert [f(20, w) for w in (1, 2, 4, 8)] == [20, 40, 80, 160]
+    assert [f(100, w) for w in (1, 2, 8)] == [20, 40, 160]
+    assert [f(48, w) for w in (1, 2, 4, 8)] == [16, 32, 64, 128]      # 48 = 3 x 16: 16 key frames per rank
     assert f(7, 1) == 7 and f(7, 2) == 14
     for steps in (5, 20, 48):
         for w in (1, 2, 4, 8):
-            assert kf(steps, w) % f(steps, w) == 0 and f(steps, w) <= 10 * w
+            assert kf(steps, w) % f(steps, w) == 0 and f(steps, w) <= 20 * w
 
 
 def test_cat_rows_is_free_for_consecutive_row_blocks():
