@@ -241,7 +241,20 @@ def cpu_baseline(arch, sd, H, W, n_timed):
     mem = [len(q["rois"]) for q in orc.mem_queue]
     steady = times[fill:]
     fps = len(steady) / sum(steady)
+    # The unmodified reference cannot run on the GPU box (/root/reference is not there), so the timed thing is the port;
+    # how the port compares with the reference on the SAME host cores was measured in the build container
+    # (tools/cpu_port_vs_reference.py) and is quoted from the committed record.
+    vs_ref = None
+    rec = os.path.join(ROOT, "profiles", "r03_cpu_port_vs_reference.json")
+    if os.path.exists(rec) and not r50:
+        r = json.load(open(rec))
+        ratio = r["mega_r101"]["port_over_reference_time"]
+        vs_ref = {"port_over_reference_time": ratio, "reference_equivalent_frames_per_s": round(fps * ratio, 4),
+                  "measured": "build container, %d threads: reference %.2f s / port %.2f s per steady key frame"
+                              % (r["host_threads"], r["mega_r101"]["reference_steady_s"], r["mega_r101"]["port_steady_s"]),
+                  "source": "profiles/r03_cpu_port_vs_reference.json"}
     return {"value": round(fps, 4), "unit": "frames/s", "cores": cores, "kind": "port", "memory_frames": min(mem),
+            "vs_unmodified_reference": vs_ref,
             "sample": "oracle/mega_oracle.py (torch-CPU fp32 restatement of the reference path), same weights and "
                       "frame size: %d steady key frames timed (%.2f s each) AFTER an untimed fill of %d key frames "
                       "(cold start %.1f s + %.1f s) that leaves all memory deques full (%s of 25)"

@@ -10,6 +10,8 @@
 // flow [T][2][H][W] f32 (x displacement, y displacement, in feature-map pixels), out [H][W][Cf].
 // One workgroup per output pixel; a wave reads 64 consecutive 16-byte channel vectors of one neighbour pixel
 // (1 KiB, fully coalesced); the T warped feature vectors wait in LDS (T*Cf f32 <= 128 KiB) for the softmax.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -116,6 +118,168 @@ __global__ __launch_bounds__(256) void fgfa_kernel(const T* __restrict__ feats, 
 }
 
 
+// Two-pass form of the same computation (round 3).  fgfa_kernel above walks the T frames one after the other with two
+// block-wide reductions each: a chain of 21 dependent (gather -> barrier -> barrier) steps per pixel, one block per CU
+// (94 KB of LDS): 588 GB/s.  Here nothing waits on a block barrier inside the frame loops:
+//   pass 1  the 4 waves take the frames round-robin; a wave gathers one frame's warped EMBEDDING (Ce channels, 16 loads
+//           per lane in flight), reduces dot / norm with shuffles and writes that frame's cosine weight;
+//   pass 2  thread (frame group g, channel vector v) accumulates sum_t w_t * warp_t(features)[v] over its frames with
+//           the taps of two frames in flight; the groups' partial sums meet in LDS.
+// 12 KB of LDS -> 8 blocks per CU hide the gather latency; blocks are dealt to the XCDs in contiguous pixel bands so
+// that an XCD's L2 only ever holds its own band (+ the flow-displaced halo) of the T feature maps.
+template <typename T>
+__global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats, const float* __restrict__ flow,
+                                                    T* __restrict__ out, float* __restrict__ weights_out, int NT,
+                                                    int H, int W, int Cf, int Ce, int key) {
+  constexpr int VE = Elem<T>::VE;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* cur = lds;                 // [Ce]  key frame's warped embedding
+  float* part = lds + Ce;           // [G - 1][Cf] partial sums of frame groups 1..G-1
+  __shared__ float red[4];
+  __shared__ float wts[64];
+  const int C = Cf + Ce;
+  const int fvec = Cf / VE, evec = Ce / VE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int pix;
+  {                                 // XCD-aware block -> pixel map (bijective): XCD x owns a contiguous band of pixels
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    pix = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int px = pix % W, py = pix / W;
+
+  struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
+  auto taps = [&](int t) {
+    const float fx = flow[((size_t)t * 2 + 0) * H * W + py * W + px];
+    const float fy = flow[((size_t)t * 2 + 1) * H * W + py * W + px];
+    const float gx = ((float)px + fx) / ((float)(W - 1) / 2.f) - 1.f;   // :55-58
+    const float gy = ((float)py + fy) / ((float)(H - 1) / 2.f) - 1.f;
+    float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;                      // unnormalise, align_corners = False
+    float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));                          // padding_mode = border
+    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    const float flx = floorf(ix), fly = floorf(iy);
+    const int x0 = (int)flx, y0 = (int)fly, x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float wx = ix - flx, wy = iy - fly;
+    Taps tp;
+    tp.o00 = (y0 * W + x0) * C; tp.o01 = (y0 * W + x1) * C; tp.o10 = (y1 * W + x0) * C; tp.o11 = (y1 * W + x1) * C;
+    tp.w00 = (1.f - wx) * (1.f - wy); tp.w01 = wx * (1.f - wy); tp.w10 = (1.f - wx) * wy; tp.w11 = wx * wy;
+    return tp;
+  };
+  auto blend = [&](const Taps& tp, const uint4& a, const uint4& b, const uint4& c, const uint4& d, float (&val)[VE]) {
+    const T* ea = reinterpret_cast<const T*>(&a); const T* eb = reinterpret_cast<const T*>(&b);
+    const T* ec = reinterpret_cast<const T*>(&c); const T* ed = reinterpret_cast<const T*>(&d);
+#pragma unroll
+    for (int e = 0; e < VE; ++e)
+      val[e] = tp.w00 * Elem<T>::ld(ea + e) + tp.w01 * Elem<T>::ld(eb + e) + tp.w10 * Elem<T>::ld(ec + e) +
+               tp.w11 * Elem<T>::ld(ed + e);
+  };
+
+  // ---- A. the key frame's warped embedding (all 256 threads) and its norm
+  {
+    const Taps tp = taps(key);
+    const T* base = feats + (size_t)key * H * W * C + Cf;
+    float n2 = 0.f;
+    for (int v = tid; v < evec; v += 256) {
+      const T* p = base + (size_t)v * VE;
+      const uint4 a = *reinterpret_cast<const uint4*>(p + tp.o00), b = *reinterpret_cast<const uint4*>(p + tp.o01);
+      const uint4 c = *reinterpret_cast<const uint4*>(p + tp.o10), d = *reinterpret_cast<const uint4*>(p + tp.o11);
+      float val[VE];
+      blend(tp, a, b, c, d, val);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { cur[v * VE + e] = val[e]; n2 += val[e] * val[e]; }
+    }
+    const float tot = block_sum_256(n2, red);          // (ends with a barrier: cur[] is visible to every wave)
+    if (tid == 0) wts[63] = sqrtf(tot) + 1e-10f;       // compute_norm :64-65
+  }
+  __syncthreads();
+  const float cur_norm = wts[63];
+
+  // ---- B. cosine weights: wave w takes frames w, w + 4, ...; no block barrier inside
+  for (int t = wave; t < NT; t += 4) {
+    const Taps tp = taps(t);
+    const T* base = feats + (size_t)t * H * W * C + Cf;
+    float dot = 0.f, nn = 0.f;
+    for (int v0 = 0; v0 < evec; v0 += 256) {           // 4 vectors per lane per round: 16 loads in flight
+      uint4 a[4], b[4], c[4], d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = min(v0 + j * 64 + lane, evec - 1);
+        const T* p = base + (size_t)v * VE;
+        a[j] = *reinterpret_cast<const uint4*>(p + tp.o00); b[j] = *reinterpret_cast<const uint4*>(p + tp.o01);
+        c[j] = *reinterpret_cast<const uint4*>(p + tp.o10); d[j] = *reinterpret_cast<const uint4*>(p + tp.o11);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = v0 + j * 64 + lane;
+        if (v < evec) {
+          float val[VE];
+          blend(tp, a[j], b[j], c[j], d[j], val);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) { dot += val[e] * cur[v * VE + e]; nn += val[e] * val[e]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dot += __shfl_xor(dot, o); nn += __shfl_xor(nn, o); }
+    if (lane == 0) wts[t] = dot / ((sqrtf(nn) + 1e-10f) * cur_norm);       // compute_weight :67-76
+  }
+  __syncthreads();
+  // ---- C. softmax over frames (:209)
+  if (tid == 0) {
+    float m = -INFINITY, s2 = 0.f;
+    for (int t = 0; t < NT; ++t) m = fmaxf(m, wts[t]);
+    for (int t = 0; t < NT; ++t) { wts[t] = expf(wts[t] - m); s2 += wts[t]; }
+    for (int t = 0; t < NT; ++t) wts[t] /= s2;
+  }
+  __syncthreads();
+  if (weights_out && tid < NT) weights_out[((size_t)tid * H + py) * W + px] = wts[tid];
+  // ---- D. the weighted sum (:211): thread (group g, vector v) over frames g, g + G, ..., two frames in flight
+  const int G = 256 / fvec;                            // host guarantees fvec <= 256 and 256 % fvec == 0
+  const int g = tid / fvec, v = tid - g * fvec;
+  float acc[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+  for (int t = g; t < NT; t += 2 * G) {
+    const int t2 = t + G;
+    const bool has2 = t2 < NT;
+    const Taps tp = taps(t), tq = taps(has2 ? t2 : t);
+    const T* p = feats + (size_t)t * H * W * C + (size_t)v * VE;
+    const T* q2 = feats + (size_t)(has2 ? t2 : t) * H * W * C + (size_t)v * VE;
+    const uint4 a = *reinterpret_cast<const uint4*>(p + tp.o00), b = *reinterpret_cast<const uint4*>(p + tp.o01);
+    const uint4 c = *reinterpret_cast<const uint4*>(p + tp.o10), d = *reinterpret_cast<const uint4*>(p + tp.o11);
+    const uint4 a2 = *reinterpret_cast<const uint4*>(q2 + tq.o00), b2 = *reinterpret_cast<const uint4*>(q2 + tq.o01);
+    const uint4 c2 = *reinterpret_cast<const uint4*>(q2 + tq.o10), d2 = *reinterpret_cast<const uint4*>(q2 + tq.o11);
+    float val[VE];
+    blend(tp, a, b, c, d, val);
+    const float w1 = wts[t];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] += w1 * val[e];
+    if (has2) {
+      blend(tq, a2, b2, c2, d2, val);
+      const float w2 = wts[t2];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] += w2 * val[e];
+    }
+  }
+  if (g > 0) {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) part[(size_t)(g - 1) * Cf + v * VE + e] = acc[e];
+  }
+  __syncthreads();
+  if (g == 0) {
+    for (int gg = 1; gg < G; ++gg)
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] += part[(size_t)(gg - 1) * Cf + v * VE + e];
+    uint4 o;
+    T* oe = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e]);
+    *reinterpret_cast<uint4*>(out + ((size_t)py * W + px) * Cf + (size_t)v * VE) = o;
+  }
+}
+
+
 // DFF (generalized_rcnn_dff.py:41-60,:132-135): out = grid_sample(key_feats, flow grid, bilinear, border) * scale_map.
 // One thread per (pixel, 16-byte channel vector): pure gather + multiply, HBM/L2-bound.
 template <typename T>
@@ -188,9 +352,23 @@ extern "C" int mega_fgfa_warp_aggregate(const void* feats, const float* flow, vo
     return MEGA_ERR_ARG;
   const int ve = dtype == MEGA_BF16 ? 8 : 4;
   if (Cf % ve || Ce % ve) return MEGA_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  static const bool legacy = getenv("MEGA_FGFA_LEGACY") != nullptr;      // A/B switch: the one-pass kernel of rounds 1-2
+  const int fvec = Cf / ve;
+  if (!legacy && fvec <= 256 && 256 % fvec == 0 && T < 63 && (size_t)H * W * (Cf + Ce) < 0x7FFFFFFFull) {
+    const size_t smem2 = ((size_t)Ce + (size_t)(256 / fvec - 1) * Cf) * sizeof(float);
+    if (dtype == MEGA_BF16)
+      hipLaunchKernelGGL((fgfa2_kernel<bf16_t>), dim3(H * W), dim3(256), smem2, st, (const bf16_t*)feats, flow,
+                         (bf16_t*)out, weights_out, T, H, W, Cf, Ce, key);
+    else if (dtype == MEGA_F32)
+      hipLaunchKernelGGL((fgfa2_kernel<float>), dim3(H * W), dim3(256), smem2, st, (const float*)feats, flow,
+                         (float*)out, weights_out, T, H, W, Cf, Ce, key);
+    else
+      return MEGA_ERR_ARG;
+    return mega_check_launch();
+  }
   const size_t smem = ((size_t)Ce + (size_t)T * Cf) * sizeof(float);
   if (smem > 150 * 1024) return MEGA_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
   if (dtype == MEGA_BF16) {
     (void)hipFuncSetAttribute((const void*)fgfa_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((fgfa_kernel<bf16_t>), dim3(H * W), dim3(256), smem, st, (const bf16_t*)feats, flow,

@@ -78,7 +78,34 @@ def config1(args, dev):
         step(i)
     med, blocks = timed(step, args.steps)
     fam, _ = families(ops, lambda: [step(i) for i in range(4)], 4)
+    cpu = None
+    if not args.no_cpu_baseline:
+        # BASELINE configs[0] IS the CPU reference run: the port (oracle BaseOracle = the reference's GeneralizedRCNN
+        # restated on torch-CPU) timed on this box's host cores, next to the unmodified reference's time measured in the
+        # build container (profiles/r03_cpu_port_vs_reference.json; /root/reference does not exist here)
+        import time as _t
+        from oracle import mega_oracle as mo
+        cores = min(len(os.sched_getaffinity(0)), 64)
+        torch.set_num_threads(cores)
+        orc = mo.BaseOracle({k: v.cpu() for k, v in sd.items()}, mo.OracleCfg(blocks=(3, 4, 6), reduce_channel=True,
+                                                                              nms_strict_gt=False))
+        frames = synth.preprocess_cpu(clip[:4].cpu())
+        ts = []
+        for i in range(4):
+            t0 = _t.perf_counter()
+            orc.forward_frame(frames[i:i + 1])
+            ts.append(_t.perf_counter() - t0)
+        s_frame = sum(ts[1:]) / 3
+        cpu = {"value": round(1.0 / s_frame, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "oracle BaseOracle, 3 frames of %dx%d after one warm-up frame (%.2f s each)" % (args.width, args.height, s_frame)}
+        rec = os.path.join(ROOT, "profiles", "r03_cpu_port_vs_reference.json")
+        if os.path.exists(rec):
+            r = json.load(open(rec))["config1_single_frame_r50"]
+            cpu["vs_unmodified_reference"] = {"port_over_reference_time": r["port_over_reference_time"],
+                                              "reference_fps_build_container": r["reference_fps"],
+                                              "source": "profiles/r03_cpu_port_vs_reference.json"}
     return {"metric": "frames/sec single-frame R-50-C4 detector, %dx%d frames" % (args.width, args.height),
+            "cpu_baseline": cpu,
             "value": round(args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(1e3 * med / args.steps, 3),
             "config": {"workload": "GeneralizedRCNN R-50-C4 + ResNetConv52MLPFeatureExtractor, 300 proposals, one frame "
                                    "per call with a host read of the detection count (BASELINE configs[0])"},
@@ -195,6 +222,7 @@ def main():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     json_fd = os.dup(1)
     os.dup2(2, 1)

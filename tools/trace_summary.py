@@ -1,5 +1,6 @@
 """Per-kernel busy time of the LAST step-batch in a tools/gpu/trace.sh timeline (no-overlap run: the tail of the stream is
-F(last batch), B(previous batch), B(last batch)).  usage: python tools/trace_summary.py gpurun_out/<tag>/tail.csv"""
+F(last batch), B(previous batch), B(last batch); a step-batch there = 20 key frames = 40 frames).
+usage: python tools/trace_summary.py gpurun_out/<tag>/tail.csv"""
 import csv
 import re
 import sys
