@@ -232,12 +232,20 @@ __device__ __forceinline__ void pos_logits_tiled_body(const float4* __restrict__
   for (int i = 0; i < 8; ++i) crev[i] = (100.0f * 0.15915494309189535f) / dim_mat[i];
   const float bias = bg[row];
   const float shift = (g & 1) ? 0.25f : 0.f;        // odd k-groups hold cosines
-#pragma unroll 1
+  // The wave's 8 MFMA tiles use 2 queries (ql = 2 wave + {0, 1}) and 4 key groups of 16: their boxes are requested up
+  // front, all six loads in flight at once (round 2 loaded them inside the tile loop: eight dependent memory round
+  // trips per block made the kernel latency-bound -- 1.8 TB/s of logits written -- whatever the VALU count).
+  float4 bqs[2], bks[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bqs[j] = rois_q[min(q0 + 2 * wave + j, Nq - 1)];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bks[j] = rois_k[min(k00 + j * 16 + row, Nk - 1)];
+#pragma unroll
   for (int tile = 0; tile < 8; ++tile) {
     const int ql = 2 * wave + (tile >> 2);
     const int kb = (tile & 3) * 16;
-    const float4 bq = rois_q[min(q0 + ql, Nq - 1)];
-    const float4 bk = rois_k[min(k00 + kb + row, Nk - 1)];
+    const float4 bq = bqs[tile >> 2];
+    const float4 bk = bks[tile & 3];
     const float wq = bq.z - bq.x + 1.f, hq = bq.w - bq.y + 1.f;
     const float cxq = 0.5f * (bq.x + bq.z), cyq = 0.5f * (bq.y + bq.w);
     const float wk = bk.z - bk.x + 1.f, hk = bk.w - bk.y + 1.f;

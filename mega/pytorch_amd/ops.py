@@ -389,6 +389,13 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     return out
 
 
+def _even_chunks(n, cap):
+    """problems per launch when n problems go out in launches of at most `cap`: as even as possible (20 -> 10 + 10, not
+    16 + 4: a 4-problem launch leaves most of the chip idle)"""
+    launches = -(-n // cap)
+    return -(-n // launches) if launches else cap
+
+
 class _AttnDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("q", "k", "vt", "pos", "pos_tiled", "resid", "bias_v", "out", "ws")] + \
                [("ws_bytes", ctypes.c_size_t)] + \
@@ -412,8 +419,9 @@ def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, t
         a, b = a.contiguous(), b.contiguous()
         keep.append((a, b))
         outs.append(torch.empty((16, (b.shape[0] + 31) // 32, a.shape[0], 32), dtype=torch.bfloat16, device=a.device))
-    for o in range(0, len(outs), 16):
-        n = min(16, len(outs) - o)
+    per = _even_chunks(len(outs), 16)
+    for o in range(0, len(outs), per):
+        n = min(per, len(outs) - o)
         arr = (_PosDesc * n)()
         for i in range(n):
             a, b = keep[o + i]
@@ -456,8 +464,9 @@ def relation_attention_batched(items, groups=16):
         o += q.shape[0]
         nb = lib.mega_relation_attention_workspace_bytes(q.shape[0], it["Nk"], groups)
         wss.append(_ws(nb, q.device) if nb else None)
-    for o in range(0, len(items), 16):
-        n = min(16, len(items) - o)
+    per = _even_chunks(len(items), 16)
+    for o in range(0, len(items), per):
+        n = min(per, len(items) - o)
         arr = (_AttnDesc * n)()
         fl = by = 0.0
         for i in range(n):
