@@ -60,44 +60,53 @@ extern "C" int mega_copy_segments(const void* segs, int n, void* stream) {
   if (!segs || n < 0) return MEGA_ERR_ARG;
   const MegaCopySegC* d = (const MegaCopySegC*)segs;
   hipStream_t st = (hipStream_t)stream;
-  for (int o = 0; o < n; o += COPY_MAXSEG) {
-    const int m = n - o < COPY_MAXSEG ? n - o : COPY_MAXSEG;
-    unsigned long long align = 16;
-    for (int i = 0; i < m; ++i) {
-      const MegaCopySegC& g = d[o + i];
-      if (g.rows < 0 || g.row_bytes < 0 || (g.rows > 0 && g.row_bytes > 0 && (!g.src || !g.dst))) return MEGA_ERR_ARG;
-      if (g.rows == 0 || g.row_bytes == 0) continue;
-      unsigned long long bits = (unsigned long long)(size_t)g.src | (unsigned long long)(size_t)g.dst |
-                                (unsigned long long)g.row_bytes;
-      if (g.rows > 1) bits |= (unsigned long long)g.src_stride | (unsigned long long)g.dst_stride;
-      while (align > 1 && (bits & (align - 1))) align >>= 1;
-    }
-    if (align < 2) return MEGA_ERR_ARG;   // (every tensor this serves is bf16 / f32 / i32: 2-byte granularity at worst)
+  auto seg_align = [](const MegaCopySegC& g) -> unsigned long long {
+    unsigned long long bits = (unsigned long long)(size_t)g.src | (unsigned long long)(size_t)g.dst |
+                              (unsigned long long)g.row_bytes;
+    if (g.rows > 1) bits |= (unsigned long long)g.src_stride | (unsigned long long)g.dst_stride;
+    unsigned long long a = 16;
+    while (a > 1 && (bits & (a - 1))) a >>= 1;
+    return a;
+  };
+  for (int i = 0; i < n; ++i) {
+    const MegaCopySegC& g = d[i];
+    if (g.rows < 0 || g.row_bytes < 0 || (g.rows > 0 && g.row_bytes > 0 && (!g.src || !g.dst))) return MEGA_ERR_ARG;
+    if (g.rows > 0 && g.row_bytes > 0 && seg_align(g) < 2) return MEGA_ERR_ARG;   // (bf16 / f32 / i32 data: >= 2 bytes)
+  }
+  // one launch per copy width that occurs (a 2-byte-aligned V^T column block must not drag the 16-byte-aligned row
+  // blocks of the same call down to 2 bytes per thread), in groups of COPY_MAXSEG segments
+  for (unsigned long long align = 16; align >= 2; align >>= 1) {
     CopyBatch b;
     b.n = 0;
     unsigned long long units = 0;
-    for (int i = 0; i < m; ++i) {
-      const MegaCopySegC& g = d[o + i];
-      if (g.rows == 0 || g.row_bytes == 0) continue;
-      CopySeg& s = b.s[b.n];
-      s.src = (const unsigned char*)g.src; s.dst = (unsigned char*)g.dst;
-      s.src_stride = g.src_stride; s.dst_stride = g.dst_stride;
-      s.rows = g.rows; s.units_per_row = (int)(g.row_bytes / align);
+    auto flush = [&]() {
+      if (b.n == 0) return;
       b.ubase[b.n] = (unsigned)units;
-      units += (unsigned long long)s.rows * s.units_per_row;
-      if (units >= 0xFFFFFFFFull) return MEGA_ERR_ARG;
+      unsigned long long nb = (units + 1023) / 1024;        // ~4 units per thread
+      if (nb > 2048) nb = 2048;
+      const dim3 grid((unsigned)(nb < 1 ? 1 : nb));
+      if (align == 16) hipLaunchKernelGGL((copy_segments_kernel<uint4>), grid, dim3(256), 0, st, b);
+      else if (align == 8) hipLaunchKernelGGL((copy_segments_kernel<uint2>), grid, dim3(256), 0, st, b);
+      else if (align == 4) hipLaunchKernelGGL((copy_segments_kernel<unsigned>), grid, dim3(256), 0, st, b);
+      else hipLaunchKernelGGL((copy_segments_kernel<unsigned short>), grid, dim3(256), 0, st, b);
+      b.n = 0;
+      units = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      const MegaCopySegC& g = d[i];
+      if (g.rows == 0 || g.row_bytes == 0 || seg_align(g) != align) continue;
+      const unsigned long long u = (unsigned long long)g.rows * (unsigned long long)(g.row_bytes / align);
+      if (u >= 0xFFFFFFFFull) return MEGA_ERR_ARG;
+      if (b.n == COPY_MAXSEG || units + u >= 0xFFFFFFFFull) flush();
+      CopySeg& sg = b.s[b.n];
+      sg.src = (const unsigned char*)g.src; sg.dst = (unsigned char*)g.dst;
+      sg.src_stride = g.src_stride; sg.dst_stride = g.dst_stride;
+      sg.rows = g.rows; sg.units_per_row = (int)(g.row_bytes / align);
+      b.ubase[b.n] = (unsigned)units;
+      units += u;
       ++b.n;
     }
-    if (b.n == 0) continue;
-    b.ubase[b.n] = (unsigned)units;
-    unsigned long long nb = (units + 1023) / 1024;        // ~4 units per thread
-    if (nb > 2048) nb = 2048;
-    if (nb < 1) nb = 1;
-    const dim3 grid((unsigned)nb);
-    if (align == 16) hipLaunchKernelGGL((copy_segments_kernel<uint4>), grid, dim3(256), 0, st, b);
-    else if (align == 8) hipLaunchKernelGGL((copy_segments_kernel<uint2>), grid, dim3(256), 0, st, b);
-    else if (align == 4) hipLaunchKernelGGL((copy_segments_kernel<unsigned>), grid, dim3(256), 0, st, b);
-    else hipLaunchKernelGGL((copy_segments_kernel<unsigned short>), grid, dim3(256), 0, st, b);
+    flush();
   }
   return mega_check_launch();
 }

@@ -730,11 +730,13 @@ extern "C" int mega_position_logits_tiled(const float* rois_q, const float* rois
 }
 
 // Number of key-range splits the attention core uses for (Nq, Nk) -- a function of the problem alone, so a problem
-// gets the same bits in a single launch and inside a batched launch.  The engine batches ~10 problems per launch, so a
-// problem only needs ~1 block per CU of its own (MEGA_ATTN_BLOCKS, default 256; round 1 used 768 for single launches).
+// gets the same bits in a single launch and inside a batched launch.  The engine batches 10-20 problems per launch
+// (>= 480 blocks without any split), so a problem only asks for MEGA_ATTN_BLOCKS = 48 blocks of its own: no MEGA shape
+// (Nq >= 300: 3 x 16 blocks) splits any more, and the partial-sum round trip + combine launch (0.21 ms per 10 key
+// frames, +1.3 % FPS measured with the splits off) disappears.  Round 1 used 768 for single launches, round 2 256.
 extern "C" int mega_relation_attention_splits(int Nq, int Nk, int groups) {
   if (Nq <= 0 || Nk <= 0 || groups <= 0) return 1;
-  static const int target = getenv("MEGA_ATTN_BLOCKS") ? atoi(getenv("MEGA_ATTN_BLOCKS")) : 256;
+  static const int target = getenv("MEGA_ATTN_BLOCKS") ? atoi(getenv("MEGA_ATTN_BLOCKS")) : 48;
   const int blocks = cdiv(Nq, 128) * groups;
   const int ntiles = cdiv(Nk, 32);
   int s = cdiv(target, blocks);

@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .relation import (RelationWeights, cat_rows, relation_attend, relation_attend_batched,
+from .relation import (RelationWeights, cat_rows, cat_rows_many, relation_attend, relation_attend_batched,
                        relation_attention_forward, relation_project_batched)
 from .structures import BoxList, cat_boxlist, to_image_list
 from .synth import _cell_anchors
@@ -569,15 +569,19 @@ class MEGAFeatureExtractor(_Packed):
     batched_attention = True  # the attention core / position logits of all key frames of a stage in ONE launch each
                               # (False: one relation_attend call per key frame -- the A/B switch of that change)
 
-    def _update_lm_batched(self, xs, globs, i=0):
+    def _update_lm_batched(self, xs, globs, i=0, also_cat=()):
         """update_lm (:690-699) for several key frames: xs[t] (a tensor or a tuple of row blocks) attends to globs[t]
-        (that step's global pool).  Returns consecutive row blocks of one buffer."""
+        (that step's global pool).  Returns consecutive row blocks of one buffer (and, with also_cat, the extra
+        concatenations that rode along in the same copy launch)."""
         pk = self._packed(globs[0].dtype, globs[0].device)
         w = pk["global"][i]
-        qs, ks, vts, xc = relation_project_batched(w, xs, globs, want_x=True)
+        res = relation_project_batched(w, xs, globs, want_x=True, also_cat=also_cat)
+        qs, ks, vts, xc = res[:4]
         if self.batched_attention:
-            return relation_attend_batched(w, [{"x": xc[t], "q": qs[t], "k": ks[t], "vt": vts[t]} for t in range(len(xs))])
-        return [relation_attend(w, xc[t], qs[t], ks[t], vts[t]) for t in range(len(xs))]
+            z = relation_attend_batched(w, [{"x": xc[t], "q": qs[t], "k": ks[t], "vt": vts[t]} for t in range(len(xs))])
+        else:
+            z = [relation_attend(w, xc[t], qs[t], ks[t], vts[t]) for t in range(len(xs))]
+        return (z, res[4]) if also_cat else z
 
     def _zero_cols(self, like, n):
         """[rows of like, n] zeros (n < 32), cut from one cached block: the pad columns between V^T blocks"""
@@ -624,9 +628,12 @@ class MEGAFeatureExtractor(_Packed):
         xs, x_refs = {}, {}
         use_glob = self.global_enable and frames[0].get("glob") is not None
         z = None
+        rc_pieces = [r for t in own for r in (frames[t]["rois_key"], frames[t]["rois_dis"])]   # stage queries' boxes
+        rc_all = None
         if use_glob and own:                                                     # :757-760
-            z = self._update_lm_batched([(frames[t]["x"], frames[t]["x_ref"]) for t in own],
-                                        [frames[t]["glob"] for t in own])
+            z, extra = self._update_lm_batched([(frames[t]["x"], frames[t]["x_ref"]) for t in own],
+                                               [frames[t]["glob"] for t in own], also_cat=(rc_pieces,))
+            rc_all = extra[0]
             for j, t in enumerate(own):
                 xs[t], x_refs[t] = z[j][:nkey[t]], z[j][nkey[t]:nkey[t] + nl[t]]
         elif own:
@@ -657,7 +664,9 @@ class MEGAFeatureExtractor(_Packed):
         feats_ref = x_refs
         rois_cur01 = {}
         if own:
-            rc_all, o = torch.cat([r for t in own for r in (frames[t]["rois_key"], frames[t]["rois_dis"])], dim=0), 0
+            if rc_all is None:
+                rc_all = cat_rows_many([rc_pieces])[0]
+            o = 0
             for t in own:
                 rois_cur01[t] = rc_all[o:o + nkey[t] + ndis[t]]
                 o += nkey[t] + ndis[t]
@@ -703,7 +712,10 @@ class MEGAFeatureExtractor(_Packed):
                     ldv[t] = (Nk[t] + 31) // 32 * 32
                     if ldv[t] > Nk[t]:
                         vp.append(self._zero_cols(vts[t], ldv[t] - Nk[t]))
-                k_flat, vt_flat, r_flat = torch.cat(kp, dim=0), torch.cat(vp, dim=1), torch.cat(rp, dim=0)
+                # (row blocks: one copy launch; the V^T column blocks are only 2-byte aligned -- 75 keys = 150 bytes --
+                # and stay with torch.cat's element-wise kernel)
+                k_flat, r_flat = ops.multi_cat([(kp, 0), (rp, 0)])
+                vt_flat = torch.cat(vp, dim=1)
                 ok = oc = 0
                 for t in own:
                     rc = frames[t]["rois_key"] if last else rois_cur01[t]
@@ -747,8 +759,8 @@ class MEGAFeatureExtractor(_Packed):
         old = [r.shape[0] for r in q["rois"]]
         E0, S = len(old), len(new_rois)
         have_old = E0 > 0
-        tr = torch.cat(([self.mem[i]["rois"]] if have_old else []) + list(new_rois), dim=0)
-        tk = torch.cat(([self.mem[i]["k"]] if have_old else []) + list(new_k), dim=0)
+        tr, tk = ops.multi_cat([(([self.mem[i]["rois"]] if have_old else []) + list(new_rois), 0),
+                                (([self.mem[i]["k"]] if have_old else []) + list(new_k), 0)])
         tv = torch.cat(([self.mem[i]["vt"]] if have_old else []) + list(new_vt), dim=1)
         off = [0]
         for n in old + [r.shape[0] for r in new_rois]:
@@ -1065,16 +1077,10 @@ class GeneralizedRCNNMEGA(nn.Module):
         used = L[lo0:]
         ns = [min(bn, r["boxes"].shape[0]) for r in used]
         nd = [min(an, n) for n in ns]
-        tape_r = torch.cat([r["boxes"][:n] for r, n in zip(used, ns)], 0)
-        tape_f = torch.cat([r["feats"][:n] for r, n in zip(used, ns)], 0)
-        tape_d = torch.cat([r["boxes"][:n] for r, n in zip(used, nd)], 0)
-        offc, offd = [0], [0]
-        for n, d in zip(ns, nd):
-            offc.append(offc[-1] + n)
-            offd.append(offd[-1] + d)
-        # global pools: a sliding window over the pushed entries as well
-        globs = [None] * len(steps)
-        if self.global_enable:
+        groups = [([r["boxes"][:n] for r, n in zip(used, ns)], 0), ([r["feats"][:n] for r, n in zip(used, ns)], 0),
+                  ([r["boxes"][:n] for r, n in zip(used, nd)], 0)]
+        gplan = None
+        if self.global_enable:        # the global-pool tape rides in the same copy launch
             gq = fe.global_queue_list[0]["feats"]
             G, gends = list(gq), []
             for _, new_globals in steps:
@@ -1086,15 +1092,28 @@ class GeneralizedRCNNMEGA(nn.Module):
             if G:
                 glo0 = max(0, gends[0] - gq.maxlen)
                 gused = G[glo0:]
-                tape_g = torch.cat(gused, 0) if len(gused) > 1 else gused[0]
-                goff = [0]
-                for e in gused:
-                    goff.append(goff[-1] + e.shape[0])
-                for j, ge in enumerate(gends):
-                    if ge > 0:
-                        globs[j] = tape_g[goff[max(0, ge - gq.maxlen) - glo0]:goff[ge - glo0]]
-                if globs[-1] is not None:
-                    fe.global_cache[0]["feats"] = globs[-1]
+                gplan = (gq, gends, glo0, gused)
+                if len(gused) > 1:
+                    groups.append((gused, 0))
+        cat = ops.multi_cat(groups)
+        tape_r, tape_f, tape_d = cat[0], cat[1], cat[2]
+        offc, offd = [0], [0]
+        for n, d in zip(ns, nd):
+            offc.append(offc[-1] + n)
+            offd.append(offd[-1] + d)
+        # global pools: a sliding window over the pushed entries as well
+        globs = [None] * len(steps)
+        if gplan is not None:
+            gq, gends, glo0, gused = gplan
+            tape_g = cat[3] if len(gused) > 1 else gused[0]
+            goff = [0]
+            for e in gused:
+                goff.append(goff[-1] + e.shape[0])
+            for j, ge in enumerate(gends):
+                if ge > 0:
+                    globs[j] = tape_g[goff[max(0, ge - gq.maxlen) - glo0]:goff[ge - glo0]]
+            if globs[-1] is not None:
+                fe.global_cache[0]["feats"] = globs[-1]
         frames = []
         for j, e in enumerate(ends):
             a, b = max(0, e - cap) - lo0, e - lo0
@@ -1122,8 +1141,7 @@ class GeneralizedRCNNMEGA(nn.Module):
         outs, self.last_logits_batch = [None] * len(frames), [None] * len(frames)
         if own:
             n = [xs[t].shape[0] for t in own]
-            logits, deltas = self.roi_heads.box.predictor(torch.cat([xs[t] for t in own], dim=0) if len(own) > 1
-                                                          else xs[own[0]].contiguous())
+            logits, deltas = self.roi_heads.box.predictor(cat_rows([xs[t] for t in own]).contiguous())
             o = 0
             same = len(own) > 1 and len(set(n)) == 1 and self.batched_postprocess
             if same:       # the usual case (every key frame has all its proposals): one launch chain for all

@@ -74,6 +74,15 @@ def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=Tru
 def cat_rows(ts):
     """torch.cat(ts, 0) for 2-D row blocks -- without a copy when the pieces already ARE consecutive row blocks of one
     buffer (slices of a batched GEMM / attention output handed back in order)."""
+    v = _rows_view(ts)
+    if v is not None:
+        return v
+    ts = [t for t in ts if t.shape[0] > 0] or list(ts[:1])
+    return torch.cat(ts, dim=0)
+
+
+def _rows_view(ts):
+    """the free case of cat_rows: consecutive row blocks of one buffer -> the view, else None"""
     ts = [t for t in ts if t.shape[0] > 0] or list(ts[:1])
     if len(ts) == 1:
         return ts[0]
@@ -83,12 +92,23 @@ def cat_rows(ts):
         base, ptr, es = t0.untyped_storage().data_ptr(), t0.data_ptr(), t0.element_size()
         for t in ts:
             if t.data_ptr() != ptr or t.untyped_storage().data_ptr() != base:
-                break
+                return None
             ptr += t.numel() * es
-        else:
-            rows = sum(t.shape[0] for t in ts)
-            return t0.as_strided((rows, t0.shape[1]), (t0.shape[1], 1), t0.storage_offset())
-    return torch.cat(ts, dim=0)
+        rows = sum(t.shape[0] for t in ts)
+        return t0.as_strided((rows, t0.shape[1]), (t0.shape[1], 1), t0.storage_offset())
+    return None
+
+
+def cat_rows_many(lists):
+    """cat_rows for several independent lists of row blocks: the lists that really need a copy are concatenated by ONE
+    launch (ops.multi_cat) instead of one torch.cat each."""
+    out = [_rows_view(ts) for ts in lists]
+    todo = [i for i, v in enumerate(out) if v is None]
+    if todo:
+        res = ops.multi_cat([([t for t in lists[i] if t.shape[0] > 0], 0) for i in todo])
+        for i, r in zip(todo, res):
+            out[i] = r
+    return out
 
 
 def _flat(xs):
@@ -101,7 +121,7 @@ def _flat(xs):
     return flat, rows
 
 
-def relation_project_batched(w, xs, refs, want_x=False):
+def relation_project_batched(w, xs, refs, want_x=False, also_cat=()):
     """The Wq / Wk / Wv projections of several INDEPENDENT attention problems (the key frames of one engine batch) as
     ONE GEMM each over the concatenated rows: M = sum of the rows, so the 64x64-tile launches of the per-frame form
     become a few big-tile launches.  Every GEMM kernel is batch-invariant (an output row never depends on the rows it
@@ -109,13 +129,15 @@ def relation_project_batched(w, xs, refs, want_x=False):
     xs[i] [Nq_i,1024] queries, refs[i] [Nr_i,1024] keys/values -- each a tensor or a tuple of row blocks (concatenated
     here, once, together with everything else) -> (qs, ks, vts): qs[i] [Nq_i,1024], ks[i] [Nr_i,1024],
     vts[i] [1024,Nr_i] (views into the batched results; a caller that keeps a slice must copy it).
-    want_x: also return the views xcat[i] [Nq_i,1024] of the concatenated queries (the attention's residual)."""
+    want_x: also return the views xcat[i] [Nq_i,1024] of the concatenated queries (the attention's residual).
+    also_cat: further lists of row blocks the caller wants concatenated (they ride in the same copy launch); their
+    results are appended to the returned tuple as one list."""
     xf, nq = _flat(xs)
     rf, nr = _flat(refs)
-    r_all = cat_rows(rf)
+    cats = cat_rows_many([rf, xf] + [list(c) for c in also_cat])
+    r_all, x_all = cats[0], cats[1]
     k_all = ops.linear(r_all, w.wk, w.bk)
     vt_all = ops.linear_transposed(w.wv, r_all, (r_all.shape[0] + 31) // 32 * 32)
-    x_all = cat_rows(xf)
     q_all = ops.linear(x_all, w.wq, w.bq)
     qs, ks, vts, xc = [], [], [], []
     oq = orr = 0
@@ -126,7 +148,8 @@ def relation_project_batched(w, xs, refs, want_x=False):
         vts.append(vt_all[:, orr:orr + nr[i]])
         oq += nq[i]
         orr += nr[i]
-    return (qs, ks, vts, xc) if want_x else (qs, ks, vts)
+    res = (qs, ks, vts, xc) if want_x else (qs, ks, vts)
+    return res + (cats[2:],) if also_cat else res
 
 
 def relation_attend(w, x, q, k, vt, rois_q=None, rois_k=None, mem_kv=None, residual=True):

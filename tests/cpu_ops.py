@@ -137,6 +137,15 @@ def relation_attention_batched(items, groups=16):
                                bias_v=it.get("bias_v"), groups=groups) for it in items]
 
 
+def multi_cat(groups):
+    return [torch.cat(list(p), dim=d) for p, d in groups]
+
+
+def copy_blocks(pairs):
+    for d, s_ in pairs:
+        d.copy_(s_)
+
+
 def preprocess_frames(frames_u8, mean, to_bgr=True):
     x = frames_u8.permute(0, 3, 1, 2).float() / 255.0
     if to_bgr:
@@ -154,7 +163,7 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
     return (out, w[:, 0]) if want_weights else out
 
 
-ALL = ["pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+ALL = ["multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames", "position_logits_batched",
        "relation_attention_batched", "postprocess_batched"]
 

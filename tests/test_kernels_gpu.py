@@ -299,7 +299,8 @@ def test_postprocess_batched_equals_per_image(dev, B, R):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(300, 750, True), (675, 1111, True), (70, 33, False), (129, 64, True)])
+@pytest.mark.parametrize("shape", [(300, 750, True), (675, 1111, True), (70, 33, False), (129, 64, True),
+                                   (40, 1500, True)])     # (40, 1500): 16 blocks -> the key range is split 3 ways + combine
 def test_relation_attention(dev, dtype, shape):
     """position logits + attention core + the projections (ops.linear) vs the literal reference formula
     (oracle.attention_module_multi_head = roi_box_feature_extractors.py:567-646)."""
@@ -536,7 +537,7 @@ def test_position_logits_tiled_bf16(dev, shape):
     assert torch.equal(got, rows.to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("shape", [(300, 750), (675, 1111), (33, 70), (129, 64)])
+@pytest.mark.parametrize("shape", [(300, 750), (675, 1111), (33, 70), (129, 64), (40, 1500)])   # last: split keys + combine
 def test_relation_attention_tiled_pos(dev, shape):
     """bf16 attention with tile-ordered bf16 logits == the same kernel fed the same (bf16-rounded) logits as f32 rows,
     bit for bit: only the fetch path differs."""
@@ -667,3 +668,29 @@ def test_igemm8_bit_equal_to_register_staged_tiles(dev):
             assert all(torch.equal(outs[0], o) for o in outs[1:]), "%s %s: run-to-run difference" % (case, force)
             assert torch.equal(outs[0], ref), "%s %s: differs from the 128x128 tile (max |d| %.3g)" % (
                 case, force, (outs[0].float() - ref.float()).abs().max().item())
+
+
+def test_multi_cat_equals_torch_cat(dev):
+    """ops.multi_cat (mega_copy_segments: every concatenation of a call in one launch per copy width) == torch.cat,
+    bit for bit: row blocks (16-byte rows), f32 boxes, and 2-byte-aligned V^T column blocks (75 keys = 150 bytes)
+    taken as views of wider buffers; empty pieces; more segments than one launch holds."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn((4000, 1024), generator=g).to(torch.bfloat16).to(dev)
+    vt = torch.randn((1024, 4000), generator=g).to(torch.bfloat16).to(dev)
+    boxes = torch.rand((900, 4), generator=g).to(dev)
+    rows = [big[0:75], big[300:600], big[75:75], big[1000:1015], big[3000:3999]]
+    cols = [vt[:, 0:75], vt[:, 75:150], vt[:, 1000:1015], vt[:, 1875:3750], vt[:, 3:4]]
+    bx = [boxes[0:300], boxes[300:375], boxes[890:900]]
+    many = [big[i * 7:i * 7 + 5] for i in range(130)]                     # 130 segments: three launches of <= 56
+    outs = ops.multi_cat([(rows, 0), (cols, 1), (bx, 0), (many, 0)])
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], torch.cat(rows, 0)) and torch.equal(outs[1], torch.cat(cols, 1))
+    assert torch.equal(outs[2], torch.cat(bx, 0)) and torch.equal(outs[3], torch.cat(many, 0))
+    # copy into views of an existing buffer (destination row stride != row length)
+    dst = torch.zeros((64, 300), dtype=torch.bfloat16, device=dev)
+    ops.copy_blocks([(dst[:, 10:85], vt[:64, 100:175]), (dst[:, 85:86], vt[:64, 7:8])])
+    ref = torch.zeros_like(dst)
+    ref[:, 10:85] = vt[:64, 100:175]
+    ref[:, 85:86] = vt[:64, 7:8]
+    assert torch.equal(dst, ref)
