@@ -24,6 +24,7 @@ SOURCES = {
     "frames.hip": ["-ffp-contract=off"],      # (x / 255) * 255 - mean must round like the reference's three torch ops
     "fgfa.hip": [],
     "assemble.hip": [],
+    "conv64.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

@@ -386,6 +386,11 @@ int dispatch_tile(const ConvParams& p, hipStream_t st) {
 
 extern "C" int mega_conv2d_nhwc_plan(int M, int Cout, int K, int in_dtype) {
   int kind = 0, bm = 0, bn = 0;
+  // (kind 6: conv64.hip -- the only K = 576 / Cout = 64 bf16 layer of these models is layer1's 3x3 conv; the real
+  // routing, mega_conv2d_nhwc_ws, also checks the kernel shape and the tile count)
+  if (in_dtype == MEGA_BF16 && Cout == 64 && K == 576 && M >= 16384 && !getenv("MEGA_IGEMM_TILE") &&
+      !(getenv("MEGA_CONV64") && getenv("MEGA_CONV64")[0] == '0'))
+    return 6 * 1000000 + 256 * 1000 + 64;
   choose_tile(M, Cout, K, choose_ksplit(K), in_dtype == MEGA_BF16, kind, bm, bn);
   if (kind == 8 && (K >> 6) < 1) { kind = 0; bm = 128; bn = 128; }
   return kind * 1000000 + bm * 1000 + bn;
@@ -438,6 +443,9 @@ extern "C" int mega_conv2d_nhwc_ws(const void* in, const void* w, const float* s
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == MEGA_BF16) {
     if (Cin % 64 != 0) return MEGA_ERR_ARG;
+    // layer1's 3x3 64 -> 64 conv: its own persistent streaming kernel (a forced tile, MEGA_IGEMM_TILE, keeps it on the
+    // generic path: that is how the bit-equality test compares the two)
+    if (out_dtype == MEGA_BF16 && !getenv("MEGA_IGEMM_TILE") && mega_conv64_supports(p, 0)) return mega_conv64_launch(p, st);
     if (out_dtype == MEGA_BF16) return dispatch_tile<bf16_t, bf16_t>(p, st);
     if (out_dtype == MEGA_F32) return dispatch_tile<bf16_t, float>(p, st);
     return MEGA_ERR_ARG;

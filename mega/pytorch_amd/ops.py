@@ -95,6 +95,8 @@ def _igemm_family(lib, M, Cout, K, dtype):
     """name of the kernel instantiation a conv / linear of this GEMM shape is dispatched to (profiler families)"""
     t = lib.mega_conv2d_nhwc_plan(M, Cout, K, _DT[dtype])
     kind, t = t // 1000000, t % 1000000
+    if kind == 6:
+        return "conv64_bf16_3x3"
     return "igemm%s_%s_%dx%d" % ("8" if kind == 8 else "", "bf16" if dtype == torch.bfloat16 else "f32", t // 1000, t % 1000)
 
 

@@ -694,3 +694,30 @@ def test_multi_cat_equals_torch_cat(dev):
     ref[:, 10:85] = vt[:64, 100:175]
     ref[:, 85:86] = vt[:64, 7:8]
     assert torch.equal(dst, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 150, 250), (5, 70, 90), (3, 151, 249), (40, 33, 47)])
+def test_conv64_persistent_bit_equal_to_generic_tiles(dev, shape, monkeypatch):
+    """conv64.hip (layer1's 3x3 64 -> 64 conv + FrozenBN + ReLU as a persistent kernel with the weights resident in LDS
+    and an 18 x 18 halo patch per 16 x 16 tile) against the generic implicit-GEMM tile on the same inputs: same MFMA, same
+    ascending (r, s, c) K order -> the same bits; and both against F.conv2d in f32.  Shapes with partial edge tiles."""
+    ops = _ops()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn((N, H, W, 64), generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn((64, 3, 3, 64), generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    sc = (torch.rand((64,), generator=g) + 0.5).to(dev)
+    bi = (torch.randn((64,), generator=g) * 0.1).to(dev)
+    from mega.pytorch_amd import _lib
+    assert _lib.load().mega_conv2d_nhwc_plan(N * H * W, 64, 576, 1) // 1000000 == 6      # dispatched to conv64
+    for relu in (True, False, 2):
+        y = ops.conv2d_nhwc(x, w, sc, bi, pad=1, relu=relu)
+        monkeypatch.setenv("MEGA_IGEMM_TILE", "128x64")
+        y_ref = ops.conv2d_nhwc(x, w, sc, bi, pad=1, relu=relu)
+        monkeypatch.delenv("MEGA_IGEMM_TILE")
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref), "relu=%s: %d elements differ" % (relu, (y != y_ref).sum().item())
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), padding=1)
+    ref = F.relu(ref * sc.cpu().view(1, -1, 1, 1) + bi.cpu().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    y = ops.conv2d_nhwc(x, w, sc, bi, pad=1, relu=True)
+    assert _relerr(y.float().cpu(), ref) < 1e-2
