@@ -206,6 +206,12 @@ int mega_resize_bilinear_u8(const unsigned char* in, unsigned char* out, unsigne
  *   feats [T][H][W][Cf+Ce] NHWC, flow [T][2][H][W] f32, out [H][W][Cf], weights_out [T][H][W] f32 or NULL. */
 int mega_fgfa_warp_aggregate(const void* feats, const float* flow, void* out, float* weights_out, int T, int H,
                              int W, int Cf, int Ce, int key, int dtype, void* stream);
+/* The same with the T maps and flow fields held in a ring of T slots (the window's deques of
+ * generalized_rcnn_fgfa.py:166-176 without the per-step torch.cat of 21 x 3072-channel maps): order = 1 + T device ints,
+ * order[0] = slot of the key frame, order[1 + t] = slot of window position t.  Frames are visited in window order, so the
+ * result has the bits of the contiguous call; one hipGraph serves every step (only the ints change). */
+int mega_fgfa_warp_aggregate_ring(const void* feats, const float* flow, void* out, float* weights_out, int T, int H,
+                                  int W, int Cf, int Ce, const int* order, int dtype, void* stream);
 
 /* DFF feature propagation: out[H][W][C] = bilinear warp (same grid convention as above) of the
  * key frame's NHWC feature map by flow [2][H][W], times the per-element scale map [H][W][C].  Replaces

@@ -130,7 +130,13 @@ __global__ __launch_bounds__(256) void fgfa_kernel(const T* __restrict__ feats, 
 template <typename T>
 __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats, const float* __restrict__ flow,
                                                     T* __restrict__ out, float* __restrict__ weights_out, int NT,
-                                                    int H, int W, int Cf, int Ce, int key) {
+                                                    int H, int W, int Cf, int Ce, int key,
+                                                    const int* __restrict__ order) {
+  // order (optional, device): the T maps live in a RING -- order[0] = slot of the key frame, order[1 + t] = slot of the
+  // frame at window position t.  Frames are visited in window order whatever their slots, so the sums have the bits of
+  // the contiguous (deque-ordered) call; flow is indexed by slot like feats.  (engine: one hipGraph for every step.)
+  auto slot_of = [&](int t) { return order ? order[1 + t] : t; };
+  if (order) key = order[0];
   constexpr int VE = Elem<T>::VE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* cur = lds;                 // [Ce]  key frame's warped embedding
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats,
   const int px = pix % W, py = pix / W;
 
   struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
-  auto taps = [&](int t) {
+  auto taps = [&](int t) {           // t = SLOT of the frame
     const float fx = flow[((size_t)t * 2 + 0) * H * W + py * W + px];
     const float fy = flow[((size_t)t * 2 + 1) * H * W + py * W + px];
     const float gx = ((float)px + fx) / ((float)(W - 1) / 2.f) - 1.f;   // :55-58
@@ -197,8 +203,9 @@ __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats,
 
   // ---- B. cosine weights: wave w takes frames w, w + 4, ...; no block barrier inside
   for (int t = wave; t < NT; t += 4) {
-    const Taps tp = taps(t);
-    const T* base = feats + (size_t)t * H * W * C + Cf;
+    const int st = slot_of(t);
+    const Taps tp = taps(st);
+    const T* base = feats + (size_t)st * H * W * C + Cf;
     float dot = 0.f, nn = 0.f;
     for (int v0 = 0; v0 < evec; v0 += 256) {           // 4 vectors per lane per round: 16 loads in flight
       uint4 a[4], b[4], c[4], d[4];
@@ -243,9 +250,10 @@ __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats,
   for (int t = g; t < NT; t += 2 * G) {
     const int t2 = t + G;
     const bool has2 = t2 < NT;
-    const Taps tp = taps(t), tq = taps(has2 ? t2 : t);
-    const T* p = feats + (size_t)t * H * W * C + (size_t)v * VE;
-    const T* q2 = feats + (size_t)(has2 ? t2 : t) * H * W * C + (size_t)v * VE;
+    const int s1 = slot_of(t), s2 = slot_of(has2 ? t2 : t);
+    const Taps tp = taps(s1), tq = taps(s2);
+    const T* p = feats + (size_t)s1 * H * W * C + (size_t)v * VE;
+    const T* q2 = feats + (size_t)s2 * H * W * C + (size_t)v * VE;
     const uint4 a = *reinterpret_cast<const uint4*>(p + tp.o00), b = *reinterpret_cast<const uint4*>(p + tp.o01);
     const uint4 c = *reinterpret_cast<const uint4*>(p + tp.o10), d = *reinterpret_cast<const uint4*>(p + tp.o11);
     const uint4 a2 = *reinterpret_cast<const uint4*>(q2 + tq.o00), b2 = *reinterpret_cast<const uint4*>(q2 + tq.o01);
@@ -345,8 +353,24 @@ extern "C" int mega_dff_warp_scale(const void* feats, const float* flow, const v
   return mega_check_launch();
 }
 
+static int fgfa_impl(const void* feats, const float* flow, void* out, float* weights_out, int T, int H, int W, int Cf,
+                     int Ce, int key, const int* order, int dtype, void* stream);
+
 extern "C" int mega_fgfa_warp_aggregate(const void* feats, const float* flow, void* out, float* weights_out, int T,
                                         int H, int W, int Cf, int Ce, int key, int dtype, void* stream) {
+  return fgfa_impl(feats, flow, out, weights_out, T, H, W, Cf, Ce, key, nullptr, dtype, stream);
+}
+
+// The same with the T maps (and their flow fields) held in a ring: order [1 + T] device ints, order[0] = slot of the key
+// frame, order[1 + t] = slot of window position t.  Same bits as the contiguous call on the frames in window order.
+extern "C" int mega_fgfa_warp_aggregate_ring(const void* feats, const float* flow, void* out, float* weights_out, int T,
+                                             int H, int W, int Cf, int Ce, const int* order, int dtype, void* stream) {
+  if (!order) return MEGA_ERR_ARG;
+  return fgfa_impl(feats, flow, out, weights_out, T, H, W, Cf, Ce, 0, order, dtype, stream);
+}
+
+static int fgfa_impl(const void* feats, const float* flow, void* out, float* weights_out, int T, int H, int W, int Cf,
+                     int Ce, int key, const int* order, int dtype, void* stream) {
   mega_clear_error();
   if (!feats || !flow || !out || T <= 0 || T > 64 || H <= 1 || W <= 1 || Cf <= 0 || Ce <= 0 || key < 0 || key >= T)
     return MEGA_ERR_ARG;
@@ -359,14 +383,15 @@ extern "C" int mega_fgfa_warp_aggregate(const void* feats, const float* flow, vo
     const size_t smem2 = ((size_t)Ce + (size_t)(256 / fvec - 1) * Cf) * sizeof(float);
     if (dtype == MEGA_BF16)
       hipLaunchKernelGGL((fgfa2_kernel<bf16_t>), dim3(H * W), dim3(256), smem2, st, (const bf16_t*)feats, flow,
-                         (bf16_t*)out, weights_out, T, H, W, Cf, Ce, key);
+                         (bf16_t*)out, weights_out, T, H, W, Cf, Ce, key, order);
     else if (dtype == MEGA_F32)
       hipLaunchKernelGGL((fgfa2_kernel<float>), dim3(H * W), dim3(256), smem2, st, (const float*)feats, flow,
-                         (float*)out, weights_out, T, H, W, Cf, Ce, key);
+                         (float*)out, weights_out, T, H, W, Cf, Ce, key, order);
     else
       return MEGA_ERR_ARG;
     return mega_check_launch();
   }
+  if (order) return MEGA_ERR_ARG;          // the ring form exists for the two-pass kernel only
   const size_t smem = ((size_t)Ce + (size_t)T * Cf) * sizeof(float);
   if (smem > 150 * 1024) return MEGA_ERR_ARG;
   if (dtype == MEGA_BF16) {

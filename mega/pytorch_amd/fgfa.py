@@ -419,3 +419,159 @@ class GeneralizedRCNNDFF(nn.Module):
 
 
 DETECTION_META_ARCHITECTURES.register("GeneralizedRCNNDFF", GeneralizedRCNNDFF)
+
+
+class FgfaClipEngine(object):
+    """Clip-level driver for GeneralizedRCNNFGFA (BASELINE configs[4]): the MI355X-first way to run the reference's
+    per-key-frame loop (generalized_rcnn_fgfa.py:144-219; feed: data/datasets/vid_fgfa.py test mode).
+
+    The reference (and `model(images)` here) runs ~200 launches per key frame at batch 1, re-concatenates the window's
+    21 images and 21 x 3072-channel maps every step, and reads the detection count back before the next frame: on
+    MI355X that is host-bound (8.7 ms per key frame for 5.6 ms of kernels) and the single-frame backbone fills 15 % of
+    the chip.  Here
+      * backbone + EmbedNet run for `lookahead` upcoming frames in ONE batch (the kernels are batch-invariant: same bits);
+      * the window lives in rings of T slots (images, [features | embeddings]); a step overwrites the oldest slot and
+        rotates an index table on the device (`order`); FlowNetS takes the pairs in slot order and the warp kernel visits
+        the frames in window order through `order` (mega_fgfa_warp_aggregate_ring) -- the bits of the contiguous call;
+      * everything after the ring update -- pair assembly, FlowNetS, warp + aggregation, RPN selection, res5 + ROIAlign +
+        fc6/fc7, predictor, post-processing (fixed 300 proposal rows, the device-side proposal count goes to the
+        post-processor) -- is ONE hipGraph replayed per key frame; detection counts are read a batch of steps later.
+    Detections are identical to `model(images)` frame by frame (tests/test_e2e_gpu.py::test_fgfa_engine_equals_model)."""
+
+    def __init__(self, model, lookahead=20, graphs=True):
+        self.m = model
+        self.T = model.all_frame_interval
+        self.key = model.key_frame_location
+        self.ahead = self.T - self.key - 1
+        self.lookahead = lookahead
+        self.use_graphs = graphs
+        self.graph = None
+        self.fgraphs = {}
+        self.replays = 0
+
+    # ---- features of a batch of frames (backbone + EmbedNet), replayed from a hipGraph per batch size
+    def _features(self, imgs):
+        m = self.m
+
+        def body(x):
+            f = _nhwc(m.backbone(x)[0])
+            return torch.cat([f, m.embednet.run(f)], dim=-1)
+        if not (self.use_graphs and imgs.is_cuda):
+            return body(imgs)
+        ent = self.fgraphs.setdefault(tuple(imgs.shape), {})
+        if "seen" not in ent:            # first use of a shape: eager (packs weights, warms the allocator)
+            ent["seen"] = True
+            return body(imgs)
+        if "graph" not in ent:
+            ent["in"] = imgs.clone()
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                ent["out"] = body(ent["in"])
+            ent["graph"] = g
+        ent["in"].copy_(imgs)
+        ent["graph"].replay()
+        return ent["out"].clone()
+
+    # ---- one key frame on the ring state (this body is what the graph captures)
+    def _body(self, size):
+        m = self.m
+        W, H = size
+        T = self.T
+        cur = self.img_ring.index_select(0, self.order[0:1])
+        pair = torch.cat([cur.expand(T, -1, -1, -1), self.img_ring], dim=1)
+        flow = m.flownet.run(pair.permute(0, 2, 3, 1).contiguous().to(m.dtype))
+        nfeat = m.backbone.out_channels
+        agg = ops.fgfa_warp_aggregate(self.feat_ring, flow, nfeat, 0, order=self.order)
+        feats = (_nchw_view(agg.unsqueeze(0)),)
+        props, _, cnt = m.rpn.propose(_nhwc(feats[0]), W, H, "key")
+        box = m.roi_heads.box
+        x = box.feature_extractor(feats, [props[0]])
+        logits, deltas = box.predictor(x)
+        pp = box.post_processor
+        return ops.postprocess(logits.float().contiguous(), deltas.float().contiguous(), props[0].contiguous(), cnt,
+                               pp.weights, W, H, pp.score_thresh, pp.nms, pp.detections_per_img, pp.strict_gt)
+
+    def _step(self, size):
+        if not (self.use_graphs and self.img_ring.is_cuda):
+            return self._body(size)
+        if self.graph is None:
+            self.graph = "armed"
+            return self._body(size)
+        if self.graph == "armed":
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._out = self._body(size)
+            self.graph = g
+        self.graph.replay()
+        self.replays += 1
+        return tuple(t.clone() for t in self._out)
+
+    @torch.no_grad()
+    def run(self, frames, first=0, last=None, sync_every=16):
+        """frames: preprocessed f32 [L,3,H,W] on the device (the whole video, or a FrameSource-like object with
+        __getitem__ over index tensors).  Key frames first..last-1 (first = 0 starts a new video).  -> list[BoxList]."""
+        m = self.m
+        L = frames.shape[0]
+        last = L if last is None else last
+        H, W = frames.shape[-2:]
+        dev = frames.device
+        T, key, ahead = self.T, self.key, self.ahead
+        out, pending = [], []
+
+        def flush():
+            if not pending:
+                return
+            counts = torch.cat([p[3] for p in pending]).tolist()
+            for (ob, os_, ol, _), n in zip(pending, counts):
+                out.append(PostProcessor.materialize((ob, os_, ol, None), int(n), (W, H)))
+            del pending[:]
+
+        idx = first
+        if idx == 0 and idx < last:
+            # frame_category 0 (:163-176): the window = frame 0 replicated key + 1 times, then frames 1 .. ahead (clamped)
+            ids = [0] * (key + 1)
+            end = 0
+            for _ in range(ahead):
+                end = min(end + 1, L - 1)
+                ids.append(end)
+            uniq = sorted(set(ids))
+            f = self._features(frames[torch.tensor(uniq, device=dev)] if len(uniq) > 1 else frames[uniq[0]:uniq[0] + 1])
+            pos = {u: i for i, u in enumerate(uniq)}
+            sel = torch.tensor([pos[i] for i in ids], device=dev)
+            fr = f.index_select(0, sel)
+            ir = frames[torch.tensor(ids, device=dev)].float()
+            self.window = list(range(T))                # slot of window position t
+            self.end_id = end
+            od = torch.tensor([self.window[key]] + self.window, dtype=torch.int32, device=dev)
+            if getattr(self, "feat_ring", None) is not None and self.feat_ring.shape == fr.shape \
+                    and self.img_ring.shape == ir.shape and self.feat_ring.device == fr.device:
+                self.feat_ring.copy_(fr)                 # a new video of the same size: the rings (and the captured
+                self.img_ring.copy_(ir)                  # graph that reads them) stay where they are
+                self.order.copy_(od)
+            else:
+                self.feat_ring, self.img_ring, self.order = fr.contiguous(), ir.contiguous(), od
+                self.graph = None
+            self.cache = {}                              # frame id -> [h,w,3072] computed ahead of need
+            pending.append(self._step((W, H)))
+            idx = 1
+        while idx < last:
+            self.end_id = min(self.end_id + 1, L - 1)
+            fid = self.end_id
+            if fid not in self.cache:                    # features of the next `lookahead` new frames in one batch
+                ids = sorted(set(min(fid + j, L - 1) for j in range(self.lookahead)))
+                ids = ids + [ids[-1]] * (self.lookahead - len(ids))      # keep the batch shape (one hipGraph)
+                fb = self._features(frames[torch.tensor(ids, device=dev)].float())
+                self.cache = {i: fb[j] for j, i in enumerate(ids)}
+            s = self.window[0]                            # the oldest frame's slot is overwritten
+            self.feat_ring[s].copy_(self.cache[fid])
+            self.img_ring[s].copy_(frames[fid])
+            self.window = self.window[1:] + [s]
+            self.order.copy_(torch.tensor([self.window[key]] + self.window, dtype=torch.int32).pin_memory(), non_blocking=True)
+            pending.append(self._step((W, H)))
+            idx += 1
+            if len(pending) >= sync_every:
+                flush()
+        flush()
+        return out

@@ -618,17 +618,24 @@ def dff_warp_scale(feats, flow, scale):
     return out
 
 
-def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
-    """feats NHWC [T,H,W,Cf+Ce], flow [T,2,H,W] f32 -> aggregated key-frame features [H,W,Cf] (+ weights [T,H,W])."""
-    _gpu(feats, flow)
+def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
+    """feats NHWC [T,H,W,Cf+Ce], flow [T,2,H,W] f32 -> aggregated key-frame features [H,W,Cf] (+ weights [T,H,W]).
+    order (i32 [1 + T] on the device): feats / flow are rings of T slots, order[0] = the key frame's slot, order[1 + t] =
+    the slot of window position t (`key` is ignored); same bits as the call on the frames in window order."""
+    _gpu(feats, flow, order)
     lib = _lib.load()
     T, H, W, C = feats.shape
     assert feats.is_contiguous() and flow.is_contiguous() and flow.dtype == torch.float32 and flow.shape == (T, 2, H, W)
     out = torch.empty((H, W, Cf), dtype=feats.dtype, device=feats.device)
     wts = torch.empty((T, H, W), dtype=torch.float32, device=feats.device) if want_weights else None
     _tok = _pb("fgfa_warp", 0.0, 4.0 * feats.numel() * feats.element_size())
-    rc = lib.mega_fgfa_warp_aggregate(_ptr(feats), _ptr(flow), _ptr(out), _ptr(wts), T, H, W, Cf, C - Cf, key,
-                                      _dt(feats), _stream())
+    if order is not None:
+        assert order.dtype == torch.int32 and order.numel() == T + 1 and order.is_contiguous()
+        rc = lib.mega_fgfa_warp_aggregate_ring(_ptr(feats), _ptr(flow), _ptr(out), _ptr(wts), T, H, W, Cf, C - Cf,
+                                               _ptr(order), _dt(feats), _stream())
+    else:
+        rc = lib.mega_fgfa_warp_aggregate(_ptr(feats), _ptr(flow), _ptr(out), _ptr(wts), T, H, W, Cf, C - Cf, key,
+                                          _dt(feats), _stream())
     _pe(_tok)
     _lib.check(rc, "mega_fgfa_warp_aggregate")
     return (out, wts) if want_weights else out

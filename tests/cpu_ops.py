@@ -157,7 +157,11 @@ def avgpool2x2_ceil(x):
     return F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1).contiguous().to(x.dtype)
 
 
-def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False):
+def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
+    if order is not None:          # ring form: window position t lives in slot order[1 + t], the key frame in order[0]
+        slots = order[1:].long()
+        key = int((slots == int(order[0])).nonzero()[0])
+        feats, flow = feats.index_select(0, slots), flow.index_select(0, slots)
     out, w = mo.fgfa_aggregate(feats.float().permute(0, 3, 1, 2), flow, key, nfeat=Cf)
     out = out[0].permute(1, 2, 0).contiguous().to(feats.dtype)
     return (out, w[:, 0]) if want_weights else out
