@@ -238,38 +238,53 @@ class ClipEngine(object):
             return ops.preprocess_frames(sel.contiguous(), self.mean, self.to_bgr)
         return sel.contiguous()
 
-    def _frame_stage(self, imgs, want):
-        """model.frame_stage_async, replayed from a hipGraph when this exact batch shape has been seen before.
-        The frame stage is ~130 launches of static shape per batch: as a graph the host pays one replay
-        (microseconds) instead of ~35 us of Python + ctypes per launch.  First occurrence of a shape runs eagerly
-        (warm-up: packs weights, sets kernel attributes, fills the allocator), the second is captured."""
+    def _frame_stage(self, imgs, want, on_counts=None):
+        """model.frame_stage_a + frame_stage_b, replayed from hipGraphs when this exact batch shape has been seen before.
+        The frame stage is ~130 launches of static shape per batch: as graphs the host pays two replays (microseconds)
+        instead of ~35 us of Python + ctypes per launch.  First occurrence of a shape runs eagerly (warm-up: packs
+        weights, sets kernel attributes, fills the allocator), the second is captured.
+        on_counts(cnt): called between the two halves with the device-side proposal counts (a fresh tensor): the caller
+        starts their copy to the host there -- the counts are all the host needs to lay out the aggregation, and they
+        exist 40 % of the stage before its features do."""
         m = self.frame_model
         if not (self.use_graphs and imgs.is_cuda):
-            return m.frame_stage_async(imgs, want)
+            a = m.frame_stage_a(imgs)
+            if on_counts is not None:
+                on_counts(a["cnt"])
+            return m.frame_stage_b(a, want)
         key = (tuple(imgs.shape), tuple(int(w) for w in want), imgs.dtype)
         ent = self._fgraphs.get(key)
         if ent is None:
             self._fgraphs[key] = {}
             self.graph_stats["eager"] += 1
-            return m.frame_stage_async(imgs, want)
+            a = m.frame_stage_a(imgs)
+            if on_counts is not None:
+                on_counts(a["cnt"])
+            return m.frame_stage_b(a, want)
         if "graph" not in ent:
             ent["static_in"] = imgs.clone()
             torch.cuda.current_stream().synchronize()
-            g = torch.cuda.CUDAGraph()
             if self._graph_pool is None:          # all frame-stage graphs replay one after the other on one stream:
                 self._graph_pool = torch.cuda.graph_pool_handle()    # they can share one activation pool
             # thread-local capture mode: the RCCL watchdog thread of a multi-GPU run polls its events with
             # hipEventQuery, which the default (global) mode forbids on ANY thread while a capture is open
-            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
-                ent["st"] = m.frame_stage_async(ent["static_in"], want)
-            ent["graph"] = g
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, pool=self._graph_pool, capture_error_mode="thread_local"):
+                ent["a"] = m.frame_stage_a(ent["static_in"])
+            with torch.cuda.graph(gb, pool=self._graph_pool, capture_error_mode="thread_local"):
+                ent["st"] = m.frame_stage_b(ent["a"], want)
+            ent["graph_a"], ent["graph"] = ga, gb
             self.graph_stats["captured"] += 1
         ent["static_in"].copy_(imgs)
+        ent["graph_a"].replay()
+        cnt = ent["a"]["cnt"].clone()
+        if on_counts is not None:
+            on_counts(cnt)
         ent["graph"].replay()
         self.graph_stats["replayed"] += 1
         st = ent["st"]
         # the graph's outputs are overwritten by the next replay: hand out copies (6 MB per 16-frame batch)
-        return {"props": st["props"].clone(), "scores": st["scores"].clone(), "cnt": st["cnt"].clone(),
+        return {"props": st["props"].clone(), "scores": st["scores"].clone(), "cnt": cnt,
                 "feats": st["feats"].clone(), "want": st["want"]}
 
     def shard_plan(self, jobs, rank=None, world=None):
@@ -291,11 +306,12 @@ class ClipEngine(object):
             mine += padded[rank * per:(rank + 1) * per]
         return plan, mine
 
-    def records_async(self, clip, jobs):
+    def records_async(self, clip, jobs, on_counts=None):
         """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
-        records_resolve()."""
+        records_resolve().  on_counts: see _frame_stage (single-process path only; the sharded path's counts travel with
+        the gathered records)."""
         if self.world == 1 and not self.force_sharded:
-            return {"st": self._frame_stage(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs])}
+            return {"st": self._frame_stage(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs], on_counts)}
         # ---- sharded.  Jobs are grouped by their row count (local-window frames: key_num rows, global-pool frames:
         # base_num rows -- a global frame's record is 4x smaller on the wire); each group is dealt to the ranks in
         # contiguous slices (padded by repeating its last job); a rank runs ONE frame-stage launch over its slices of
@@ -415,9 +431,18 @@ class ClipEngine(object):
 
         def launch(flat):
             """one frame-stage launch (+ async copy of its proposal counts) -> handle"""
-            h = self.records_async(clip, flat)
+            early = {}
+
+            def on_counts(c):     # between the two halves of the frame stage: counts -> pinned host memory + event
+                if use_streams:
+                    early["cnt_host"] = torch.empty(c.shape, dtype=c.dtype).pin_memory()
+                    early["cnt_host"].copy_(c, non_blocking=True)
+                    early["cnt_ev"] = torch.cuda.Event()
+                    early["cnt_ev"].record(sF)
+            h = self.records_async(clip, flat, on_counts)
             h["jobs"] = flat
-            if use_streams:   # proposal counts -> pinned host memory, async
+            h.update(early)
+            if use_streams and "cnt_host" not in h:   # (sharded path: the counts arrive with the gathered records)
                 c = self._cnt_of(h)
                 h["cnt_host"] = torch.empty(c.shape, dtype=c.dtype).pin_memory()
                 h["cnt_host"].copy_(c, non_blocking=True)
@@ -461,9 +486,13 @@ class ClipEngine(object):
         def aggregate(b, per_step, hs, ev):
             with _On(sB):
                 if use_streams and ev is not None:
-                    sB.wait_event(ev)
+                    sB.wait_event(ev)                 # GPU side: the aggregation starts after the whole frame stage
                     tw = _time.perf_counter()
-                    ev.synchronize()                  # host waits for THIS frame-stage batch only, not the stream
+                    # host side: only the proposal COUNTS are needed to lay the aggregation out; they were copied between
+                    # the two halves of the frame stage, so the ~180 launches below are enqueued while res5 / ROIAlign /
+                    # fc0 still run (a block of one step-batch used to spend 6 ms host-bound here after the GPU went idle)
+                    for h in hs:
+                        (h.get("cnt_ev") or ev).synchronize()
                     ht["frame_wait"] += _time.perf_counter() - tw
                 recs = []
                 for h in hs:

@@ -129,7 +129,9 @@ class FlowNetS(_Packed):
         dt = pair_nhwc.dtype
         pk = self._packed(dt, pair_nhwc.device)
         m = _mult(dt)
-        x = ops.avgpool2x2_ceil(_padc(pair_nhwc, m))
+        # pool at 8 channels (one 16-byte vector per pixel), THEN zero-pad to the GEMM's K vector: padding the full-resolution
+        # pair to 64 channels first wrote and re-read 1.6 GB per key frame for the same values
+        x = _padc(ops.avgpool2x2_ceil(_padc(pair_nhwc, 8 if dt == torch.bfloat16 else 4)), m)
         r1 = self._conv(pk, "flow_conv1", x)
         r2 = self._conv(pk, "conv2", r1)
         r3 = self._conv(pk, "conv3", r2)

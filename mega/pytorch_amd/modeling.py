@@ -942,17 +942,26 @@ class GeneralizedRCNNMEGA(nn.Module):
 
     # ------------------------------------------------------------------ frame stage (batched, frame-independent)
     @torch.no_grad()
-    def frame_stage_async(self, imgs, want):
-        """Enqueue the whole frame stage for imgs [B,3,H,W] (f32, preprocessed) WITHOUT any host sync.
-        want[b] = proposal rows computed for frame b (key_num for local frames, base_num for global-pool frames).
-        Shapes are static: frame b always gets want[b] ROI rows; rows past its (device-side) proposal count are
-        all-zero boxes whose features are simply never used.  Returns a handle for frame_stage_resolve()."""
-        fe = self.roi_heads.box.feature_extractor
-        B, _, H, W = imgs.shape
+    def frame_stage_a(self, imgs):
+        """First half of the frame stage: backbone + RPN head + proposal selection for imgs [B,3,H,W] (f32, preprocessed),
+        no host sync.  -> {"c4", "props" [B,K,4], "scores" [B,K], "cnt" [B] (device)}.  The proposal COUNTS exist at the end
+        of this half: the engine copies them to the host here, so that it can lay out the aggregation while the second half
+        (res5 + ROIAlign + fc0, ~40 % of the stage) is still running."""
+        _, _, H, W = imgs.shape
         c4 = _nhwc(self.backbone(imgs)[0])
         props, scores, cnt = self.rpn.propose(c4, W, H, "key")           # [B,K,4], [B,K], [B] (device)
+        return {"c4": c4, "props": props, "scores": scores, "cnt": cnt}
+
+    @torch.no_grad()
+    def frame_stage_b(self, a, want):
+        """Second half: res5 + ROIAlign + fc0 on the proposals of frame_stage_a.  want[b] = proposal rows computed for
+        frame b (key_num for local frames, base_num for global-pool frames).  Shapes are static: frame b always gets
+        want[b] ROI rows; rows past its (device-side) proposal count are all-zero boxes whose features are simply never
+        used.  Returns the handle frame_stage_resolve() takes."""
+        fe = self.roi_heads.box.feature_extractor
+        c4, props = a["c4"], a["props"]
         want = tuple(int(w) for w in want)
-        key = (want, str(imgs.device))
+        key = (want, str(c4.device))
         if not hasattr(self, "_roi_index_cache"):
             self._roi_index_cache = {}
         cache = self._roi_index_cache.get(key)
@@ -961,12 +970,18 @@ class GeneralizedRCNNMEGA(nn.Module):
             K = props.shape[1]
             flat = torch.cat([b * K + torch.arange(w) for b, w in enumerate(want)])
             ids = torch.cat([torch.full((w,), float(b)) for b, w in enumerate(want)]).view(-1, 1)
-            cache = (key, flat.to(imgs.device), ids.to(imgs.device))
+            cache = (key, flat.to(c4.device), ids.to(c4.device))
             self._roi_index_cache[key] = cache
         boxes = props.view(-1, 4).index_select(0, cache[1])
         rois5 = torch.cat([cache[2], boxes], dim=1)
         feats = fe.box_features(c4, rois5)
-        return {"props": props, "scores": scores, "cnt": cnt, "feats": feats, "want": want}
+        return {"props": props, "scores": a["scores"], "cnt": a["cnt"], "feats": feats, "want": want}
+
+    @torch.no_grad()
+    def frame_stage_async(self, imgs, want):
+        """Enqueue the whole frame stage for imgs [B,3,H,W] (f32, preprocessed) WITHOUT any host sync:
+        frame_stage_b(frame_stage_a(imgs), want).  Returns a handle for frame_stage_resolve()."""
+        return self.frame_stage_b(self.frame_stage_a(imgs), want)
 
     @staticmethod
     def frame_stage_resolve(st, counts=None):
