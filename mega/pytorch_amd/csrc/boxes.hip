@@ -556,7 +556,7 @@ __global__ void post_prepare_kernel(const float* __restrict__ logits, const floa
                                     const float4* __restrict__ props, const int* __restrict__ nprop_ptr, int R, int NC,
                                     float wx, float wy, float ww, float wh, float clip, float im_w, float im_h,
                                     float score_thresh, float4* __restrict__ cboxes, float* __restrict__ cscores,
-                                    float* __restrict__ probs_out) {
+                                    float* __restrict__ probs_out, unsigned char* __restrict__ flags) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const int b = blockIdx.y;
@@ -565,6 +565,7 @@ __global__ void post_prepare_kernel(const float* __restrict__ logits, const floa
   props += (size_t)b * R;
   cboxes += (size_t)b * (NC - 1) * R;
   cscores += (size_t)b * (NC - 1) * R;
+  flags += (size_t)b * (NC - 1) * R;     // the kept flags of this call start from zero (written here, not by a memset node)
   if (probs_out) probs_out += (size_t)b * R * NC;
   const int nprop = nprop_ptr ? min(nprop_ptr[b], R) : R;
   const bool live = r < nprop;
@@ -594,6 +595,7 @@ __global__ void post_prepare_kernel(const float* __restrict__ logits, const floa
     const size_t o = (size_t)(j - 1) * R + r;
     cboxes[o] = make_float4(x1, y1, x2, y2);
     cscores[o] = (live && pr > score_thresh) ? pr : -1.f;
+    flags[o] = 0;
   }
 }
 
@@ -748,7 +750,12 @@ __global__ __launch_bounds__(1024) void post_finalize_kernel(const unsigned char
   if (tid == 0) *out_cnt = base;
 }
 
-__global__ void set_int_kernel(int* p, int v) { *p = v; }
+// *p = v and zero[0 .. nzero) = 0  (grid covers nzero bytes, 4 per thread)
+__global__ void set_int_kernel(int* p, int v, unsigned char* zero, int nzero) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i == 0) *p = v;
+  for (int e = i; e < min(i + 4, nzero); ++e) zero[e] = 0;
+}
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -821,8 +828,8 @@ extern "C" int mega_nms(const float* dets, const float* scores, int n, float thr
   void* mws = w;
   int ns = 64;
   while (ns < n) ns <<= 1;
-  (void)hipMemsetAsync(flags, 0, (size_t)n, st);
-  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, st, counts, n);
+  // (a kernel, not hipMemsetAsync: captured into a hipGraph a memset NODE was seen to run out of order, see NOTES)
+  hipLaunchKernelGGL(set_int_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, st, counts, n, flags, n);
   hipLaunchKernelGGL(sort_boxes_kernel, dim3(1), dim3(1024), (size_t)ns * sizeof(u64), st, scores, (const float4*)dets,
                      (const int*)nullptr, n, sboxes, (float*)nullptr, order);
   int rc = mega_nms_sorted((const float*)sboxes, counts, nullptr, order, 1, n, thr, strict_gt, n, keep_pos, keep_cnt,
@@ -931,10 +938,12 @@ extern "C" int mega_postprocess_batched(const float* logits, const float* deltas
   int* counts = (int*)w; w += align_up((size_t)P * 4, 256);
   int* keep_cnt = (int*)w; w += align_up((size_t)P * 4, 256);
   void* mws = w;
-  (void)hipMemsetAsync(flags, 0, m, st);
+  // (the kept flags are zeroed by post_prepare_kernel, one store per candidate it writes anyway: a hipMemsetAsync here
+  // becomes a memset NODE when the call is captured into a hipGraph, and a captured FGFA step whose graph holds that node
+  // produced history-dependent kept sets after a restart -- see NOTES, traps)
   hipLaunchKernelGGL(post_prepare_kernel, dim3(cdiv(R, 64), B), dim3(64), 0, st, logits, deltas, (const float4*)props,
                      nprop, R, NC, wx, wy, ww, wh, logf(1000.f / 16.f), im_w, im_h, score_thresh, cboxes, cscores,
-                     probs_out);
+                     probs_out, flags);
   hipLaunchKernelGGL(post_sort_kernel, dim3(P), dim3(256), 0, st, cboxes, cscores, R, sboxes, order, counts);
   int rc = mega_nms_sorted((const float*)sboxes, counts, nullptr, order, P, R, nms_thresh, strict_gt, R, keep_pos,
                            keep_cnt, flags, mws, mega_nms_workspace_bytes(P, R), stream);

@@ -450,6 +450,7 @@ class FgfaClipEngine(object):
         self.graph = None
         self.fgraphs = {}
         self.replays = 0
+        self.keep_intermediates = False      # tests / diagnostics: self._dbg = (flow, aggregated map, proposals, logits)
 
     # ---- features of a batch of frames (backbone + EmbedNet), replayed from a hipGraph per batch size
     def _features(self, imgs):
@@ -491,6 +492,8 @@ class FgfaClipEngine(object):
         x = box.feature_extractor(feats, [props[0]])
         logits, deltas = box.predictor(x)
         pp = box.post_processor
+        if self.keep_intermediates:
+            self._dbg = (flow, agg, props, logits, deltas, x, cnt)
         return ops.postprocess(logits.float().contiguous(), deltas.float().contiguous(), props[0].contiguous(), cnt,
                                pp.weights, W, H, pp.score_thresh, pp.nms, pp.detections_per_img, pp.strict_gt)
 
