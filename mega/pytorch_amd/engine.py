@@ -308,8 +308,8 @@ class ClipEngine(object):
 
     def records_async(self, clip, jobs, on_counts=None):
         """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
-        records_resolve().  on_counts: see _frame_stage (single-process path only; the sharded path's counts travel with
-        the gathered records)."""
+        records_resolve().  on_counts: see _frame_stage; in the sharded path the ranks' counts are all-gathered between the
+        two halves of the frame stage (one tiny collective) and handed to on_counts in job order."""
         if self.world == 1 and not self.force_sharded:
             return {"st": self._frame_stage(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs], on_counts)}
         # ---- sharded.  Jobs are grouped by their row count (local-window frames: key_num rows, global-pool frames:
@@ -320,7 +320,22 @@ class ClipEngine(object):
         plan, mine = self.shard_plan(jobs)
         mine_ids = [jobs[p][0] for p in mine]
         mine_want = [int(jobs[p][1]) for p in mine]
-        st = self._frame_stage(self._frames(clip, mine_ids), mine_want)
+        early = None
+        if on_counts is not None:
+            def early(c):      # this rank's counts -> every rank, re-ordered to job order (index table cached per plan)
+                nm = c.shape[0]
+                sig = (tuple(int(j[1]) for j in jobs), self.world, str(c.device))
+                tab = getattr(self, "_cnt_index", None)
+                if tab is None or tab[0] != sig:
+                    idx = [0] * len(jobs)
+                    for _, poss, per, first in plan:
+                        for slot, pos in enumerate(poss):
+                            idx[pos] = (slot // per) * nm + first + slot % per
+                    tab = self._cnt_index = (sig, torch.tensor(idx, dtype=torch.int64, device=c.device))
+                allc = torch.empty((self.world * nm,), dtype=c.dtype, device=c.device)
+                self.dist.all_gather_into_tensor(allc, c.contiguous(), group=self.group)
+                on_counts(allc.index_select(0, tab[1]))
+        st = self._frame_stage(self._frames(clip, mine_ids), mine_want, early)
         dev, D, fdt = st["props"].device, st["feats"].shape[1], st["feats"].dtype
         esz = st["feats"].element_size()
         got = {}
@@ -439,7 +454,7 @@ class ClipEngine(object):
                     early["cnt_host"].copy_(c, non_blocking=True)
                     early["cnt_ev"] = torch.cuda.Event()
                     early["cnt_ev"].record(sF)
-            h = self.records_async(clip, flat, on_counts)
+            h = self.records_async(clip, flat, on_counts if use_streams else None)
             h["jobs"] = flat
             h.update(early)
             if use_streams and "cnt_host" not in h:   # (sharded path: the counts arrive with the gathered records)
