@@ -573,7 +573,8 @@ class FgfaClipEngine(object):
             self.feat_ring[s].copy_(self.cache[fid])
             self.img_ring[s].copy_(frames[fid])
             self.window = self.window[1:] + [s]
-            self.order.copy_(torch.tensor([self.window[key]] + self.window, dtype=torch.int32).pin_memory(), non_blocking=True)
+            od = torch.tensor([self.window[key]] + self.window, dtype=torch.int32)
+            self.order.copy_(od.pin_memory() if self.order.is_cuda else od, non_blocking=True)
             pending.append(self._step((W, H)))
             idx += 1
             if len(pending) >= sync_every:

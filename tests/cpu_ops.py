@@ -86,7 +86,11 @@ def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh,
                 strict_gt=True, want_probs=False):
     cfg = mo.OracleCfg(score_thresh=score_thresh, nms=nms_thresh, detections_per_img=max_det,
                        bbox_reg_weights=tuple(weights), nms_strict_gt=strict_gt, num_classes=logits.shape[1])
-    b, s, l = mo.postprocess(logits, deltas, props, im_w, im_h, cfg)
+    if nprop is not None:        # rows past the (device-side) proposal count are not proposals
+        n_live = min(int(nprop.reshape(-1)[0]), logits.shape[0])
+        b, s, l = mo.postprocess(logits[:n_live], deltas[:n_live], props[:n_live], im_w, im_h, cfg)
+    else:
+        b, s, l = mo.postprocess(logits, deltas, props, im_w, im_h, cfg)
     cap = (logits.shape[1] - 1) * logits.shape[0]
     ob, os_, ol = torch.zeros((cap, 4)), torch.zeros((cap,)), torch.zeros((cap,), dtype=torch.int64)
     n = b.shape[0]

@@ -157,6 +157,53 @@ def test_fgfa_detector_matches_oracle(monkeypatch):
         assert (det.get_field("scores") - ws).abs().max() < 1e-5
 
 
+def test_fgfa_clip_engine_equals_model_on_cpu_twins(monkeypatch):
+    """fgfa.FgfaClipEngine's host logic -- features of upcoming frames in look-ahead batches, the window in rings with a
+    rotating slot table, the cold-start fill, the end-of-video clamp, restart on a second video -- against
+    GeneralizedRCNNFGFA.forward frame by frame, on the CPU twins (no graphs here; the GPU test covers the graph)."""
+    from mega.pytorch_amd import fgfa as fgfa_mod
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    H, W, L, nkey = 64, 96, 9, 9
+    cfg = config.get_cfg("R-50", "fgfa")
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.VID.FGFA.ALL_FRAME_INTERVAL, cfg.MODEL.VID.FGFA.KEY_FRAME_LOCATION = 7, 3
+    cfg.MODEL.VID.FGFA.MIN_OFFSET, cfg.MODEL.VID.FGFA.MAX_OFFSET = -3, 3
+    cfg.MODEL.RPN.POST_NMS_TOP_N_TEST = 40
+    sd = synth.make_fgfa_state_dict(seed=3)
+    m1, m2 = modeling.build_detection_model(cfg), modeling.build_detection_model(cfg)
+    m1.load_state_dict(sd)
+    m2.load_state_dict(sd)
+    frames = synth.preprocess_cpu(synth.make_clip(L, H, W, seed=6))
+    eng = fgfa_mod.FgfaClipEngine(m2, lookahead=2, graphs=False)
+    with torch.no_grad():
+        got = eng.run(frames, first=0, last=nkey)
+        assert len(got) == nkey
+        for idx in range(nkey):          # the window is 7 frames, the video 9: the last 3 key frames see the clamped tail
+            images = {"cur": frames[idx], "ref": [frames[min(L - 1, idx + 3)]], "frame_category": 0 if idx == 0 else 1,
+                      "seg_len": L, "ref_init": [frames[i] for i in range(1, 4)]}
+            ref = m1(images)[0]
+            # the CPU twins are not batch-invariant to the last bit (MKL): a detection whose score sits within round-off
+            # of SCORE_THRESH may exist on one side only -- everything clear of the threshold must match one to one
+            def unmatched(a, b):
+                n = 0
+                for k in range(len(a)):
+                    s_ = a.get_field("scores")[k]
+                    if s_ < 0.001 + 2e-5:
+                        continue
+                    hit = (b.get_field("labels") == a.get_field("labels")[k]) & ((b.get_field("scores") - s_).abs() < 1e-5) \
+                        & ((b.bbox - a.bbox[k]).abs().max(dim=1).values < 1e-3)
+                    n += 0 if bool(hit.any()) else 1
+                return n
+            # (and a 1e-6 difference in the aggregated map can flip a near-tie in the per-class NMS: measured 0 unmatched on
+            # 8 of 9 key frames, 3 on one; the GPU kernels are batch-invariant and the GPU test is bit-exact)
+            assert abs(len(ref) - len(got[idx])) <= 2, (idx, len(ref), len(got[idx]))
+            assert unmatched(ref, got[idx]) <= 4 and unmatched(got[idx], ref) <= 4, idx
+        again = eng.run(frames, first=0, last=3)
+    for a, b in zip(again, got[:3]):
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("labels"), b.get_field("labels"))
+
+
 def test_base_detector_matches_oracle(monkeypatch):
     """single-frame GeneralizedRCNN (BASELINE config 1) on the CPU twins == BaseOracle."""
     cpu_ops.install(monkeypatch)
