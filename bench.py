@@ -433,10 +433,13 @@ def main():
             fam[k] = {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": round(v["launches"] / prof_steps, 1),
                       "tflops": round(v["flops"] / (v["ms"] * 1e9), 2) if v["ms"] > 0 else 0.0,
                       "gbps": round(v["bytes"] / (v["ms"] * 1e6), 1) if v["ms"] > 0 else 0.0}
-        # dominant kernel = the igemm instantiation (one rocprofv3 kernel symbol) with the largest share of GPU time
+        # dominant kernel = the igemm instantiation (one rocprofv3 kernel symbol) with the largest share of GPU time.
+        # igemm8's streaming launch class ("igemm8s_*": 1x1 layers with K <= 512, bound by HBM / the CU fetch rate) is its
+        # own symbol and is reported in roofline_hbm; the MFMA roofline is taken over the matrix-core-bound symbols.
         tag = "bf16" if args.dtype == "bfloat16" else "f32"
-        igemms = {k: v for k, v in summ.items() if k.startswith(("igemm_" + tag, "igemm8_" + tag))}
-        dom = max(igemms, key=lambda k: igemms[k]["ms"])
+        igemms = {k: v for k, v in summ.items() if k.startswith(("igemm_" + tag, "igemm8_" + tag, "igemm8s_" + tag))}
+        mm = {k: v for k, v in igemms.items() if not k.startswith("igemm8s_")}
+        dom = max(mm, key=lambda k: mm[k]["ms"])
         tile = dom.rsplit("_", 1)[1].split("x")
         is8 = dom.startswith("igemm8_")
         peak = 2500.0 if args.dtype == "bfloat16" else 157.3
@@ -449,8 +452,8 @@ def main():
         # the number is read from the newest committed summary and labelled with its source -- it is a property of that
         # profiled run of this code, not of this run.
         traffic, traffic_src = None, None
-        if is8:       # igemm8_kernel<OT, MF1>: MF1 = 2 (256-row tile) or 1 (192-row tile)
-            sym = "igemm8_kernel<bf16, %d>" % (2 if tile[0] == "256" else 1)
+        if is8:       # igemm8_kernel<OT, MF1, CLS>: MF1 = 2 (256-row tile) or 1 (192-row tile), CLS 0 = matrix-core-bound
+            sym = "igemm8_kernel<bf16, %d, 0>" % (2 if tile[0] == "256" else 1)
         else:
             sym = "igemm_kernel<%s, %s, %s, %s>" % (tag if tag == "bf16" else "float", tag if tag == "bf16" else "float",
                                                     tile[0], tile[1])
@@ -459,6 +462,9 @@ def main():
             if os.path.exists(pmc):
                 ks = json.load(open(pmc))["kernels"]
                 k = next((v for name, v in ks.items() if name.replace(" ", "").startswith(sym.replace(" ", "")[:-1])), None)
+                if k is None and is8:      # summaries written before the launch-class split: <OT, MF1, ABL>
+                    old = ("igemm8_kernel<bf16,%d" % (2 if tile[0] == "256" else 1))
+                    k = next((v for name, v in ks.items() if name.replace(" ", "").startswith(old)), None)
                 if k:
                     traffic, traffic_src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/%s_pmc_summary.json" % rnd
                     break
@@ -496,6 +502,8 @@ def main():
             except Exception:    # noqa: BLE001
                 return None
         conv = lambda f: f.startswith("igemm")      # noqa: E731
+        hbm_entry("igemm8 streaming class (1x1 layers with K <= 512: layer3 conv3, res5 conv3, layer2 / layer3 projections)",
+                  lambda f, d_: f.startswith("igemm8s_"))
         hbm_entry("stem 7x7/2 conv + BN + ReLU", lambda f, d_: f == "stem")
         hbm_entry("max-pool 3x3/2", lambda f, d_: f == "maxpool")
         hbm_entry("layer1 convs (Cin or Cout = 64)", lambda f, d_: conv(f) and shape_of(d_) is not None

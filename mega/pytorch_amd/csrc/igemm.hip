@@ -345,10 +345,11 @@ inline void choose_tile(int M, int Cout, int K, int z, bool bf16, int& kind, int
   const long b128 = (long)cdiv(M, 128) * cdiv(Cout, 128) * z;
   const long b12864 = (long)cdiv(M, 128) * cdiv(Cout, 64) * z;
   static const int use8 = getenv("MEGA_IGEMM8") ? atoi(getenv("MEGA_IGEMM8")) : 1;
-  // K = 64 (one K-tile: layer1's 64 -> 256 convs) runs on igemm8 too, bit-identically and 8 % faster (0.164 -> 0.151 ms),
-  // but those launches are pure streaming (HBM-bound epilogues); they stay on the 128x128 tiles by default so that the
-  // igemm8 symbols in a profile remain the matrix-core-bound layers.  MEGA_IGEMM8_MIN_KTILES=1 sends them over.
-  static const int min_kt = getenv("MEGA_IGEMM8_MIN_KTILES") ? atoi(getenv("MEGA_IGEMM8_MIN_KTILES")) : 2;
+  // K = 64 (one K-tile: layer1's 64 -> 256 convs) runs on igemm8 too, bit-identically and 8 % faster (0.164 -> 0.151 ms
+  // per 20 frames each).  Rounds 1-2 kept them on the 128x128 tiles so that the igemm8 symbols of a profile stayed the
+  // matrix-core-bound layers; since round 3 the streaming layers have their own igemm8 symbol (CLS = 1), so they go over by
+  // default (MEGA_IGEMM8_MIN_KTILES=2 restores the old dispatch).
+  static const int min_kt = getenv("MEGA_IGEMM8_MIN_KTILES") ? atoi(getenv("MEGA_IGEMM8_MIN_KTILES")) : 1;
   if (bf16 && use8 && Cout >= 256 && K >= 64 * min_kt) {
     // igemm8 runs one block per CU: pick the row count that wastes the fewest CU-rounds (cost ~ rounds x rows)
     const long t256 = (long)cdiv(M, 256) * cdiv(Cout, 256) * z, t192 = (long)cdiv(M, 192) * cdiv(Cout, 256) * z;
@@ -393,6 +394,8 @@ extern "C" int mega_conv2d_nhwc_plan(int M, int Cout, int K, int in_dtype) {
     return 6 * 1000000 + 256 * 1000 + 64;
   choose_tile(M, Cout, K, choose_ksplit(K), in_dtype == MEGA_BF16, kind, bm, bn);
   if (kind == 8 && (K >> 6) < 1) { kind = 0; bm = 128; bn = 128; }
+  // kind 7 = igemm8's streaming class (K <= 512 implies a 1x1 layer here: Cin is a multiple of 64, so a 3x3 has K >= 576)
+  if (kind == 8 && mega_igemm8_streaming(1, K) && choose_ksplit(K) == 1) kind = 7;
   return kind * 1000000 + bm * 1000 + bn;
 }
 

@@ -52,7 +52,12 @@ struct KPos {
 // ABL != 0: timing-only ablations for tools/gpu (1: no fragment ds_reads in the loop, 2: no DMA in the loop, 3: no MFMA);
 // results are garbage by construction.  Only ABL = 0 is instantiated unless the library is built with
 // -DMEGA_EXPERIMENTS (see mega_igemm8_launch).
-template <typename OT, int MF1, int ABL = 0>
+// CLS: launch class, part of the symbol only (the code is the same): 0 = matrix-core-bound layers (3x3 convs and every
+// layer with more than 8 K-tiles), 1 = streaming layers (1x1 convs / linears with K <= 512: at most 8 K-tiles per output
+// tile, so prologue, epilogue and the operand fetch set their time -- layer3's conv3, res5's conv3, layer2's 1x1s).  The
+// two classes sit under different roofs (MFMA vs HBM / CU fetch rate); as ONE symbol their rocprofv3 average blends
+// 1290 TF/s (RPN conv) with 480 TF/s (layer3 conv3) and says nothing about either.
+template <typename OT, int MF1, int CLS = 0, int ABL = 0>
 __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   constexpr int BM = 128 + 64 * MF1;
   constexpr int BN = 256;
@@ -452,17 +457,20 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #undef MEGA_STAMP
 }
 
-template <typename OT, int MF1, int ABL = 0>
+template <typename OT, int MF1, int CLS = 0, int ABL = 0>
 int launch8(const ConvParams& p, hipStream_t st) {
   constexpr int BM = 128 + 64 * MF1;
   const int ntm = cdiv(p.M, BM), ntn = cdiv(p.Cout, 256);
   // set on every launch (a per-process flag would miss the second device of a multi-GPU process)
-  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
-  hipLaunchKernelGGL((igemm8_kernel<OT, MF1, ABL>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8, st, p);
+  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1, CLS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+  hipLaunchKernelGGL((igemm8_kernel<OT, MF1, CLS, ABL>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8, st, p);
   return mega_check_launch();
 }
 
 }  // namespace
+
+// the streaming launch class of igemm8_kernel's CLS parameter (see there)
+int mega_igemm8_streaming(int taps, int K) { return taps == 1 && K <= 512; }
 
 int mega_igemm8_supports(const ConvParams& p) {
   // capability (a single K-tile works: the ring's second tile is then all zeros); which shapes are SENT here by default
@@ -477,15 +485,15 @@ int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st)
   // built with MEGA_BUILD_EXPERIMENTS=1 (mega/pytorch_amd/build.py adds -DMEGA_EXPERIMENTS).
   static const int abl = getenv("MEGA_IGEMM8_ABLATE") ? atoi(getenv("MEGA_IGEMM8_ABLATE")) : 0;
   if (abl && bm == 256 && !out_f32) {
-    if (abl == 1) return launch8<bf16_t, 2, 1>(p, st);
-    if (abl == 2) return launch8<bf16_t, 2, 2>(p, st);
-    if (abl == 3) return launch8<bf16_t, 2, 3>(p, st);
+    if (abl == 1) return launch8<bf16_t, 2, 0, 1>(p, st);
+    if (abl == 2) return launch8<bf16_t, 2, 0, 2>(p, st);
+    if (abl == 3) return launch8<bf16_t, 2, 0, 3>(p, st);
     if (abl == 4) {          // timeline of block 0: 12 stamps per K-tile per wave, first 8 K-tiles
       static unsigned long long* d_tr = nullptr;
       if (!d_tr) (void)hipMalloc(&d_tr, 8 * 96 * sizeof(unsigned long long));
       ConvParams q = p;
       q.partial = reinterpret_cast<float*>(d_tr);
-      const int rc = launch8<bf16_t, 2, 4>(q, st);
+      const int rc = launch8<bf16_t, 2, 0, 4>(q, st);
       (void)hipStreamSynchronize(st);
       static unsigned long long h[8 * 96];
       (void)hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost);
@@ -506,6 +514,9 @@ int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st)
     }
   }
 #endif
+  const bool stream = mega_igemm8_streaming(p.R * p.S, p.K) && p.ksplit == 1;
+  if (bm == 256 && stream) return out_f32 ? launch8<float, 2, 1>(p, st) : launch8<bf16_t, 2, 1>(p, st);
+  if (bm == 192 && stream) return out_f32 ? launch8<float, 1, 1>(p, st) : launch8<bf16_t, 1, 1>(p, st);
   if (bm == 256) return out_f32 ? launch8<float, 2>(p, st) : launch8<bf16_t, 2>(p, st);
   if (bm == 192) return out_f32 ? launch8<float, 1>(p, st) : launch8<bf16_t, 1>(p, st);
   return MEGA_ERR_ARG;

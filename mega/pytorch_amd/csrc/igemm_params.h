@@ -23,6 +23,8 @@ struct ConvParams {
 int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st);
 // 1 when the shape is one igemm8 can take (bf16, Cin % 64 == 0, operands < 2 GiB, ...)
 int mega_igemm8_supports(const ConvParams& p);
+// 1 when a launch of `taps` = R * S kernel taps and GEMM depth K belongs to igemm8's streaming class (1x1, K <= 512)
+int mega_igemm8_streaming(int taps, int K);
 // conv64.hip: persistent 3x3 / 64 -> 64 channel kernel (layer1's conv2); bit-identical to the generic tiles
 int mega_conv64_supports(const ConvParams& p, int out_f32);
 int mega_conv64_launch(const ConvParams& p, hipStream_t st);

@@ -306,6 +306,16 @@ class ClipEngine(object):
             mine += padded[rank * per:(rank + 1) * per]
         return plan, mine
 
+    @staticmethod
+    def count_index(plan, njobs, nm):
+        """Where job p's proposal count sits in the all-gathered count vector [world x nm] (nm = frames per rank and
+        launch): the job in slot s of its group was computed by rank s // per as frame first + s % per of that rank's launch."""
+        idx = [0] * njobs
+        for _, poss, per, first in plan:
+            for slot, pos in enumerate(poss):
+                idx[pos] = (slot // per) * nm + first + slot % per
+        return idx
+
     def records_async(self, clip, jobs, on_counts=None):
         """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
         records_resolve().  on_counts: see _frame_stage; in the sharded path the ranks' counts are all-gathered between the
@@ -327,11 +337,8 @@ class ClipEngine(object):
                 sig = (tuple(int(j[1]) for j in jobs), self.world, str(c.device))
                 tab = getattr(self, "_cnt_index", None)
                 if tab is None or tab[0] != sig:
-                    idx = [0] * len(jobs)
-                    for _, poss, per, first in plan:
-                        for slot, pos in enumerate(poss):
-                            idx[pos] = (slot // per) * nm + first + slot % per
-                    tab = self._cnt_index = (sig, torch.tensor(idx, dtype=torch.int64, device=c.device))
+                    tab = self._cnt_index = (sig, torch.tensor(self.count_index(plan, len(jobs), nm), dtype=torch.int64,
+                                                               device=c.device))
                 allc = torch.empty((self.world * nm,), dtype=c.dtype, device=c.device)
                 self.dist.all_gather_into_tensor(allc, c.contiguous(), group=self.group)
                 on_counts(allc.index_select(0, tab[1]))

@@ -97,7 +97,8 @@ def _igemm_family(lib, M, Cout, K, dtype):
     kind, t = t // 1000000, t % 1000000
     if kind == 6:
         return "conv64_bf16_3x3"
-    return "igemm%s_%s_%dx%d" % ("8" if kind == 8 else "", "bf16" if dtype == torch.bfloat16 else "f32", t // 1000, t % 1000)
+    return "igemm%s_%s_%dx%d" % ({8: "8", 7: "8s"}.get(kind, ""), "bf16" if dtype == torch.bfloat16 else "f32", t // 1000,
+                                 t % 1000)
 
 
 def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,

@@ -93,6 +93,17 @@ def test_prefetch_slice_is_the_frame_stage_slice():
                 poss = [p for p, j in enumerate(jobs) if int(j[1]) == want]
                 got = [slots[i] for i in range(len(slots))]
                 assert got[:len(poss)] == poss and all(p == poss[-1] for p in got[len(poss):])
+            # the early count all-gather: rank r sends the counts of ITS launch (here: the job position itself, as a
+            # stand-in); count_index must pick every job's own count out of the concatenation of the ranks' vectors
+            vecs = []
+            for rank in range(world):
+                plan_r, mine_r = eng.shard_plan(jobs, rank=rank, world=world)
+                vecs.append(list(mine_r))
+            nm = len(vecs[0])
+            assert all(len(v) == nm for v in vecs)
+            flat = [x for v in vecs for x in v]
+            idx = eng.count_index(eng.shard_plan(jobs, rank=0, world=world)[0], len(jobs), nm)
+            assert [flat[i] for i in idx] == list(range(len(jobs)))
     # and run()'s prefetch asks the source for exactly those frames
     asked = []
 
