@@ -367,27 +367,35 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     sc[j] = (p.ksplit == 1 && p.scale && n < p.Cout) ? p.scale[n] : 1.f;
     bi[j] = (p.ksplit == 1 && p.bias && n < p.Cout) ? p.bias[n] : 0.f;
   }
-  // The residual rows are fetched at the START of each slab pass (before the accumulators go through LDS), so the HBM
-  // latency of these loads overlaps the staging instead of sitting, four dependent loads per thread, in the read-out
-  // loop (the 1x1 "conv3 + residual" layers are HBM-bound: their epilogue is most of their time).
+  // The residual rows are requested TWO slabs at a time, before the first of the pair goes through LDS (the fragment
+  // registers of the K loop are dead by now): every __syncthreads() of the slab loop waits for outstanding global loads,
+  // so with per-slab requests (round 2) a tile paid one exposed HBM round trip per slab -- four per 256-row tile; now
+  // two (all four at once needs 64 registers and spills).  The 1x1 "conv3 + residual" layers are HBM-bound: their
+  // epilogue is most of their time.
   constexpr int NIT = 64 * VPR / NT8;                  // 16-byte output vectors per thread per slab (4 bf16 / 8 f32)
   const bool res_vec = res != nullptr && vec_ok && sizeof(OT) == 2 && p.ksplit == 1;
+  uint4 rres2[2][NIT];
+  auto load_res = [&](int i, int f, uint4 (&dst)[NIT]) {
+    const int wrows = i == 1 ? WROWS1 : 64;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * NT8;
+      const int row = e / VPR, cv = e - row * VPR;
+      const int m = m0 + i * 128 + (row >> 5) * wrows + f * 32 + (row & 31), n = n0 + cv * OVE;
+      dst[it] = make_uint4(0, 0, 0, 0);
+      if (m < p.M && n + OVE <= p.Cout) dst[it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
+    }
+  };
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int f = 0; f < (i == 1 ? MF1 : 2); ++f) {
       const int wrows = i == 1 ? WROWS1 : 64;          // rows per wave row inside this A half
-      uint4 rres[NIT];
-      if (res_vec) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int e = tid + it * NT8;
-          const int row = e / VPR, cv = e - row * VPR;
-          const int m = m0 + i * 128 + (row >> 5) * wrows + f * 32 + (row & 31), n = n0 + cv * OVE;
-          rres[it] = make_uint4(0, 0, 0, 0);
-          if (m < p.M && n + OVE <= p.Cout) rres[it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
-        }
+      if (res_vec && f == 0) {                         // slabs (i, 0) and (i, 1) of this A half
+        load_res(i, 0, rres2[0]);
+        if (i == 0 || MF1 == 2) load_res(i, 1, rres2[1]);
       }
+      const uint4 (&rres)[NIT] = rres2[f];
       if (i + f > 0) __syncthreads();                  // the previous slab has been read out
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
