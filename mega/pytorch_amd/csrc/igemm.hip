@@ -230,6 +230,87 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
     sc[j] = (p.ksplit == 1 && p.scale && n < p.Cout) ? p.scale[n] : 1.f;
     bi[j] = (p.ksplit == 1 && p.bias && n < p.Cout) ? p.bias[n] : 0.f;
   }
+  // ---- fast path (Cout a multiple of the tile width, output below 2 GiB -- every layer of the frame stage): buffer
+  //      loads / stores with the hardware range check instead of per-vector bounds branches.  With branches in the
+  //      read-out loop hipcc merges the wait counts at every join into vmcnt(0), so each 16-byte store waited for
+  //      the previous one to be acknowledged and each residual vector was an exposed round trip; straight-line code
+  //      keeps the counts exact, the residual rows are a rolling (two-slab) prefetch and the stores drain behind the
+  //      next slab's staging (barriers wait for LDS traffic only).
+  constexpr bool RES_FAST = 64 * VPR / NTHREADS <= 8;  // (f32 256-wide tiles: 16 residual vectors per slab would spill)
+  const bool fast = vec_ok && p.ksplit == 1 && n0 + BN <= p.Cout &&
+                    ((size_t)(p.M - 1) * p.ldo + p.Cout) * sizeof(OT) < 0x7FF00000ull &&
+                    (res == nullptr || (RES_FAST && ((size_t)(p.M - 1) * p.ldr + p.Cout) * sizeof(T) < 0x7FF00000ull));
+  if (fast) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)(((size_t)(p.M - 1) * p.ldo + p.Cout) * sizeof(OT)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.res ? p.res : p.out), 0, res ? (int)(((size_t)(p.M - 1) * p.ldr + p.Cout) * sizeof(T)) : 0,
+        0x00020000);
+    constexpr int NIT = 64 * VPR / NTHREADS;           // 16-byte vectors per thread per slab
+    constexpr int RSTEP = NTHREADS / VPR;              // slab rows between a thread's consecutive vectors
+    static_assert(NIT >= 1 && NIT * NTHREADS == 64 * VPR, "slab vectors must divide evenly");
+    const int row0 = tid / VPR, cvo = (tid % VPR) * OVE, ncol = n0 + cvo;
+    auto slab_m = [&](int i, int it) {
+      const int row = row0 + it * RSTEP;
+      return m0 + (row >> 5) * WTM + i * 32 + (row & 31);
+    };
+    auto run = [&](auto HR) {
+      constexpr bool HAS_RES = decltype(HR)::value;
+      constexpr int PD = 2;                          // slabs of residual rows in flight
+      u32x4_t rr[PD][HAS_RES ? NIT : 1];
+      auto ldres = [&](int i, u32x4_t (&dst)[HAS_RES ? NIT : 1]) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, (unsigned)(slab_m(i, it) * p.ldr + ncol) * (unsigned)sizeof(T), 0, 0);
+      };
+      if (HAS_RES) {
+        ldres(0, rr[0]);
+        if (PD > 1 && TM > 1) ldres(1, rr[PD - 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (i > 0) {                                   // the previous slab has been read out
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nl = wn * WTN + j * 32 + (lane & 31);
+          const int rb = wm * 32 + 4 * (lane >> 5);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][j][r] * sc[j] + bi[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int row = row0 + it * RSTEP;
+          float v[OVE];
+#pragma unroll
+          for (int t = 0; t < OVE; t += 4) {
+            const float4 f = *reinterpret_cast<const float4*>(cs + row * CST + cvo + t);
+            v[t] = f.x; v[t + 1] = f.y; v[t + 2] = f.z; v[t + 3] = f.w;
+          }
+          if (HAS_RES) {
+            const T* re = reinterpret_cast<const T*>(&rr[i % PD][it]);
+#pragma unroll
+            for (int t = 0; t < OVE; ++t) v[t] += Elem<T>::ld(re + t);
+          }
+          u32x4_t o;
+          OT* oe = reinterpret_cast<OT*>(&o);
+#pragma unroll
+          for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, act(v[t]));
+          __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (unsigned)(slab_m(i, it) * p.ldo + ncol) * (unsigned)sizeof(OT), 0, 0);
+        }
+        if (HAS_RES && i + PD < TM) ldres(i + PD, rr[i % PD]);   // slab i + PD into the registers slab i just freed
+      }
+    };
+    if (res) run(std::integral_constant<bool, RES_FAST>{}); else run(std::false_type{});
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (i > 0) __syncthreads();               // the previous slab has been read out

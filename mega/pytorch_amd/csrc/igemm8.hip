@@ -57,6 +57,8 @@ struct KPos {
 // tile, so prologue, epilogue and the operand fetch set their time -- layer3's conv3, res5's conv3, layer2's 1x1s).  The
 // two classes sit under different roofs (MFMA vs HBM / CU fetch rate); as ONE symbol their rocprofv3 average blends
 // 1290 TF/s (RPN conv) with 480 TF/s (layer3 conv3) and says nothing about either.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
 template <typename OT, int MF1, int CLS = 0, int ABL = 0>
 __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   constexpr int BM = 128 + 64 * MF1;
@@ -367,11 +369,13 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     sc[j] = (p.ksplit == 1 && p.scale && n < p.Cout) ? p.scale[n] : 1.f;
     bi[j] = (p.ksplit == 1 && p.bias && n < p.Cout) ? p.bias[n] : 0.f;
   }
-  // The residual rows are requested TWO slabs at a time, before the first of the pair goes through LDS (the fragment
-  // registers of the K loop are dead by now): every __syncthreads() of the slab loop waits for outstanding global loads,
-  // so with per-slab requests (round 2) a tile paid one exposed HBM round trip per slab -- four per 256-row tile; now
-  // two (all four at once needs 64 registers and spills).  The 1x1 "conv3 + residual" layers are HBM-bound: their
-  // epilogue is most of their time.
+  // The slab loop's barriers are raw s_barrier + lgkmcnt(0) (LDS traffic only), NOT __syncthreads(): a __syncthreads()
+  // is also a vmcnt(0) fence, which made every slab wait for its own global stores to be acknowledged and for every
+  // residual load in flight -- four exposed HBM round trips per 256-row tile (round 2), two with the residual rows
+  // requested per slab pair (first half of round 3).  Now stores drain behind the next slab's staging and the residual
+  // rows are a rolling two-slab prefetch: slab s+2's rows are requested into slab s's registers as soon as slab s is
+  // written (the K loop's fragment registers are dead here; all four at once would need 64 registers and spill).  The
+  // 1x1 "conv3 + residual" layers are HBM-bound: the epilogue is most of their time.
   constexpr int NIT = 64 * VPR / NT8;                  // 16-byte output vectors per thread per slab (4 bf16 / 8 f32)
   const bool res_vec = res != nullptr && vec_ok && sizeof(OT) == 2 && p.ksplit == 1;
   uint4 rres2[2][NIT];
@@ -386,17 +390,89 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
       if (m < p.M && n + OVE <= p.Cout) dst[it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
     }
   };
+  // ---- fast path (every bf16 / f32 layer whose Cout is a multiple of 256 and whose output is below 2 GiB: all of the
+  //      frame stage): buffer loads / stores with the hardware range check instead of per-vector bounds branches.  With
+  //      branches in the read-out loop hipcc merges the wait counts at every join into vmcnt(0) -- each 16-byte store
+  //      then waited for the previous one to be acknowledged, four serialized round trips per slab.  Straight-line code
+  //      keeps the counts exact: the stores of a slab go out back to back and drain behind the next slab's staging.
+  const bool fast = vec_ok && p.ksplit == 1 && n0 + BN <= p.Cout && (res == nullptr || sizeof(OT) == 2) &&
+                    ((size_t)(p.M - 1) * p.ldo + p.Cout) * sizeof(OT) < 0x7FF00000ull &&
+                    (res == nullptr || ((size_t)(p.M - 1) * p.ldr + p.Cout) * 2 < 0x7FF00000ull);
+  if (fast) {
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)(((size_t)(p.M - 1) * p.ldo + p.Cout) * sizeof(OT)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.res ? p.res : p.out), 0, res ? (int)(((size_t)(p.M - 1) * p.ldr + p.Cout) * 2) : 0, 0x00020000);
+    constexpr int RSTEP = NT8 / VPR;                   // slab rows between a thread's consecutive vectors
+    const int row0 = tid / VPR, ncol = n0 + (tid % VPR) * OVE;
+    auto slab_m = [&](int i, int f, int it) {
+      const int row = row0 + it * RSTEP;
+      return m0 + i * 128 + (row >> 5) * (i == 1 ? WROWS1 : 64) + f * 32 + (row & 31);
+    };
+    auto run = [&](auto HR) {
+      constexpr bool HAS_RES = decltype(HR)::value;
+      u32x4_t rr[2][NIT];
+      auto ldres = [&](int i, int f, u32x4_t (&dst)[NIT]) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, (unsigned)(slab_m(i, f, it) * p.ldr + ncol) * 2u, 0, 0);
+      };
+      if (HAS_RES) {
+        ldres(0, 0, rr[0]);
+        ldres(0, 1, rr[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int f = 0; f < (i == 1 ? MF1 : 2); ++f) {
+          if (i + f > 0) { MEGA_WAIT_LDS(); MEGA_BAR(); }    // the previous slab has been read out
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int nl = j * 128 + wc * 32 + l31;
+            const int rb = wr * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][f][j][r] * sc[j] + bi[j];
+          }
+          MEGA_WAIT_LDS();
+          MEGA_BAR();
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int row = row0 + it * RSTEP;
+            float v[OVE];
+#pragma unroll
+            for (int t = 0; t < OVE; t += 4) {
+              const float4 q4 = *reinterpret_cast<const float4*>(cs + row * CST + (tid % VPR) * OVE + t);
+              v[t] = q4.x; v[t + 1] = q4.y; v[t + 2] = q4.z; v[t + 3] = q4.w;
+            }
+            if (HAS_RES) {
+              const bf16_t* re = reinterpret_cast<const bf16_t*>(&rr[f][it]);
+#pragma unroll
+              for (int t = 0; t < OVE; ++t) v[t] += bf16_to_f32(re[t]);
+            }
+            u32x4_t o;
+            OT* oe = reinterpret_cast<OT*>(&o);
+#pragma unroll
+            for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, act(v[t]));
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (unsigned)(slab_m(i, f, it) * p.ldo + ncol) * (unsigned)sizeof(OT), 0, 0);
+          }
+          if (HAS_RES && i == 0 && f < MF1) ldres(1, f, rr[f]);   // slab s + 2 into the registers slab s just freed
+        }
+      }
+    };
+    if (res) run(std::true_type{}); else run(std::false_type{});
+    return;
+  }
+  if (res_vec) {
+    load_res(0, 0, rres2[0]);
+    load_res(0, 1, rres2[1]);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int f = 0; f < (i == 1 ? MF1 : 2); ++f) {
       const int wrows = i == 1 ? WROWS1 : 64;          // rows per wave row inside this A half
-      if (res_vec && f == 0) {                         // slabs (i, 0) and (i, 1) of this A half
-        load_res(i, 0, rres2[0]);
-        if (i == 0 || MF1 == 2) load_res(i, 1, rres2[1]);
-      }
-      const uint4 (&rres)[NIT] = rres2[f];
-      if (i + f > 0) __syncthreads();                  // the previous slab has been read out
+      uint4 (&rres)[NIT] = rres2[f];
+      if (i + f > 0) { MEGA_WAIT_LDS(); MEGA_BAR(); }  // the previous slab has been read out
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int nl = j * 128 + wc * 32 + l31;
@@ -404,7 +480,8 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][f][j][r] * sc[j] + bi[j];
       }
-      __syncthreads();
+      MEGA_WAIT_LDS();
+      MEGA_BAR();
       if (p.ksplit > 1) {                              // raw partial sums; splitk_finalize_kernel (igemm.hip) finishes
         float* part = p.partial + (size_t)blockIdx.z * p.M * p.Cout;
         for (int e = tid; e < 64 * (BN / 4); e += NT8) {
@@ -454,6 +531,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
           }
         }
       }
+      if (res_vec && i == 0 && f < MF1) load_res(1, f, rres);   // slab s + 2 into the registers slab s just freed
     }
   }
 #undef MEGA_LDS_RD
