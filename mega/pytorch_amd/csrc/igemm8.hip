@@ -59,6 +59,25 @@ struct KPos {
 // 1290 TF/s (RPN conv) with 480 TF/s (layer3 conv3) and says nothing about either.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
+// ABL == 5: whole-tile timeline of EVERY block (waves 0 and 4, one per MFMA group): 16 u64 slots per wave in p.partial
+// (tools/gpu/timeline8.py): s_memtime (shader cycles) at 0 entry, 1 K loop starts, 2 K loop done, 3 + 2s slab s staged,
+// 4 + 2s slab s stores issued, 11 stores acknowledged; 12 = HW_ID | XCC_ID << 32; 13 / 14 = s_memrealtime (100 MHz) at
+// entry / end.  The results stay correct.
+#define MEGA_TS(k)                                                                                                      \
+  do {                                                                                                                  \
+    if (ABL == 5 && (wave & 3) == 0) {                                                                                  \
+      const unsigned long long tt = __builtin_amdgcn_s_memtime();                                                       \
+      if (lane == 0) reinterpret_cast<unsigned long long*>(p.partial)[((size_t)blockIdx.x * 2 + (wave >> 2)) * 16 + (k)] = tt; \
+    }                                                                                                                   \
+  } while (0)
+#define MEGA_TS_RT(k)                                                                                                   \
+  do {                                                                                                                  \
+    if (ABL == 5 && (wave & 3) == 0) {                                                                                  \
+      const unsigned long long tt = __builtin_amdgcn_s_memrealtime();                                                   \
+      if (lane == 0) reinterpret_cast<unsigned long long*>(p.partial)[((size_t)blockIdx.x * 2 + (wave >> 2)) * 16 + (k)] = tt; \
+    }                                                                                                                   \
+  } while (0)
+
 template <typename OT, int MF1, int CLS = 0, int ABL = 0>
 __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   constexpr int BM = 128 + 64 * MF1;
@@ -71,6 +90,8 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  MEGA_TS(0);
+  MEGA_TS_RT(13);
 
   // ---- XCD-aware block -> tile map (bijective for any grid size): the blocks of one XCD walk N first, so they share
   //      A row panels in that XCD's L2
@@ -335,6 +356,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     MEGA_STAMP();
   };
 
+  MEGA_TS(1);
   const int nkt2 = (nkt + 1) & ~1;     // an odd tail tile is computed on all-zero operands (its DMAs are out of range)
   for (int t = 0; t < nkt2; t += 2) {
     tile_phases(std::integral_constant<int, 0>{});
@@ -347,6 +369,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   if (wr == 0) MEGA_BAR();             // group 0 waits for group 1's last MFMA segment
   MEGA_WAIT_VM(0);                     // the out-of-range tail DMAs also write (zeros) into the LDS re-used below
   MEGA_BAR();
+  MEGA_TS(2);
 
   // ---- epilogue: accumulators (lane owns column lane & 31, rows (r&3) + 8 (r>>2) + 4 (lane>>5) of a 32 x 32
   //      fragment) are scaled / biased and staged through LDS as f32, one 64-row slab per (A half, M fragment) --
@@ -435,6 +458,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
           }
           MEGA_WAIT_LDS();
           MEGA_BAR();
+          MEGA_TS(3 + 2 * (2 * i + f));
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
             const int row = row0 + it * RSTEP;
@@ -456,10 +480,23 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
             __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (unsigned)(slab_m(i, f, it) * p.ldo + ncol) * (unsigned)sizeof(OT), 0, 0);
           }
           if (HAS_RES && i == 0 && f < MF1) ldres(1, f, rr[f]);   // slab s + 2 into the registers slab s just freed
+          MEGA_TS(4 + 2 * (2 * i + f));
         }
       }
     };
     if (res) run(std::true_type{}); else run(std::false_type{});
+    if (ABL == 5) {
+      MEGA_WAIT_VM(0);
+      MEGA_TS(11);
+      MEGA_TS_RT(14);
+      if ((wave & 3) == 0 && lane == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        reinterpret_cast<unsigned long long*>(p.partial)[((size_t)blockIdx.x * 2 + (wave >> 2)) * 16 + 12] =
+            (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+      }
+    }
     return;
   }
   if (res_vec) {
@@ -574,6 +611,26 @@ int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st)
     if (abl == 1) return launch8<bf16_t, 2, 0, 1>(p, st);
     if (abl == 2) return launch8<bf16_t, 2, 0, 2>(p, st);
     if (abl == 3) return launch8<bf16_t, 2, 0, 3>(p, st);
+    if (abl == 5) {          // whole-tile timeline of every block -> MEGA_IGEMM8_TIMELINE_OUT (raw u64 [grid][2][16])
+      static unsigned long long* d_tr = nullptr;
+      static size_t cap = 0;
+      const size_t nblk = (size_t)cdiv(p.M, 256) * cdiv(p.Cout, 256), bytes = nblk * 2 * 16 * sizeof(unsigned long long);
+      if (bytes > cap) { if (d_tr) (void)hipFree(d_tr); (void)hipMalloc(&d_tr, bytes); cap = bytes; }
+      (void)hipMemsetAsync(d_tr, 0, bytes, st);
+      ConvParams q = p;
+      q.partial = reinterpret_cast<float*>(d_tr);
+      const int rc = launch8<bf16_t, 2, 0, 5>(q, st);
+      (void)hipStreamSynchronize(st);
+      const char* path = getenv("MEGA_IGEMM8_TIMELINE_OUT");
+      if (path) {
+        unsigned long long* h = (unsigned long long*)malloc(bytes);
+        (void)hipMemcpy(h, d_tr, bytes, hipMemcpyDeviceToHost);
+        FILE* f = fopen(path, "wb");
+        if (f) { fwrite(h, 1, bytes, f); fclose(f); }
+        free(h);
+      }
+      return rc;
+    }
     if (abl == 4) {          // timeline of block 0: 12 stamps per K-tile per wave, first 8 K-tiles
       static unsigned long long* d_tr = nullptr;
       if (!d_tr) (void)hipMalloc(&d_tr, 8 * 96 * sizeof(unsigned long long));
