@@ -27,6 +27,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// two floats -> one dword of two bf16 (low half = a): v_cvt_pk_bf16_f32
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+  const bf16x2_v v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VE = 4;  // elements per 16-byte vector

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
   //      the previous one to be acknowledged and each residual vector was an exposed round trip; straight-line code
   //      keeps the counts exact, the residual rows are a rolling (two-slab) prefetch and the stores drain behind the
   //      next slab's staging (barriers wait for LDS traffic only).
-  constexpr bool RES_FAST = 64 * VPR / NTHREADS <= 8;  // (f32 256-wide tiles: 16 residual vectors per slab would spill)
+  constexpr bool RES_FAST = 64 * VPR / NTHREADS <= 4;  // (256-wide tiles: 8-16 residual vectors per slab in flight twice would spill)
   const bool fast = vec_ok && p.ksplit == 1 && n0 + BN <= p.Cout &&
                     ((size_t)(p.M - 1) * p.ldo + p.Cout) * sizeof(OT) < 0x7FF00000ull &&
                     (res == nullptr || (RES_FAST && ((size_t)(p.M - 1) * p.ldr + p.Cout) * sizeof(T) < 0x7FF00000ull));
@@ -251,12 +251,14 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
     constexpr int RSTEP = NTHREADS / VPR;              // slab rows between a thread's consecutive vectors
     static_assert(NIT >= 1 && NIT * NTHREADS == 64 * VPR, "slab vectors must divide evenly");
     const int row0 = tid / VPR, cvo = (tid % VPR) * OVE, ncol = n0 + cvo;
-    auto slab_m = [&](int i, int it) {
-      const int row = row0 + it * RSTEP;
-      return m0 + (row >> 5) * WTM + i * 32 + (row & 31);
+    auto slab_m = [&](int i, int it) {      // (row0 < RSTEP, RSTEP divides 32: per-thread part + compile-time part)
+      return (m0 + row0) + (((it * RSTEP) >> 5) * WTM + i * 32 + ((it * RSTEP) & 31));
     };
-    auto run = [&](auto HR) {
+    // RL = 1: ReLU on the ROUNDED value (bf16: one v_pk_max_i16 per pair on the packed bits; f32: v_max) -- equal to
+    // the generic x > 0 ? x : x * slope bit for bit except that negative inputs give +0 instead of -0 (see igemm8.hip)
+    auto run = [&](auto HR, auto RL) {
       constexpr bool HAS_RES = decltype(HR)::value;
+      constexpr bool RELU = decltype(RL)::value;
       constexpr int PD = 2;                          // slabs of residual rows in flight
       u32x4_t rr[PD][HAS_RES ? NIT : 1];
       auto ldres = [&](int i, u32x4_t (&dst)[HAS_RES ? NIT : 1]) {
@@ -299,16 +301,32 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
 #pragma unroll
             for (int t = 0; t < OVE; ++t) v[t] += Elem<T>::ld(re + t);
           }
-          u32x4_t o;
-          OT* oe = reinterpret_cast<OT*>(&o);
+          u32x4_t o;                                 // packed explicitly (no type-punned stores into o)
+          if constexpr (sizeof(OT) == 2) {
 #pragma unroll
-          for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, act(v[t]));
+            for (int d = 0; d < 4; ++d) {
+              if constexpr (RELU) {
+                const s16x2_t z = {0, 0};
+                o[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pack_bf16x2(v[2 * d], v[2 * d + 1])), z));
+              } else {
+                o[d] = pack_bf16x2(act(v[2 * d]), act(v[2 * d + 1]));
+              }
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = __float_as_uint(RELU ? fmaxf(v[t], 0.f) : act(v[t]));
+          }
           __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (unsigned)(slab_m(i, it) * p.ldo + ncol) * (unsigned)sizeof(OT), 0, 0);
         }
         if (HAS_RES && i + PD < TM) ldres(i + PD, rr[i % PD]);   // slab i + PD into the registers slab i just freed
       }
     };
-    if (res) run(std::integral_constant<bool, RES_FAST>{}); else run(std::false_type{});
+    if (res) {
+      if (p.relu == 1) run(std::integral_constant<bool, RES_FAST>{}, std::true_type{});
+      else run(std::integral_constant<bool, RES_FAST>{}, std::false_type{});
+    } else {
+      if (p.relu == 1) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
+    }
     return;
   }
 #pragma unroll

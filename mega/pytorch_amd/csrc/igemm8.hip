@@ -428,12 +428,18 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
         const_cast<void*>(p.res ? p.res : p.out), 0, res ? (int)(((size_t)(p.M - 1) * p.ldr + p.Cout) * 2) : 0, 0x00020000);
     constexpr int RSTEP = NT8 / VPR;                   // slab rows between a thread's consecutive vectors
     const int row0 = tid / VPR, ncol = n0 + (tid % VPR) * OVE;
+    // (row0 < RSTEP and RSTEP divides 32: the slab row row0 + it * RSTEP splits into a per-thread part and a
+    // compile-time part -- one add per vector instead of the shift / mask / multiply chain)
     auto slab_m = [&](int i, int f, int it) {
-      const int row = row0 + it * RSTEP;
-      return m0 + i * 128 + (row >> 5) * (i == 1 ? WROWS1 : 64) + f * 32 + (row & 31);
+      return (m0 + row0) + (i * 128 + ((it * RSTEP) >> 5) * (i == 1 ? WROWS1 : 64) + f * 32 + ((it * RSTEP) & 31));
     };
-    auto run = [&](auto HR) {
+    // RL = 1: ReLU applied to the ROUNDED value -- for bf16 one v_pk_max_i16 per pair on the packed bits (sign bit set
+    // -> 0), for f32 one v_max: round(relu(x)) == relu(round(x)) bit for bit except that a negative input gives +0
+    // instead of the generic form's -0 (x * 0).  The generic x > 0 ? x : x * slope costs cmp + cndmask + mul per element:
+    // with it the read-out of a slab was bound by its ~106 vector-ALU instructions per thread, not by LDS or memory.
+    auto run = [&](auto HR, auto RL) {
       constexpr bool HAS_RES = decltype(HR)::value;
+      constexpr bool RELU = decltype(RL)::value;
       u32x4_t rr[2][NIT];
       auto ldres = [&](int i, int f, u32x4_t (&dst)[NIT]) {
 #pragma unroll
@@ -469,14 +475,29 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
               v[t] = q4.x; v[t + 1] = q4.y; v[t + 2] = q4.z; v[t + 3] = q4.w;
             }
             if (HAS_RES) {
-              const bf16_t* re = reinterpret_cast<const bf16_t*>(&rr[f][it]);
+              u32x4_t r4 = rr[f][it];
+              asm volatile("" : "+v"(r4));             // unpack HERE: hoisted, the 64 unpacked floats of two slabs spill
 #pragma unroll
-              for (int t = 0; t < OVE; ++t) v[t] += bf16_to_f32(re[t]);
+              for (int d = 0; d < 4; ++d) {
+                v[2 * d] += __uint_as_float(r4[d] << 16);
+                v[2 * d + 1] += __uint_as_float(r4[d] & 0xffff0000u);
+              }
             }
-            u32x4_t o;
-            OT* oe = reinterpret_cast<OT*>(&o);
+            u32x4_t o;                                 // packed explicitly (no type-punned stores into o)
+            if constexpr (sizeof(OT) == 2) {
 #pragma unroll
-            for (int t = 0; t < OVE; ++t) Elem<OT>::st(oe + t, act(v[t]));
+              for (int d = 0; d < 4; ++d) {
+                if constexpr (RELU) {
+                  const s16x2_t z = {0, 0};
+                  o[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pack_bf16x2(v[2 * d], v[2 * d + 1])), z));
+                } else {
+                  o[d] = pack_bf16x2(act(v[2 * d]), act(v[2 * d + 1]));
+                }
+              }
+            } else {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) o[t] = __float_as_uint(RELU ? fmaxf(v[t], 0.f) : act(v[t]));
+            }
             __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (unsigned)(slab_m(i, f, it) * p.ldo + ncol) * (unsigned)sizeof(OT), 0, 0);
           }
           if (HAS_RES && i == 0 && f < MF1) ldres(1, f, rr[f]);   // slab s + 2 into the registers slab s just freed
@@ -484,7 +505,11 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
         }
       }
     };
-    if (res) run(std::true_type{}); else run(std::false_type{});
+    if (res) {
+      if (p.relu == 1) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+    } else {
+      if (p.relu == 1) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
+    }
     if (ABL == 5) {
       MEGA_WAIT_VM(0);
       MEGA_TS(11);
