@@ -575,10 +575,12 @@ class MEGAFeatureExtractor(_Packed):
         concatenations that rode along in the same copy launch)."""
         pk = self._packed(globs[0].dtype, globs[0].device)
         w = pk["global"][i]
-        res = relation_project_batched(w, xs, globs, want_x=True, also_cat=also_cat)
+        res = relation_project_batched(w, xs, globs, want_x=True, also_cat=also_cat, pad_refs=self.batched_attention)
         qs, ks, vts, xc = res[:4]
         if self.batched_attention:
-            z = relation_attend_batched(w, [{"x": xc[t], "q": qs[t], "k": ks[t], "vt": vts[t]} for t in range(len(xs))])
+            # the key sets are the projections' own (32-aligned, zero-padded) blocks: nothing to assemble per frame
+            z = relation_attend_batched(w, [{"x": xc[t], "q": qs[t], "k_all": ks[t], "vt_all": vts[t],
+                                             "Nk": ks[t].shape[0]} for t in range(len(xs))])
         else:
             z = [relation_attend(w, xc[t], qs[t], ks[t], vts[t]) for t in range(len(xs))]
         return (z, res[4]) if also_cat else z
@@ -646,12 +648,20 @@ class MEGAFeatureExtractor(_Packed):
             z_all = cat_rows(z)
             cache = getattr(self, "_cur_index", None)
             if cache is None or cache[0] != sig or cache[1].device != z_all.device:
+                # built on the host from the window's proposal counts (dis_key; the same rule as _dis_index) and
+                # uploaded once: the counts of an untrained RPN change from batch to batch, and the device-side
+                # arange / add / cat form was 40 tiny launches per batch
                 idx, o = [], 0
+                an = self.advanced_num
                 for t in own:
-                    idx.append(torch.arange(o, o + nkey[t], device=z_all.device))
-                    idx.append(frames[t]["dis_index"] + (o + nkey[t]))
+                    idx.append(torch.arange(o, o + nkey[t]))
+                    off = o + nkey[t]
+                    for n in frames[t]["dis_key"]:        # rows per window record: its first advanced_num are 'dis' rows
+                        idx.append(torch.arange(off, off + min(an, n)))
+                        off += n
+                    assert off == o + nkey[t] + nl[t]
                     o += nkey[t] + nl[t]
-                cache = (sig, torch.cat(idx))
+                cache = (sig, torch.cat(idx).to(z_all.device, non_blocking=True))
                 self._cur_index = cache
             cur_all = z_all.index_select(0, cache[1])
             o = 0

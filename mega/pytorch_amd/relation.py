@@ -121,7 +121,19 @@ def _flat(xs):
     return flat, rows
 
 
-def relation_project_batched(w, xs, refs, want_x=False, also_cat=()):
+_ZROWS = {}
+
+
+def _zero_rows(like, n):
+    """[n, cols of like] zeros (n < 32) cut from one cached block per (device, dtype, width)"""
+    key = (like.device, like.dtype, like.shape[1])
+    z = _ZROWS.get(key)
+    if z is None:
+        z = _ZROWS[key] = like.new_zeros((32, like.shape[1]))
+    return z[:n]
+
+
+def relation_project_batched(w, xs, refs, want_x=False, also_cat=(), pad_refs=False):
     """The Wq / Wk / Wv projections of several INDEPENDENT attention problems (the key frames of one engine batch) as
     ONE GEMM each over the concatenated rows: M = sum of the rows, so the 64x64-tile launches of the per-frame form
     become a few big-tile launches.  Every GEMM kernel is batch-invariant (an output row never depends on the rows it
@@ -131,9 +143,24 @@ def relation_project_batched(w, xs, refs, want_x=False, also_cat=()):
     vts[i] [1024,Nr_i] (views into the batched results; a caller that keeps a slice must copy it).
     want_x: also return the views xcat[i] [Nq_i,1024] of the concatenated queries (the attention's residual).
     also_cat: further lists of row blocks the caller wants concatenated (they ride in the same copy launch); their
-    results are appended to the returned tuple as one list."""
+    results are appended to the returned tuple as one list.
+    pad_refs: every problem's key rows are followed by zero rows up to a multiple of 32 (block copies in the same
+    launch), so that its V^T block starts at a 32-aligned column and ends in exact-zero pad columns (Wv . 0): vts[i] is
+    then [1024, ceil32(Nr_i)] and can be handed to the attention kernel as it is -- no per-problem pad + concatenation
+    (one fill and one 2-byte cat launch per key frame before).  ks[i] stays [Nr_i,1024]."""
     xf, nq = _flat(xs)
-    rf, nr = _flat(refs)
+    if pad_refs:
+        rf, nr, npad = [], [], []
+        for r in refs:
+            parts = list(r) if isinstance(r, (tuple, list)) else [r]
+            n = sum(p.shape[0] for p in parts)
+            pad = (-n) % 32
+            rf += parts + ([_zero_rows(parts[0], pad)] if pad else [])
+            nr.append(n)
+            npad.append(n + pad)
+    else:
+        rf, nr = _flat(refs)
+        npad = nr
     cats = cat_rows_many([rf, xf] + [list(c) for c in also_cat])
     r_all, x_all = cats[0], cats[1]
     k_all = ops.linear(r_all, w.wk, w.bk)
@@ -145,9 +172,9 @@ def relation_project_batched(w, xs, refs, want_x=False, also_cat=()):
         qs.append(q_all[oq:oq + nq[i]])
         xc.append(x_all[oq:oq + nq[i]])
         ks.append(k_all[orr:orr + nr[i]])
-        vts.append(vt_all[:, orr:orr + nr[i]])
+        vts.append(vt_all[:, orr:orr + npad[i]])
         oq += nq[i]
-        orr += nr[i]
+        orr += npad[i]
     res = (qs, ks, vts, xc) if want_x else (qs, ks, vts)
     return res + (cats[2:],) if also_cat else res
 
