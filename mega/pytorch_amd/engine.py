@@ -140,6 +140,8 @@ class ClipEngine(object):
         self.use_graphs = graphs
         self._fgraphs = {}
         self._graph_pool = None
+        self._graph_pool_r = None          # res5 graphs (replayed beside the RPN branch): their own pool and stream
+        self._res5_stream = None
         self.reuse_records = reuse_records
         self.frames_per_launch = steps_per_batch + 2      # reuse_records: fixed frame-stage launch size
         # experimental, opt-in: steady-state aggregation steps on fixed-address pools, replayed from one hipGraph
@@ -268,18 +270,41 @@ class ClipEngine(object):
                 self._graph_pool = torch.cuda.graph_pool_handle()    # they can share one activation pool
             # thread-local capture mode: the RCCL watchdog thread of a multi-GPU run polls its events with
             # hipEventQuery, which the default (global) mode forbids on ANY thread while a capture is open
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, pool=self._graph_pool, capture_error_mode="thread_local"):
-                ent["a"] = m.frame_stage_a(ent["static_in"])
+            # Four graphs: a0 backbone -> a1 RPN branch -> (counts) -> b2 ROIAlign + fc0 on this stream, b1 (res5, which
+            # needs C4 only) on a side stream beside a1: the proposal selection at the end of a1 is one block per frame
+            # (40 blocks on 256 CUs, ~0.4 ms per 40-frame batch) and disappears under res5's convolutions.  b1 runs
+            # CONCURRENTLY with a1, so its temporaries live in a pool of their own (graphs sharing a pool must replay one
+            # after the other); c4 and x5 are graph outputs kept alive here, never recycled.
+            if self._graph_pool_r is None:
+                self._graph_pool_r = torch.cuda.graph_pool_handle()
+                self._res5_stream = torch.cuda.Stream(device=imgs.device)
+            g0, g1, gr, gb = (torch.cuda.CUDAGraph() for _ in range(4))
+            W, H = imgs.shape[3], imgs.shape[2]
+            with torch.cuda.graph(g0, pool=self._graph_pool, capture_error_mode="thread_local"):
+                ent["c4"] = m.frame_stage_a0(ent["static_in"])
+            with torch.cuda.graph(g1, pool=self._graph_pool, capture_error_mode="thread_local"):
+                ent["a"] = m.frame_stage_a1(ent["c4"], W, H)
+            with torch.cuda.graph(gr, pool=self._graph_pool_r, capture_error_mode="thread_local"):
+                ent["x5"] = m.frame_stage_b1(ent["c4"])
             with torch.cuda.graph(gb, pool=self._graph_pool, capture_error_mode="thread_local"):
-                ent["st"] = m.frame_stage_b(ent["a"], want)
-            ent["graph_a"], ent["graph"] = ga, gb
+                ent["st"] = m.frame_stage_b2(ent["x5"], ent["a"], want)
+            ent["graph_a0"], ent["graph_a1"], ent["graph_b1"], ent["graph"] = g0, g1, gr, gb
+            ent["e0"], ent["e1"] = torch.cuda.Event(), torch.cuda.Event()
             self.graph_stats["captured"] += 1
+        cur = torch.cuda.current_stream()
         ent["static_in"].copy_(imgs)
-        ent["graph_a"].replay()
+        ent["graph_a0"].replay()
+        ent["e0"].record(cur)
+        side = self._res5_stream
+        side.wait_event(ent["e0"])
+        with torch.cuda.stream(side):
+            ent["graph_b1"].replay()
+            ent["e1"].record(side)
+        ent["graph_a1"].replay()
         cnt = ent["a"]["cnt"].clone()
         if on_counts is not None:
             on_counts(cnt)
+        cur.wait_event(ent["e1"])
         ent["graph"].replay()
         self.graph_stats["replayed"] += 1
         st = ent["st"]

@@ -449,11 +449,20 @@ class MEGAFeatureExtractor(_Packed):
     def box_features(self, feat_nhwc, rois5):
         """res5 (+1x1 reduce) on the full C4 maps -> ROIAlign -> fc0 + ReLU.  feat [B,H,W,1024], rois5 [K,5]
         -> [K,1024].  (:885-896 and :898-907)"""
+        return self.pooled_fc(self.res5_features(feat_nhwc), rois5)
+
+    def res5_features(self, feat_nhwc):
+        """the proposal-independent half of box_features: res5 (+1x1 reduce) on the full C4 maps"""
         pk = self._packed(feat_nhwc.dtype, feat_nhwc.device)
         x = self.head.run(feat_nhwc)
         if self.conv is not None:
             x = ops.conv2d_nhwc(x, pk["rc_w"], None, pk["rc_b"], relu=True)
-        pooled = ops.roi_align(x, rois5, self.scale, (self.resolution, self.resolution), self.sampling_ratio)
+        return x
+
+    def pooled_fc(self, x5, rois5):
+        """ROIAlign on the res5 maps -> fc0 + ReLU"""
+        pk = self._packed(x5.dtype, x5.device)
+        pooled = ops.roi_align(x5, rois5, self.scale, (self.resolution, self.resolution), self.sampling_ratio)
         return ops.linear(pooled.view(pooled.shape[0], -1), pk["fc_w"][0], pk["fc_b"][0], relu=True)
 
     # ---- test-time state (:657-688)
@@ -957,10 +966,25 @@ class GeneralizedRCNNMEGA(nn.Module):
         no host sync.  -> {"c4", "props" [B,K,4], "scores" [B,K], "cnt" [B] (device)}.  The proposal COUNTS exist at the end
         of this half: the engine copies them to the host here, so that it can lay out the aggregation while the second half
         (res5 + ROIAlign + fc0, ~40 % of the stage) is still running."""
-        _, _, H, W = imgs.shape
-        c4 = _nhwc(self.backbone(imgs)[0])
+        return self.frame_stage_a1(self.frame_stage_a0(imgs), imgs.shape[3], imgs.shape[2])
+
+    # The four quarters of the frame stage, for engines that run the two branches below C4 side by side (engine.py:
+    # the RPN branch's proposal selection is a chain of one-block-per-frame kernels -- 40 blocks on 256 CUs for ~0.4 ms
+    # per 40-frame batch -- that hides completely under res5's convolutions):
+    #   a0: backbone -> C4        a1: RPN head + proposal selection (needs C4)
+    #   b1: res5 on the full maps (needs C4 only)        b2: ROIAlign + fc0 (needs a1's proposals and b1's maps)
+    @torch.no_grad()
+    def frame_stage_a0(self, imgs):
+        return _nhwc(self.backbone(imgs)[0])
+
+    @torch.no_grad()
+    def frame_stage_a1(self, c4, W, H):
         props, scores, cnt = self.rpn.propose(c4, W, H, "key")           # [B,K,4], [B,K], [B] (device)
         return {"c4": c4, "props": props, "scores": scores, "cnt": cnt}
+
+    @torch.no_grad()
+    def frame_stage_b1(self, c4):
+        return self.roi_heads.box.feature_extractor.res5_features(c4)
 
     @torch.no_grad()
     def frame_stage_b(self, a, want):
@@ -968,6 +992,11 @@ class GeneralizedRCNNMEGA(nn.Module):
         frame b (key_num for local frames, base_num for global-pool frames).  Shapes are static: frame b always gets
         want[b] ROI rows; rows past its (device-side) proposal count are all-zero boxes whose features are simply never
         used.  Returns the handle frame_stage_resolve() takes."""
+        return self.frame_stage_b2(self.frame_stage_b1(a["c4"]), a, want)
+
+    @torch.no_grad()
+    def frame_stage_b2(self, x5, a, want):
+        """ROIAlign + fc0 of frame_stage_b on res5 maps x5 = frame_stage_b1(a["c4"])."""
         fe = self.roi_heads.box.feature_extractor
         c4, props = a["c4"], a["props"]
         want = tuple(int(w) for w in want)
@@ -984,7 +1013,7 @@ class GeneralizedRCNNMEGA(nn.Module):
             self._roi_index_cache[key] = cache
         boxes = props.view(-1, 4).index_select(0, cache[1])
         rois5 = torch.cat([cache[2], boxes], dim=1)
-        feats = fe.box_features(c4, rois5)
+        feats = fe.pooled_fc(x5, rois5)
         return {"props": props, "scores": a["scores"], "cnt": a["cnt"], "feats": feats, "want": want}
 
     @torch.no_grad()

@@ -66,11 +66,19 @@ class RDNFeatureExtractor(_Packed):
 
     def box_features(self, feat_nhwc, rois5):
         """res5 (+1x1 reduce) -> ROIAlign -> fcs[0] + ReLU (:404-414; for the key frame :421-433 with i = 0)."""
+        return self.pooled_fc(self.res5_features(feat_nhwc), rois5)
+
+    def res5_features(self, feat_nhwc):
+        """the proposal-independent half of box_features (the engine runs it beside the RPN branch)"""
         pk = self._packed(feat_nhwc.dtype, feat_nhwc.device)
         x = self.head.run(feat_nhwc)
         if self.conv is not None:
             x = ops.conv2d_nhwc(x, pk["rc_w"], None, pk["rc_b"], relu=True)
-        pooled = ops.roi_align(x, rois5, self.scale, (self.resolution, self.resolution), self.sampling_ratio)
+        return x
+
+    def pooled_fc(self, x5, rois5):
+        pk = self._packed(x5.dtype, x5.device)
+        pooled = ops.roi_align(x5, rois5, self.scale, (self.resolution, self.resolution), self.sampling_ratio)
         return ops.linear(pooled.view(pooled.shape[0], -1), pk["fc_w"][0], pk["fc_b"][0], relu=True)
 
     # the MEGA detector's reset hooks: RDN keeps no memory / global pools
