@@ -61,11 +61,12 @@ def run(name, N, H, W, Cin, Cout, R, pad, res):
         min(per_cu), max(per_cu), np.median(gaps), gaps.mean(), np.percentile(gaps, 90), tot.sum() / (len(per_cu) * float(span))))
     return span
 spans = {}
-spans["l3.conv3"] = run("l3.conv3 1x1 256->1024 + res", 25, 38, 63, 256, 1024, 1, 0, True)
-spans["l3.conv1"] = run("l3.conv1 1x1 1024->256", 25, 38, 63, 1024, 256, 1, 0, False)
-spans["l2.conv3"] = run("l2.conv3 1x1 128->512 + res", 25, 75, 125, 128, 512, 1, 0, True)
-spans["l1.conv3"] = run("l1.conv3 1x1 64->256 + res", 25, 150, 250, 64, 256, 1, 0, True)
-spans["l3.conv2"] = run("l3.conv2 3x3 256->256", 25, 38, 63, 256, 256, 3, 1, False)
+spans["l3.conv3"] = run("l3.conv3 1x1 256->1024 + res", 40, 38, 63, 256, 1024, 1, 0, True)
+spans["l3.conv1"] = run("l3.conv1 1x1 1024->256", 40, 38, 63, 1024, 256, 1, 0, False)
+spans["l2.conv3"] = run("l2.conv3 1x1 128->512 + res", 40, 75, 125, 128, 512, 1, 0, True)
+spans["l1.conv3"] = run("l1.conv3 1x1 64->256 + res", 40, 150, 250, 64, 256, 1, 0, True)
+spans["l3.conv2"] = run("l3.conv2 3x3 256->256", 40, 38, 63, 256, 256, 3, 1, False)
+spans["rpn.conv"] = run("rpn.conv 3x3 1024->1024", 40, 38, 63, 1024, 1024, 3, 1, False)
 '''
 timing = r'''
 import sys, os, torch
@@ -86,7 +87,7 @@ def t(N, H, W, Cin, Cout, R, pad, res):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 20 * 1e3
 print("un-probed launch durations (us): l3.conv3 %.1f  l3.conv1 %.1f  l2.conv3 %.1f  l1.conv3 %.1f  l3.conv2 %.1f" % (
-    t(25,38,63,256,1024,1,0,True), t(25,38,63,1024,256,1,0,False), t(25,75,125,128,512,1,0,True), t(25,150,250,64,256,1,0,True), t(25,38,63,256,256,3,1,False)))
+    t(40,38,63,256,1024,1,0,True), t(40,38,63,1024,256,1,0,False), t(40,75,125,128,512,1,0,True), t(40,150,250,64,256,1,0,True), t(40,38,63,256,256,3,1,False)))
 '''
 if __name__ == "__main__":
     out = os.path.join(_root, "gpurun_out", "timeline8.bin")

@@ -21,7 +21,7 @@ def main(path):
     roi = [i for i, r in enumerate(seg) if 'roi_align' in r[2]][-1]
     # the frame stage ends with the first FC (one igemm launch after ROIAlign)
     f, b = seg[:roi + 2], seg[roi + 2:]
-    for title, part, div in (("frame stage of one step-batch", f, 1), ("aggregation of TWO step-batches (halve)", b, 2)):
+    for title, part, div in (("frame stage of one step-batch", f, 1), ("aggregation, per step-batch (two batches traced, halved)", b, 2)):
         agg = defaultdict(lambda: [0, 0])
         for r in part:
             k = name(r[2])
