@@ -472,6 +472,38 @@ def test_cat_rows_is_free_for_consecutive_row_blocks():
     assert cat_rows([base[2:4]]) is not None and cat_rows([base[2:4]]).shape == (2, 6)
 
 
+def test_padded_key_sets_of_the_global_stage(monkeypatch):
+    """relation_project_batched(pad_refs=True): every problem's key rows are followed by zero rows up to a multiple of 32,
+    so its V^T block is a 32-aligned column block of the one GEMM output that ends in exact-zero pad columns -- what
+    update_lm's batched form hands to the attention kernel without a per-frame fill + cat.  Same q / k / V^T values as
+    the unpadded form; the attention output on the padded blocks equals the assembled form."""
+    import types
+    from mega.pytorch_amd import relation
+    cpu_ops.install(monkeypatch)
+    g = torch.Generator().manual_seed(3)
+    w = types.SimpleNamespace(wq=torch.randn((1024, 1024), generator=g) * 0.02, bq=torch.randn((1024,), generator=g) * 0.1,
+                              wk=torch.randn((1024, 1024), generator=g) * 0.02, bk=torch.randn((1024,), generator=g) * 0.1,
+                              wv=torch.randn((1024, 1024), generator=g) * 0.02, bv=torch.randn((1024,), generator=g) * 0.1,
+                              with_pos=False)
+    xs = [torch.randn((n, 1024), generator=g) for n in (7, 12, 5)]
+    refs = [torch.randn((30, 1024), generator=g), (torch.randn((20, 1024), generator=g), torch.randn((13, 1024), generator=g)),
+            torch.randn((64, 1024), generator=g)]                       # 30 -> 32, 33 -> 64 (two row blocks), 64 -> 64
+    q0, k0, v0 = relation.relation_project_batched(w, xs, refs)
+    q1, k1, v1, xc = relation.relation_project_batched(w, xs, refs, want_x=True, pad_refs=True)
+    for i, nr in enumerate((30, 33, 64)):
+        ld = (nr + 31) // 32 * 32
+        assert k1[i].shape == (nr, 1024) and v1[i].shape == (1024, ld) and v1[i].stride(1) == 1
+        assert torch.allclose(q0[i], q1[i], atol=1e-5) and torch.allclose(k0[i], k1[i], atol=1e-5)
+        assert torch.allclose(v0[i], v1[i][:, :nr], atol=1e-5)
+        assert torch.equal(v1[i][:, nr:], torch.zeros((1024, ld - nr)))          # exact zeros: Wv . 0
+        assert torch.equal(xc[i], xs[i])
+    a = relation.relation_attend_batched(w, [{"x": xc[t], "q": q1[t], "k_all": k1[t], "vt_all": v1[t], "Nk": k1[t].shape[0]}
+                                             for t in range(3)])
+    b = relation.relation_attend_batched(w, [{"x": xs[t], "q": q0[t], "k": k0[t], "vt": v0[t]} for t in range(3)])
+    for t in range(3):
+        assert torch.allclose(a[t], b[t], atol=1e-4)
+
+
 def test_tapes_equal_per_frame_bookkeeping(monkeypatch):
     """prepare_batch / _push_memory_batch (one tape + views per step-batch) leave the model in the state, and hand out the
     tensors, of the per-key-frame forms they replace (prepare_step / _push_memory), including ragged records (frames with
