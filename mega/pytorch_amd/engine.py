@@ -226,18 +226,31 @@ class ClipEngine(object):
         return jobs
 
     # ------------------------------------------------------------------ frame stage (optionally sharded)
+    class _RawFrames(object):
+        """uint8 frames [n,H,W,3] whose preprocessing is still to run: the frame stage's graph path lets the
+        preprocess kernel write straight into the graphs' static input (no 288 MB staging copy per 40-frame batch)."""
+
+        def __init__(self, u8, mean, to_bgr):
+            self.u8, self.mean, self.to_bgr = u8, mean, to_bgr
+            n, h, w, _ = u8.shape
+            self.shape, self.dtype, self.is_cuda, self.device = (n, 3, h, w), torch.float32, u8.is_cuda, u8.device
+
+        def materialize(self, out=None):
+            return ops.preprocess_frames(self.u8, self.mean, self.to_bgr, out=out)
+
     def _frames(self, clip, ids):
-        """clip: uint8 [T,H,W,3] (device) -> preprocessed f32 [n,3,H,W]; or already-preprocessed f32 [T,3,H,W];
-        or a feed.FrameSource (decodes on host threads, resizes on the device)."""
+        """clip: uint8 [T,H,W,3] (device) -> preprocessed f32 [n,3,H,W] (as _RawFrames: preprocessing deferred to the
+        frame stage); or already-preprocessed f32 [T,3,H,W]; or a feed.FrameSource (decodes on host threads, resizes
+        on the device)."""
         if hasattr(clip, "fetch"):
-            return ops.preprocess_frames(clip.fetch(list(ids)).contiguous(), self.mean, self.to_bgr)
+            return self._RawFrames(clip.fetch(list(ids)).contiguous(), self.mean, self.to_bgr)
         if clip.is_cuda:   # pinned + non_blocking: the host must not wait for the work already queued on the stream
             idx = torch.tensor(ids, dtype=torch.int64).pin_memory().to(clip.device, non_blocking=True)
         else:
             idx = torch.as_tensor(ids)
         sel = clip.index_select(0, idx)
         if clip.dtype == torch.uint8:
-            return ops.preprocess_frames(sel.contiguous(), self.mean, self.to_bgr)
+            return self._RawFrames(sel.contiguous(), self.mean, self.to_bgr)
         return sel.contiguous()
 
     def _frame_stage(self, imgs, want, on_counts=None):
@@ -249,7 +262,10 @@ class ClipEngine(object):
         starts their copy to the host there -- the counts are all the host needs to lay out the aggregation, and they
         exist 40 % of the stage before its features do."""
         m = self.frame_model
+        raw = imgs if isinstance(imgs, self._RawFrames) else None
         if not (self.use_graphs and imgs.is_cuda):
+            if raw is not None:
+                imgs = raw.materialize()
             a = m.frame_stage_a(imgs)
             if on_counts is not None:
                 on_counts(a["cnt"])
@@ -259,12 +275,14 @@ class ClipEngine(object):
         if ent is None:
             self._fgraphs[key] = {}
             self.graph_stats["eager"] += 1
+            if raw is not None:
+                imgs = raw.materialize()
             a = m.frame_stage_a(imgs)
             if on_counts is not None:
                 on_counts(a["cnt"])
             return m.frame_stage_b(a, want)
         if "graph" not in ent:
-            ent["static_in"] = imgs.clone()
+            ent["static_in"] = raw.materialize() if raw is not None else imgs.clone()
             torch.cuda.current_stream().synchronize()
             if self._graph_pool is None:          # all frame-stage graphs replay one after the other on one stream:
                 self._graph_pool = torch.cuda.graph_pool_handle()    # they can share one activation pool
@@ -292,7 +310,10 @@ class ClipEngine(object):
             ent["e0"], ent["e1"] = torch.cuda.Event(), torch.cuda.Event()
             self.graph_stats["captured"] += 1
         cur = torch.cuda.current_stream()
-        ent["static_in"].copy_(imgs)
+        if raw is not None:
+            raw.materialize(out=ent["static_in"])       # (the capture batch: written twice, once)
+        else:
+            ent["static_in"].copy_(imgs)
         ent["graph_a0"].replay()
         ent["e0"].record(cur)
         side = self._res5_stream

@@ -568,13 +568,16 @@ def resize_bilinear_u8(frames_u8, out_hw, tables):
     return out
 
 
-def preprocess_frames(frames_u8, mean, to_bgr=True):
-    """uint8 [N,H,W,3] RGB -> f32 [N,3,H,W] (BGR*255 - mean)."""
-    _gpu(frames_u8)
+def preprocess_frames(frames_u8, mean, to_bgr=True, out=None):
+    """uint8 [N,H,W,3] RGB -> f32 [N,3,H,W] (BGR*255 - mean); out: optional contiguous f32 [N,3,H,W] to write into."""
+    _gpu(frames_u8, out)
     lib = _lib.load()
     N, H, W, C = frames_u8.shape
     assert C == 3 and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
-    out = torch.empty((N, 3, H, W), dtype=torch.float32, device=frames_u8.device)
+    if out is None:
+        out = torch.empty((N, 3, H, W), dtype=torch.float32, device=frames_u8.device)
+    else:
+        assert out.shape == (N, 3, H, W) and out.dtype == torch.float32 and out.is_contiguous()
     _tok = _pb("preprocess", 0.0, frames_u8.numel() * 5)
     rc = lib.mega_preprocess_frames(_ptr(frames_u8), _ptr(out), N, H, W, float(mean[0]), float(mean[1]),
                                     float(mean[2]), int(to_bgr), _stream())

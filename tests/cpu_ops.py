@@ -150,11 +150,15 @@ def copy_blocks(pairs):
         d.copy_(s_)
 
 
-def preprocess_frames(frames_u8, mean, to_bgr=True):
+def preprocess_frames(frames_u8, mean, to_bgr=True, out=None):
     x = frames_u8.permute(0, 3, 1, 2).float() / 255.0
     if to_bgr:
         x = x[:, [2, 1, 0]] * 255.0
-    return x - torch.tensor(mean).view(1, 3, 1, 1)
+    x = x - torch.tensor(mean).view(1, 3, 1, 1)
+    if out is not None:
+        out.copy_(x)
+        return out
+    return x
 
 
 def avgpool2x2_ceil(x):
