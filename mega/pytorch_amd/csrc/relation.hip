@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void pos_logits_tiled_kernel(const float4* __r
 }
 
 // the same for several (query boxes, key boxes) problems in one launch: blockIdx.z = problem
-constexpr int POS_MAXB = 16;
+constexpr int POS_MAXB = 20;          // problems per launch: the key frames of the bench's 20-key-frame step-batch in ONE launch
 struct PosBatch {
   struct { const float4* rq; const float4* rk; bf16_t* out; int Nq, Nk; } p[POS_MAXB];
 };
@@ -632,13 +632,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 // blockIdx.z enumerates (problem, key-range split) pairs through a small table, so the chip is filled by all
 // problems together and the host pays one launch per stage instead of one per key frame.  Every problem runs exactly
 // the code (and the split count) of its single-problem launch: same bits.
-constexpr int ATTN_MAXB = 16;
+constexpr int ATTN_MAXB = 20;         // (kernel arguments are limited to 4 KiB: see the static_assert below)
 constexpr int ATTN_MAXZ = 256;
 struct AttnBatch {
   int n, nz;
   unsigned char zprob[ATTN_MAXZ], zsplit[ATTN_MAXZ];
   AttnParams p[ATTN_MAXB];
 };
+static_assert(sizeof(AttnBatch) <= 4096, "AttnBatch travels as the kernel argument");
 
 // MINB = blocks per CU the register allocation aims at: 2 (174 VGPRs) or 3 (168 VGPRs; the tiled-position variant then
 // spills 6 dwords) -- an A/B pair, selected by MEGA_ATTN_OCC3 until one of them is measured to win.

@@ -392,6 +392,9 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     return out
 
 
+_MAX_BATCHED = 20    # problems per batched position-logit / attention launch (POS_MAXB / ATTN_MAXB in relation.hip)
+
+
 def _even_chunks(n, cap):
     """problems per launch when n problems go out in launches of at most `cap`: as even as possible (20 -> 10 + 10, not
     16 + 4: a 4-problem launch leaves most of the chip idle)"""
@@ -412,7 +415,7 @@ class _PosDesc(ctypes.Structure):
 
 def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, tiled=False):
     """position_logits for several (query boxes, key boxes) problems; the tile-ordered bf16 form (bf16 mode) runs as
-    ONE launch per 16 problems, the f32 forms fall back to one call per problem."""
+    ONE launch per 20 problems, the f32 forms fall back to one call per problem."""
     if not tiled:
         return [position_logits(a, b, wg_t, bg, dim_mat, precise=precise, tiled=False) for a, b in zip(rois_qs, rois_ks)]
     _gpu(wg_t, bg, dim_mat, *rois_qs, *rois_ks)
@@ -422,7 +425,7 @@ def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, t
         a, b = a.contiguous(), b.contiguous()
         keep.append((a, b))
         outs.append(torch.empty((16, (b.shape[0] + 31) // 32, a.shape[0], 32), dtype=torch.bfloat16, device=a.device))
-    per = _even_chunks(len(outs), 16)
+    per = _even_chunks(len(outs), _MAX_BATCHED)
     for o in range(0, len(outs), per):
         n = min(per, len(outs) - o)
         arr = (_PosDesc * n)()
@@ -440,7 +443,7 @@ def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, t
 
 def relation_attention_batched(items, groups=16):
     """relation_attention for a list of independent problems, each a dict(q, k, vt, Nk, pos, resid, bias_v), in ONE launch
-    per 16 problems (+ one combine launch).  Every problem gets the bits of its own relation_attention call."""
+    per 20 problems (+ one combine launch).  Every problem gets the bits of its own relation_attention call."""
     if not items:
         return []
     lib = _lib.load()
@@ -467,7 +470,7 @@ def relation_attention_batched(items, groups=16):
         o += q.shape[0]
         nb = lib.mega_relation_attention_workspace_bytes(q.shape[0], it["Nk"], groups)
         wss.append(_ws(nb, q.device) if nb else None)
-    per = _even_chunks(len(items), 16)
+    per = _even_chunks(len(items), _MAX_BATCHED)
     for o in range(0, len(items), per):
         n = min(per, len(items) - o)
         arr = (_AttnDesc * n)()
