@@ -37,6 +37,7 @@ constexpr int NT8 = 512;
 constexpr int ROWB = 128;              // bytes per LDS row = one K-tile of one row
 constexpr int HALF = 128 * ROWB;       // one half-tile slot (16 KiB)
 constexpr int LDS8 = 8 * HALF;         // 128 KiB: A slots in the first 64 KiB, B slots in the second (ds_read offsets are 16 bit)
+constexpr int LDS8_ALLOC = 2 * 64 * (256 + 4) * 4 > LDS8 ? 2 * 64 * (256 + 4) * 4 : LDS8;   // + 2 KiB: the epilogue's two staging slabs
 __host__ __device__ constexpr int slot_a(int i, int par) { return (i * 2 + par) * HALF; }
 __host__ __device__ constexpr int slot_b(int j, int par) { return 4 * HALF + (j * 2 + par) * HALF; }
 constexpr unsigned OOB = 0x80000000u;  // >= num_records of every operand (operands are < 2 GiB): the DMA writes zeros
@@ -437,6 +438,12 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     // -> 0), for f32 one v_max: round(relu(x)) == relu(round(x)) bit for bit except that a negative input gives +0
     // instead of the generic form's -0 (x * 0).  The generic x > 0 ? x : x * slope costs cmp + cndmask + mul per element:
     // with it the read-out of a slab was bound by its ~106 vector-ALU instructions per thread, not by LDS or memory.
+    // two staging slabs, used alternately: ONE barrier per slab.  Slab s + 2 overwrites slab s's buffer only after the
+    // barrier that follows the staging of slab s + 1, and every wave reads slab s before it stages s + 1.  (The second
+    // slab's offset is opaque to the compiler: folded into the ds offsets it would exceed their 16 bits and cost an
+    // address register per store.)
+    int slab1 = 64 * CST;
+    asm volatile("" : "+v"(slab1));
     auto run = [&](auto HR, auto RL) {
       constexpr bool HAS_RES = decltype(HR)::value;
       constexpr bool RELU = decltype(RL)::value;
@@ -454,13 +461,13 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int f = 0; f < (i == 1 ? MF1 : 2); ++f) {
-          if (i + f > 0) { MEGA_WAIT_LDS(); MEGA_BAR(); }    // the previous slab has been read out
+          float* csb = ((2 * i + f) & 1) ? cs + slab1 : cs;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int nl = j * 128 + wc * 32 + l31;
             const int rb = wr * 32 + 4 * (lane >> 5);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][f][j][r] * sc[j] + bi[j];
+            for (int r = 0; r < 16; ++r) csb[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][f][j][r] * sc[j] + bi[j];
           }
           MEGA_WAIT_LDS();
           MEGA_BAR();
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
             float v[OVE];
 #pragma unroll
             for (int t = 0; t < OVE; t += 4) {
-              const float4 q4 = *reinterpret_cast<const float4*>(cs + row * CST + (tid % VPR) * OVE + t);
+              const float4 q4 = *reinterpret_cast<const float4*>(csb + row * CST + (tid % VPR) * OVE + t);
               v[t] = q4.x; v[t + 1] = q4.y; v[t + 2] = q4.z; v[t + 3] = q4.w;
             }
             if (HAS_RES) {
@@ -610,8 +617,8 @@ int launch8(const ConvParams& p, hipStream_t st) {
   constexpr int BM = 128 + 64 * MF1;
   const int ntm = cdiv(p.M, BM), ntn = cdiv(p.Cout, 256);
   // set on every launch (a per-process flag would miss the second device of a multi-GPU process)
-  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1, CLS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
-  hipLaunchKernelGGL((igemm8_kernel<OT, MF1, CLS, ABL>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8, st, p);
+  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1, CLS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_ALLOC);
+  hipLaunchKernelGGL((igemm8_kernel<OT, MF1, CLS, ABL>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8_ALLOC, st, p);
   return mega_check_launch();
 }
 
