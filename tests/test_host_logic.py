@@ -326,6 +326,33 @@ def test_engine_record_reuse_gives_same_detections(monkeypatch):
     assert computed[1] < computed[0]
 
 
+def test_engine_takes_uint8_clips_and_defers_preprocessing(monkeypatch):
+    """ClipEngine.run on the raw uint8 clip == run on the preprocessed clip: uint8 frames travel to the frame stage as
+    _RawFrames (on the GPU the preprocess kernel then writes straight into the graphs' static input), bit for bit the
+    same pixels as the eager transform."""
+    from mega.pytorch_amd import engine
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    T, nkey = 16, 4
+    cfg = _small_cfg()
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    u8 = synth.make_clip(T, 96, 128, seed=2)
+    outs = []
+    for clip in (u8, synth.preprocess_cpu(u8)):
+        model = modeling.build_detection_model(cfg)
+        model.load_state_dict(sd)
+        eng = engine.ClipEngine(model, steps_per_batch=2, overlap=False, graphs=False)
+        raw = eng._frames(clip, [0, 3])
+        assert isinstance(raw, engine.ClipEngine._RawFrames) == (clip.dtype == torch.uint8) and tuple(raw.shape) == (2, 3, 96, 128)
+        if clip.dtype == torch.uint8:
+            dst = torch.empty((2, 3, 96, 128))
+            assert raw.materialize(out=dst) is dst and torch.equal(dst, synth.preprocess_cpu(u8[[0, 3]]))
+        outs.append(eng.run(clip, T, last=nkey))
+    for a, b in zip(*outs):
+        assert len(a) == len(b) and torch.equal(a.get_field("labels"), b.get_field("labels"))
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+
+
 def test_static_aggregation_equals_eager(monkeypatch):
     """ClipEngine(static_aggregation=True): once the window, memory and global pools are full, the aggregation step
     runs on fixed-address shift-append pools (the hipGraph-able form) -- same detections as the deque-based eager
