@@ -226,6 +226,11 @@ int mega_dff_warp_scale(const void* feats, const float* flow, const void* scale,
  * Destinations must not overlap; addresses / strides / row lengths 2-byte aligned at least.  Bit-exact data movement. */
 int mega_copy_segments(const void* segs, int n, void* stream);
 
+/* dst[i] = bf16(src[i]) (round to nearest even), n contiguous elements, both pointers 16-byte aligned: the rounded copy
+ * of the head's f32 activation stream that the bf16 Wq / Wk / Wv projections read
+ * (roi_box_feature_extractors.py:584-597 run in one dtype; this is the mixed-precision seam of the bf16 mode). */
+int mega_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+
 /* hipGetErrorString of the last launch failure any entry point of this library reported (MEGA_ERR_LAUNCH). */
 const char* mega_last_error_string(void);
 
@@ -237,6 +242,9 @@ typedef struct {
   const void* q; const void* k; const void* vt; const float* pos; const void* pos_tiled; const void* resid;
   const float* bias_v; void* out; void* ws; size_t ws_bytes;
   int ldq, ldk, ldv, ldp, ldr, ldo, Nq, Nk;
+  int io_f32;      /* != 0 with dtype bf16: resid and out are f32 rows (the head's f32 activation stream, cfg.HEAD_STREAM:
+                    * x + attention is never rounded to bf16 between the stages of roi_box_feature_extractors.py:806-829) */
+  int reserved;
 } mega_attn_desc;
 int mega_relation_attention_batched(const void* descs /* mega_attn_desc[n], host memory */, int n, int groups,
                                     float scale, int dtype, void* stream);

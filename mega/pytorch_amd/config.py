@@ -77,6 +77,11 @@ def get_cfg(arch="R-101", method="mega"):
 def _mega_cfg(r50):
     return CfgNode({
         "DTYPE": "float32",                      # defaults.py:541; "bfloat16" selects the bf16 MFMA path
+        # bf16 mode only: dtype of the aggregation head's activation stream (fc0 output -> x + attention -> stage FCs ->
+        # predictor, roi_box_feature_extractors.py:806-829,:898-933).  "float32" (default): the stream is never rounded
+        # to bf16 and the stage FCs / predictor run in exact-f32 MFMA (logits within ~1e-4 of the f32 path);
+        # "bfloat16": every hand-off rounds (the round-3 behaviour, ~2 % faster, logit error median 1.7e-3)
+        "HEAD_STREAM": "float32",
         "INPUT": {"MIN_SIZE_TEST": 600, "MAX_SIZE_TEST": 1000,
                   "PIXEL_MEAN": [102.9801, 115.9465, 122.7717], "PIXEL_STD": [1.0, 1.0, 1.0], "TO_BGR255": True},
         "MODEL": {

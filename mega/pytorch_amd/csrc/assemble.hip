@@ -46,7 +46,35 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(CopyBatch b) {
   }
 }
 
+// f32 -> bf16 (round to nearest even, the hardware conversion every epilogue uses), 8 elements per thread
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n8,
+                                                            size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    u32x4_t o;
+    o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w); o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
+    reinterpret_cast<u32x4_t*>(dst)[i] = o;
+  }
+  if (blockIdx.x == 0)       // tail (n not a multiple of 8)
+    for (size_t i = n8 * 8 + threadIdx.x; i < n; i += 256) dst[i] = f32_to_bf16(src[i]);
+}
+
 }  // namespace
+
+// dst[i] = bf16(src[i]) for n contiguous elements (both 16-byte aligned).  The aggregation head keeps its activation
+// stream in f32 (cfg.HEAD_STREAM) and feeds the bf16 projections (Wq / Wk / Wv) a rounded copy: the rounding the bf16
+// GEMM's A operand needs anyway, without rounding the stream itself.
+extern "C" int mega_cast_f32_to_bf16(const float* src, void* dst, size_t n, void* stream) {
+  mega_clear_error();
+  if (n == 0) return MEGA_OK;
+  if (!src || !dst || (reinterpret_cast<size_t>(src) & 15) || (reinterpret_cast<size_t>(dst) & 15)) return MEGA_ERR_ARG;
+  const size_t n8 = n / 8;
+  size_t nb = (n8 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n8, n);
+  return mega_check_launch();
+}
 
 struct MegaCopySegC {
   const void* src; void* dst; long long src_stride, dst_stride; int rows, row_bytes;

@@ -355,6 +355,7 @@ struct AttnParams {
   float scale;
   int nsplit, tiles_per_split;
   int vmask_always;           // experiments: mask the V^T tail in every tile (the pre-round-3 form) instead of the last one
+  int io_f32;                 // resid / out are f32 rows whatever T is (the head's f32 activation stream in bf16 mode)
   float* part_o;              // [nsplit][Nq][G*64] un-normalised partial outputs (nsplit > 1)
   float* part_ml;             // [nsplit][2][G][Nq]   running max / sum of each partial
 };
@@ -499,10 +500,22 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
     auto ex = [](float v) { return sizeof(T) == 2 ? __expf(v) : expf(v); };
     const float alpha = ex(m_run - m_new);
     float psum = 0.f;
+    unsigned pk[8];              // bf16 mode: P packed for the PV MFMA (two keys per dword)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = ex(s[r] - m_new);
-      psum += s[r];
+    for (int r = 0; r < 16; ++r) s[r] = ex(s[r] - m_new);
+    if (sizeof(T) == 2) {
+      // P reaches the PV MFMA rounded to bf16; the row sum is taken over the SAME rounded values, so that
+      // out = sum p'_j v_j / sum p'_j is an exact weighted mean of the v_j with slightly perturbed weights.  With the sum
+      // over the unrounded p_j the rounding errors times the COMMON part of the values (bias + the mean of the post-ReLU
+      // features) did not cancel: 2.6e-4 of the 6.5e-4 median logit error of the bf16 head (tools/head_precision_cpu.py).
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        pk[d] = pack_bf16x2(s[2 * d], s[2 * d + 1]);
+        psum += __uint_as_float(pk[d] << 16) + __uint_as_float(pk[d] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) psum += s[r];
     }
     l_run = l_run * alpha + psum;
     m_run = m_new;
@@ -529,10 +542,10 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
     for (int u = 0; u < C::NPV; ++u) {
       uint4 pa, v0, v1;
       if (sizeof(T) == 2) {
-        pa.x = pack_bf16x2(s[8 * u + 0], s[8 * u + 1]);
-        pa.y = pack_bf16x2(s[8 * u + 2], s[8 * u + 3]);
-        pa.z = pack_bf16x2(s[8 * u + 4], s[8 * u + 5]);
-        pa.w = pack_bf16x2(s[8 * u + 6], s[8 * u + 7]);
+        pa.x = pk[4 * u + 0];
+        pa.y = pk[4 * u + 1];
+        pa.z = pk[4 * u + 2];
+        pa.w = pk[4 * u + 3];
         const int off = (16 * u + 4 * h2) * 2;
         const uint2 a0 = *reinterpret_cast<const uint2*>(vb0 + off);
         const uint2 a1 = *reinterpret_cast<const uint2*>(vb0 + off + 16);
@@ -616,8 +629,13 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
       const int q = qw0 + ql;
       if (q < p.Nq) {
         float v = (jj == 0 ? o0[r] : o1[r]) * sRow[wave][ql] + bv;
-        if (resid) v += Elem<T>::ld(resid + (size_t)q * p.ldr + col);
-        Elem<T>::st(out + (size_t)q * p.ldo + col, v);
+        if (p.io_f32) {          // (block-uniform) the residual stream stays f32: nothing is rounded between stages
+          if (resid) v += reinterpret_cast<const float*>(p.resid)[(size_t)q * p.ldr + col];
+          reinterpret_cast<float*>(p.out)[(size_t)q * p.ldo + col] = v;
+        } else {
+          if (resid) v += Elem<T>::ld(resid + (size_t)q * p.ldr + col);
+          Elem<T>::st(out + (size_t)q * p.ldo + col, v);
+        }
       }
     }
   }
@@ -669,8 +687,13 @@ __device__ __forceinline__ void attn_combine_body(const AttnParams& p) {
       num += w * p.part_o[((size_t)s * p.Nq + q) * D + c];
     }
     float v = num / den + (p.bias_v ? p.bias_v[c] : 0.f);
-    if (p.resid) v += Elem<T>::ld((const T*)p.resid + (size_t)q * p.ldr + c);
-    Elem<T>::st((T*)p.out + (size_t)q * p.ldo + c, v);
+    if (p.io_f32) {
+      if (p.resid) v += reinterpret_cast<const float*>(p.resid)[(size_t)q * p.ldr + c];
+      reinterpret_cast<float*>(p.out)[(size_t)q * p.ldo + c] = v;
+    } else {
+      if (p.resid) v += Elem<T>::ld((const T*)p.resid + (size_t)q * p.ldr + c);
+      Elem<T>::st((T*)p.out + (size_t)q * p.ldo + c, v);
+    }
   }
 }
 
@@ -756,8 +779,10 @@ extern "C" size_t mega_relation_attention_workspace_bytes(int Nq, int Nk, int gr
 // Multi-head relation attention core (groups heads x 64).  See header comment for the formula.
 static int attn_fill(AttnParams& p, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
                      const float* pos, int ldp, const void* pos_tiled, const void* resid, int ldr, const float* bias_v,
-                     void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype, void* ws, size_t ws_bytes) {
+                     void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype, void* ws, size_t ws_bytes,
+                     int io_f32 = 0) {
   if (!q || !k || !vt || !out || Nq <= 0 || Nk <= 0 || groups <= 0) return MEGA_ERR_ARG;
+  p.io_f32 = (io_f32 != 0 && dtype != MEGA_F32) ? 1 : 0;   // (f32 mode: T is float already)
   const int ve = dtype == MEGA_BF16 ? 8 : 4;
   if (ldq % ve || ldk % ve || ldv % ve || (pos && (ldp % 32 || ldp < Nk))) return MEGA_ERR_ARG;
   if (ldv < ((Nk + ve - 1) / ve) * ve) return MEGA_ERR_ARG;
@@ -813,6 +838,7 @@ struct MegaAttnDescC {
   const void* q; const void* k; const void* vt; const float* pos; const void* pos_tiled; const void* resid;
   const float* bias_v; void* out; void* ws; size_t ws_bytes;
   int ldq, ldk, ldv, ldp, ldr, ldo, Nq, Nk;
+  int io_f32, reserved;
 };
 
 extern "C" int mega_relation_attention_batched(const void* descs, int n, int groups, float scale, int dtype,
@@ -830,7 +856,7 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
     if ((d[i].pos_tiled != nullptr) != tiled) return MEGA_ERR_ARG;
     const int rc = attn_fill(b.p[i], d[i].q, d[i].ldq, d[i].k, d[i].ldk, d[i].vt, d[i].ldv, d[i].pos, d[i].ldp,
                              d[i].pos_tiled, d[i].resid, d[i].ldr, d[i].bias_v, d[i].out, d[i].ldo, d[i].Nq, d[i].Nk,
-                             groups, scale, dtype, d[i].ws, d[i].ws_bytes);
+                             groups, scale, dtype, d[i].ws, d[i].ws_bytes, d[i].io_f32);
     if (rc != MEGA_OK) return rc;
     if (nz + b.p[i].nsplit > ATTN_MAXZ) return MEGA_ERR_ARG;
     for (int s2 = 0; s2 < b.p[i].nsplit; ++s2) { b.zprob[nz] = (unsigned char)i; b.zsplit[nz] = (unsigned char)s2; ++nz; }

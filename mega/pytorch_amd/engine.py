@@ -423,21 +423,21 @@ class ClipEngine(object):
         them from the device, one host sync)."""
         if "st" in h:
             recs = self.model.frame_stage_resolve(h["st"], counts)
-            if self.frame_model is not self.model:
-                from .modeling import compute_dtype
-                dt = compute_dtype(self.model.cfg)
-                for r in recs:
-                    r["feats"] = r["feats"].to(dt)
-            return recs
-        g = h["gathered"]
-        if counts is None:
-            counts = g["cnt"].tolist()
-        out = []
-        for i, w in enumerate(g["want"]):
-            n = min(int(counts[i]), w)
-            boxes, scores, feats, _ = g["recs"][i]
-            out.append({"boxes": boxes[:n], "scores": scores[:n], "feats": feats[:n]})
-        return out
+        else:
+            g = h["gathered"]
+            if counts is None:
+                counts = g["cnt"].tolist()
+            recs = []
+            for i, w in enumerate(g["want"]):
+                n = min(int(counts[i]), w)
+                boxes, scores, feats, _ = g["recs"][i]
+                recs.append({"boxes": boxes[:n], "scores": scores[:n], "feats": feats[:n]})
+        if self.frame_model is not self.model:      # mixed-precision runs: the records enter the head in ITS stream dtype
+            from .modeling import stream_dtype
+            dt = stream_dtype(self.model.cfg)
+            for r in recs:
+                r["feats"] = r["feats"].to(dt)
+        return recs
 
     def compute_records(self, clip, jobs):
         return self.records_resolve(self.records_async(clip, jobs))

@@ -22,7 +22,7 @@ from torch import nn
 
 from . import ops
 from .relation import (RelationWeights, cat_rows, cat_rows_many, relation_attend, relation_attend_batched,
-                       relation_attention_forward, relation_project_batched)
+                       relation_attention_forward, relation_project_batched, op_dtype, project_v)
 from .structures import BoxList, cat_boxlist, to_image_list
 from .synth import _cell_anchors
 
@@ -31,6 +31,18 @@ _DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float": torch.
 
 def compute_dtype(cfg):
     return _DTYPES[str(getattr(cfg, "DTYPE", "float32"))]
+
+
+def stream_dtype(cfg):
+    """dtype of the aggregation head's ACTIVATION STREAM -- the fc0 output, x + attention, the stage FC outputs, the
+    predictor input (roi_box_feature_extractors.py:806-829,:898-933).  f32 compute: f32.  bf16 compute: cfg.HEAD_STREAM,
+    default float32: the Wq / Wk / Wv projections, Q K^T and P V run on the bf16 matrix cores as before (their errors
+    average out over the keys), but nothing on the direct path proposal features -> class logits is rounded to bf16: the
+    stage FCs and the predictor run in exact-f32 MFMA on the f32 stream.  "bfloat16" restores the round-3 hand-offs (8
+    bf16 roundings of the stream: logit error median 1.7e-3 against the f32 oracle instead of ~1e-4)."""
+    if compute_dtype(cfg) == torch.float32:
+        return torch.float32
+    return _DTYPES[str(getattr(cfg, "HEAD_STREAM", "float32"))]
 
 
 def _nhwc(x):
@@ -422,6 +434,8 @@ class MEGAFeatureExtractor(_Packed):
         else:
             self.global_res_stage = 0
         self.out_channels = rep
+        self.dtype = compute_dtype(cfg)
+        self.stream = stream_dtype(cfg)
         self.mem = None
         self.global_cache = None
         self.cache_memory_kv = True      # keep the Wk / Wv projections of memory rows (False: re-project every step)
@@ -430,8 +444,9 @@ class MEGAFeatureExtractor(_Packed):
     # ---- kernel operands
     def _pack(self, dtype, device):
         sd = {k: v.detach() for k, v in self.state_dict().items()}
-        pk = {"local": [RelationWeights(sd, "", "l_", i, dtype, device, with_pos=True) for i in range(self.stage)],
-              "global": [RelationWeights(sd, "", "g_", i, dtype, device, with_pos=False)
+        sv = self.stream != dtype      # f32 head stream in bf16 mode: split Wv (relation.project_v)
+        pk = {"local": [RelationWeights(sd, "", "l_", i, dtype, device, with_pos=True, split_v=sv) for i in range(self.stage)],
+              "global": [RelationWeights(sd, "", "g_", i, dtype, device, with_pos=False, split_v=sv)
                          for i in range(self.global_res_stage + 1)] if self.global_enable else []}
         # fc0 consumes the bin-major [K, 49, C] ROIAlign output: permute its columns from (c, ph, pw) to (ph, pw, c)
         w0 = self.l_fcs[0].weight.detach()
@@ -440,6 +455,9 @@ class MEGAFeatureExtractor(_Packed):
         pk["fc_w"] = [w0.contiguous().to(dtype).to(device)] + [self.l_fcs[i].weight.detach().to(dtype).to(device).contiguous()
                                                                 for i in range(1, self.stage)]
         pk["fc_b"] = [self.l_fcs[i].bias.detach().float().to(device).contiguous() for i in range(self.stage)]
+        if self.stream != dtype:      # f32 activation stream in bf16 mode: the stage FCs read and write it in exact f32
+            for i in range(1, self.stage):
+                pk["fc_w"][i] = self.l_fcs[i].weight.detach().float().to(device).contiguous()
         if self.conv is not None:
             pk["rc_w"] = _pack_conv(self.conv, dtype).to(device)
             pk["rc_b"] = self.conv.bias.detach().float().to(device).contiguous()
@@ -453,7 +471,7 @@ class MEGAFeatureExtractor(_Packed):
 
     def res5_features(self, feat_nhwc):
         """the proposal-independent half of box_features: res5 (+1x1 reduce) on the full C4 maps"""
-        pk = self._packed(feat_nhwc.dtype, feat_nhwc.device)
+        pk = self._packed(self.dtype, feat_nhwc.device)
         x = self.head.run(feat_nhwc)
         if self.conv is not None:
             x = ops.conv2d_nhwc(x, pk["rc_w"], None, pk["rc_b"], relu=True)
@@ -461,9 +479,10 @@ class MEGAFeatureExtractor(_Packed):
 
     def pooled_fc(self, x5, rois5):
         """ROIAlign on the res5 maps -> fc0 + ReLU"""
-        pk = self._packed(x5.dtype, x5.device)
+        pk = self._packed(self.dtype, x5.device)
         pooled = ops.roi_align(x5, rois5, self.scale, (self.resolution, self.resolution), self.sampling_ratio)
-        return ops.linear(pooled.view(pooled.shape[0], -1), pk["fc_w"][0], pk["fc_b"][0], relu=True)
+        return ops.linear(pooled.view(pooled.shape[0], -1), pk["fc_w"][0], pk["fc_b"][0], relu=True,
+                          out_dtype=self.stream)
 
     # ---- test-time state (:657-688)
     def init_memory(self):
@@ -508,7 +527,7 @@ class MEGAFeatureExtractor(_Packed):
                        "vt": torch.cat(list(q["vt"]), dim=1)}
 
     def update_lm(self, feats, i=0):
-        pk = self._packed(feats.dtype, feats.device)
+        pk = self._packed(self.dtype, feats.device)
         return relation_attention_forward(pk["global"][i], feats, self.global_cache[-1]["feats"], residual=True)
 
     # ---- aggregation for one key frame (:898-933 after the fc0 line)
@@ -517,7 +536,7 @@ class MEGAFeatureExtractor(_Packed):
         (oldest frame first); rois_dis [Nd,4] with either dis_index [Nd] (rows of x_ref forming the 'dis' set;
         update_lm is row-wise, so update_lm(x_ref_dis) == update_lm(x_ref)[dis_index]) or, in the reference's
         call convention, the explicit x_ref_dis [Nd,1024] tensor."""
-        pk = self._packed(x.dtype, x.device)
+        pk = self._packed(self.dtype, x.device)
         nkey = x.shape[0]
         nl = x_ref.shape[0]
         if self.global_enable and self.global_cache and "feats" in self.global_cache[-1]:
@@ -582,7 +601,7 @@ class MEGAFeatureExtractor(_Packed):
         """update_lm (:690-699) for several key frames: xs[t] (a tensor or a tuple of row blocks) attends to globs[t]
         (that step's global pool).  Returns consecutive row blocks of one buffer (and, with also_cat, the extra
         concatenations that rode along in the same copy launch)."""
-        pk = self._packed(globs[0].dtype, globs[0].device)
+        pk = self._packed(self.dtype, globs[0].device)
         w = pk["global"][i]
         res = relation_project_batched(w, xs, globs, want_x=True, also_cat=also_cat, pad_refs=self.batched_attention)
         qs, ks, vts, xc = res[:4]
@@ -630,7 +649,7 @@ class MEGAFeatureExtractor(_Packed):
         frame order, so the memory pools stay replicated.  No key frame is aggregated twice: the step no longer has a
         serial (replicated) part."""
         assert self.cache_memory_kv and self.static_pools is None
-        pk = self._packed(frames[0]["x"].dtype, frames[0]["x"].device)
+        pk = self._packed(self.dtype, frames[0]["x"].device)
         S = len(frames)
         own = [t for t in range(S) if shard is None or shard.owner(t) == shard.rank]
         nkey = [f["x"].shape[0] for f in frames]
@@ -705,9 +724,9 @@ class MEGAFeatureExtractor(_Packed):
                 if shard is not None:
                     # memory entries of ALL frames: gather the entry rows, project them here (same bits as the owner's)
                     ent = shard.gather_rows({t: feats_ref[t][:n_ent[t]] for t in own}, n_ent, frames[0]["x"])
-                    e_all = torch.cat(ent, dim=0)
+                    e_all = op_dtype(w, torch.cat(ent, dim=0))
                     ek_all = ops.linear(e_all, w.wk, w.bk)
-                    evt_all = ops.linear_transposed(w.wv, e_all, (e_all.shape[0] + 31) // 32 * 32)
+                    evt_all = project_v(w, e_all, (e_all.shape[0] + 31) // 32 * 32)
                     o, new_k, new_vt = 0, [], []
                     for t in range(S):
                         new_k.append(ek_all[o:o + n_ent[t]])

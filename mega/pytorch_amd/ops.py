@@ -367,6 +367,9 @@ def position_logits(rois_q, rois_k, wg_t, bg, dim_mat, precise=True, tiled=False
 def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=16):
     """q [Nq,G*64] (u folded in), k [Nk,G*64], vt [G*64, ldv] key-contiguous projected V -> [Nq, G*64]."""
     _gpu(q, k, vt, pos, resid, bias_v)
+    if resid is not None and resid.dtype != q.dtype:     # f32 activation stream over bf16 operands: same kernel, same bits
+        return relation_attention_batched([{"q": q, "k": k, "vt": vt, "Nk": Nk, "pos": pos, "resid": resid,
+                                            "bias_v": bias_v}], groups)[0]
     lib = _lib.load()
     Nq = q.shape[0]
     assert q.dtype == k.dtype == vt.dtype and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
@@ -405,7 +408,7 @@ def _even_chunks(n, cap):
 class _AttnDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("q", "k", "vt", "pos", "pos_tiled", "resid", "bias_v", "out", "ws")] + \
                [("ws_bytes", ctypes.c_size_t)] + \
-               [(n, ctypes.c_int) for n in ("ldq", "ldk", "ldv", "ldp", "ldr", "ldo", "Nq", "Nk")]
+               [(n, ctypes.c_int) for n in ("ldq", "ldk", "ldv", "ldp", "ldr", "ldo", "Nq", "Nk", "io_f32", "reserved")]
 
 
 class _PosDesc(ctypes.Structure):
@@ -448,9 +451,13 @@ def relation_attention_batched(items, groups=16):
         return []
     lib = _lib.load()
     dt = items[0]["q"].dtype
+    # stream dtype: the residual's (the head's f32 activation stream over bf16 operands), else the operands'
+    r0 = items[0].get("resid")
+    sdt = dt if r0 is None else r0.dtype
+    io_f32 = int(sdt == torch.float32 and dt != torch.float32)
     outs, wss = [], []
     # one output buffer, the problems' row blocks in order (the next batched GEMM reads it without a concatenation)
-    out_all = torch.empty((sum(it["q"].shape[0] for it in items), groups * 64), dtype=dt, device=items[0]["q"].device)
+    out_all = torch.empty((sum(it["q"].shape[0] for it in items), groups * 64), dtype=sdt, device=items[0]["q"].device)
     o = 0
     for it in items:
         q, k, vt, pos = it["q"], it["k"], it["vt"], it.get("pos")
@@ -458,8 +465,9 @@ def relation_attention_batched(items, groups=16):
         # q / k / resid: row blocks (or column-complete views) of wider buffers are fine -- unit column stride, the row
         # stride is what the kernel gets as the leading dimension, 16-byte aligned rows
         resid = it.get("resid")
+        assert resid is None or resid.dtype == sdt
         for t_ in (q, k, resid):
-            assert t_ is None or (t_.dtype == dt and t_.stride(1) == 1 and t_.data_ptr() % 16 == 0 and
+            assert t_ is None or (t_.dtype in (dt, sdt) and t_.stride(1) == 1 and t_.data_ptr() % 16 == 0 and
                                   (t_.stride(0) * t_.element_size()) % 16 == 0)
         assert q.dtype == k.dtype == vt.dtype == dt
         # vt: [G*64, >= ceil32(Nk)] with unit column stride; a column block of a wider matrix is fine (16-B aligned)
@@ -482,6 +490,7 @@ def relation_attention_batched(items, groups=16):
             d.q, d.k, d.vt, d.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), outs[o + i].data_ptr()
             d.ldq, d.ldk, d.ldv, d.ldo, d.Nq, d.Nk = q.stride(0), k.stride(0), vt.stride(0), groups * 64, Nq, Nk
             d.resid, d.ldr = _ptr(resid), 0 if resid is None else resid.stride(0)
+            d.io_f32 = io_f32
             d.bias_v = _ptr(it.get("bias_v"))
             if pos is not None and pos.dtype == torch.bfloat16:
                 assert pos.is_contiguous() and tuple(pos.shape) == (groups, (Nk + 31) // 32, Nq, 32)
@@ -491,7 +500,7 @@ def relation_attention_batched(items, groups=16):
             w = wss[o + i]
             d.ws, d.ws_bytes = _ptr(w), 0 if w is None else w.numel()
             fl += 4.0 * Nq * Nk * 64 * groups
-            by += (q.numel() + k.numel() + vt.numel() + outs[o + i].numel()) * q.element_size() + \
+            by += (q.numel() + k.numel() + vt.numel()) * q.element_size() + outs[o + i].numel() * outs[o + i].element_size() + \
                 (0 if pos is None else pos.numel() * pos.element_size())
         _tok = _pb("attention_" + ("bf16" if dt == torch.bfloat16 else "f32"), fl, by)
         rc = lib.mega_relation_attention_batched(ctypes.addressof(arr), n, groups, 1.0 / math.sqrt(64.0), _DT[dt], _stream())
@@ -589,22 +598,39 @@ def preprocess_frames(frames_u8, mean, to_bgr=True, out=None):
     return out
 
 
-def linear_transposed(w, x, ld):
-    """Returns (x @ w^T)^T laid out [Nout, ld] with ld >= M and the pad columns zero:
+def cast_bf16(x):
+    """f32 -> bf16 copy (round to nearest even) of a contiguous tensor; a bf16 input is returned as it is."""
+    if x.dtype == torch.bfloat16:
+        return x
+    _gpu(x)
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _tok = _pb("assemble", 0.0, x.numel() * 6.0)
+    rc = lib.mega_cast_f32_to_bf16(_ptr(x), _ptr(out), x.numel(), _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_cast_f32_to_bf16")
+    return out
+
+
+def linear_transposed(w, x, ld, residual=None):
+    """Returns (x @ w^T)^T (+ residual) laid out [Nout, ld] with ld >= M and the pad columns zero:
     out[n][m] = sum_k w[n][k] * x[m][k].  The weight matrix plays the GEMM 'A rows' role, so the
-    projected values of one output feature are contiguous over rows m (keys)."""
-    _gpu(w, x)
+    projected values of one output feature are contiguous over rows m (keys).  residual: [Nout, ld] of the same dtype,
+    added in the epilogue (the second pass of a split-weight projection, relation.project_v)."""
+    _gpu(w, x, residual)
     lib = _lib.load()
     Nout, K = w.shape
     M = x.shape[0]
     assert x.shape[1] == K and ld >= M and w.dtype == x.dtype and w.is_contiguous() and x.is_contiguous()
+    assert residual is None or (residual.shape == (Nout, ld) and residual.dtype == x.dtype and residual.is_contiguous())
     out = torch.zeros((Nout, ld), dtype=x.dtype, device=x.device)
     _tok = None
     if _PROF is not None:
         _tok = _pb(_igemm_family(lib, Nout, M, K, x.dtype),
                    2.0 * Nout * M * K, (w.numel() + x.numel() + out.numel()) * x.element_size())
-    rc = lib.mega_conv2d_nhwc(_ptr(w), _ptr(x), None, None, None, _ptr(out), Nout, 1, 1, K, M, 1, 1, 1, 0, 1, 0, ld,
-                              ld, _dt(x), _dt(x), _stream())
+    rc = lib.mega_conv2d_nhwc(_ptr(w), _ptr(x), None, None, _ptr(residual), _ptr(out), Nout, 1, 1, K, M, 1, 1, 1, 0, 1, 0,
+                              ld, ld, _dt(x), _dt(x), _stream())
     _pe(_tok)
     _lib.check(rc, "mega_conv2d_nhwc(transposed)")
     return out

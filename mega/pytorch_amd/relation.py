@@ -19,7 +19,7 @@ class RelationWeights(object):
     """Kernel-ready weights of one (kind, index) attention: kind 'l_' (local/memory, with position term),
     'g_' (global) or '' (RDN: position term, no u)."""
 
-    def __init__(self, sd, pfx, kind, index, dtype, device, with_pos):
+    def __init__(self, sd, pfx, kind, index, dtype, device, with_pos, split_v=False):
         def g(name):
             return sd["%s%s%s.%d%s" % (pfx, kind, name[0], index, name[1])].detach().float()
         ukey = "%s%sus.%d" % (pfx, kind, index)        # RDN's AttentionExtractor (kind '') has no u term
@@ -28,7 +28,15 @@ class RelationWeights(object):
         self.bq = (g(("Wqs", ".bias")) + u).to(device).contiguous()                   # u folded into the bias
         self.wk = g(("Wks", ".weight")).to(device=device, dtype=dtype).contiguous()
         self.bk = g(("Wks", ".bias")).to(device).contiguous()
-        self.wv = g(("Wvs", ".weight")).reshape(1024, 1024).to(device=device, dtype=dtype).contiguous()
+        wv32 = g(("Wvs", ".weight")).reshape(1024, 1024)
+        self.wv = wv32.to(device=device, dtype=dtype).contiguous()
+        # split_v (bf16 mode with an f32 head stream): the part of Wv that bf16 drops, as a second bf16 matrix.  The
+        # rounding error of Wv is the SAME for every key, and the values share a large common part (bias + mean of the
+        # post-ReLU features), so its effect on sum_j p_j v_j does not average out over the keys the way the per-key
+        # roundings of ref / V do: 3.3e-4 of the bf16 head's 6.5e-4 median logit error (tools/head_precision_cpu.py).
+        self.wv_lo = None
+        if split_v and dtype != torch.float32:
+            self.wv_lo = (wv32 - self.wv.float().cpu()).to(device=device, dtype=dtype).contiguous()
         self.bv = g(("Wvs", ".bias")).to(device).contiguous()
         self.with_pos = with_pos
         if with_pos:
@@ -37,6 +45,22 @@ class RelationWeights(object):
             self.bg = sd["%s%sWgs.%d.bias" % (pfx, kind, index)].detach().float().to(device).contiguous()
             feat_range = torch.arange(0, 64 / 8)
             self.dim_mat = torch.full((len(feat_range),), 1000.0).pow(8.0 / 64 * feat_range).to(device)
+
+
+def op_dtype(w, t):
+    """t as a GEMM operand of w's projections: the bf16 mode with an f32 activation stream (cfg.HEAD_STREAM) hands the
+    matrix cores a ROUNDED COPY of the stream (ops.cast_bf16) -- the stream itself, the attention's residual, stays f32."""
+    return t if t.dtype == w.wq.dtype else ops.cast_bf16(t.contiguous())
+
+
+def project_v(w, ref, ld):
+    """V'^T = (ref @ Wv^T)^T [1024, ld] (key-contiguous, pad columns zero).  With split weights (w.wv_lo) two passes:
+    the small term Wv_lo . ref first, then Wv_hi . ref with the first pass as the epilogue's residual -- the value
+    that is finally rounded to bf16 is then Wv . ref to ~2^-16 instead of (Wv + dW) . ref with a 2^-9 dW common to all
+    keys."""
+    if getattr(w, "wv_lo", None) is None:
+        return ops.linear_transposed(w.wv, ref, ld)
+    return ops.linear_transposed(w.wv, ref, ld, residual=ops.linear_transposed(w.wv_lo, ref, ld))
 
 
 def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=True, mem_kv=None, return_kv=False):
@@ -49,9 +73,10 @@ def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=Tru
     are computed once, when the rows were part of `ref`, instead of every step).  rois_k then covers Nr + Nm rows.
     return_kv: also return this call's (k [Nr,1024], vt [1024,ld]) of `ref` so the caller can keep slices of them."""
     Nr = ref.shape[0]
+    ref = op_dtype(w, ref)
     k = ops.linear(ref, w.wk, w.bk)
     ldr = (Nr + 31) // 32 * 32
-    vt = ops.linear_transposed(w.wv, ref, ldr)
+    vt = project_v(w, ref, ldr)
     k_all, vt_all, Nk = k, vt, Nr
     if mem_kv is not None:
         k_mem, vt_mem = mem_kv
@@ -62,10 +87,10 @@ def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=Tru
         if ldv > Nk:
             parts.append(vt.new_zeros((vt.shape[0], ldv - Nk)))
         vt_all = torch.cat(parts, dim=1)
-    q = ops.linear(x, w.wq, w.bq)
+    q = ops.linear(op_dtype(w, x), w.wq, w.bq)
     pos = None
     if w.with_pos:
-        fast = x.dtype != torch.float32      # bf16 mode: matrix-core kernel, bf16 logits in the attention's tile order
+        fast = w.wq.dtype != torch.float32   # bf16 mode: matrix-core kernel, bf16 logits in the attention's tile order
         pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
     out = ops.relation_attention(q, k_all, vt_all, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
     return (out, k, vt) if return_kv else out
@@ -163,9 +188,10 @@ def relation_project_batched(w, xs, refs, want_x=False, also_cat=(), pad_refs=Fa
         npad = nr
     cats = cat_rows_many([rf, xf] + [list(c) for c in also_cat])
     r_all, x_all = cats[0], cats[1]
-    k_all = ops.linear(r_all, w.wk, w.bk)
-    vt_all = ops.linear_transposed(w.wv, r_all, (r_all.shape[0] + 31) // 32 * 32)
-    q_all = ops.linear(x_all, w.wq, w.bq)
+    r_op = op_dtype(w, r_all)             # (f32 activation stream: one rounded copy per concatenation, not per problem)
+    k_all = ops.linear(r_op, w.wk, w.bk)
+    vt_all = project_v(w, r_op, (r_all.shape[0] + 31) // 32 * 32)
+    q_all = ops.linear(op_dtype(w, x_all), w.wq, w.bq)
     qs, ks, vts, xc = [], [], [], []
     oq = orr = 0
     for i in range(len(xs)):
@@ -195,7 +221,7 @@ def relation_attend(w, x, q, k, vt, rois_q=None, rois_k=None, mem_kv=None, resid
     vv = torch.cat(vparts, dim=1) if len(vparts) > 1 else vt.contiguous()
     pos = None
     if w.with_pos:
-        fast = x.dtype != torch.float32
+        fast = w.wq.dtype != torch.float32
         pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
     return ops.relation_attention(q, k, vv, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
 
@@ -229,7 +255,7 @@ def relation_attend_batched(w, jobs, residual=True):
         rq.append(j.get("rois_q"))
         rk.append(j.get("rois_k"))
     if w.with_pos:
-        fast = jobs[0]["x"].dtype != torch.float32
+        fast = w.wq.dtype != torch.float32
         pos = ops.position_logits_batched(rq, rk, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
         for it, p in zip(items, pos):
             it["pos"] = p

@@ -37,9 +37,12 @@ def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=Non
     return y.view(M, w.shape[0])
 
 
-def linear_transposed(w, x, ld):
+def linear_transposed(w, x, ld, residual=None):
     out = torch.zeros((w.shape[0], ld), dtype=x.dtype)
-    out[:, :x.shape[0]] = (x.float() @ w.float().t()).t().to(x.dtype)
+    y = (x.float() @ w.float().t()).t()
+    if residual is not None:
+        y = y + residual.float()[:, :x.shape[0]]
+    out[:, :x.shape[0]] = y.to(x.dtype)
     return out
 
 
@@ -122,14 +125,22 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     s = torch.bmm(qh, kh.transpose(1, 2)) / math.sqrt(64.0)
     if pos is not None:
         s = s + pos[:, :, :Nk]
-    p = F.softmax(s, dim=2)
+    if q.dtype == torch.bfloat16:      # the kernel's bf16 mode: P rounded for the PV MFMA, row sum over the rounded values
+        e = torch.exp(s - s.max(dim=2, keepdim=True).values).to(torch.bfloat16).float()
+        p = e / e.sum(dim=2, keepdim=True)
+    else:
+        p = F.softmax(s, dim=2)
     v = vt.float()[:, :Nk].view(groups, 64, Nk)
     o = torch.bmm(p, v.transpose(1, 2)).permute(1, 0, 2).reshape(Nq, groups * 64)
     if bias_v is not None:
         o = o + bias_v
     if resid is not None:
         o = o + resid.float()
-    return o.to(q.dtype)
+    return o.to(q.dtype if resid is None else resid.dtype)     # (f32 activation stream over bf16 operands: io_f32)
+
+
+def cast_bf16(x):
+    return x.to(torch.bfloat16)
 
 
 def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, tiled=False):
@@ -175,7 +186,7 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
     return (out, w[:, 0]) if want_weights else out
 
 
-ALL = ["multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+ALL = ["cast_bf16", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames", "position_logits_batched",
        "relation_attention_batched", "postprocess_batched"]
 
