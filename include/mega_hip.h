@@ -53,6 +53,11 @@ int mega_conv2d_nhwc_tile(int M, int Cout, int K);
  * BM x 256 tiles, BM = 256 or 192).  Every kernel accumulates an output element over K in the same order with the
  * same MFMA instruction, so the choice never changes a result bit. */
 int mega_conv2d_nhwc_plan(int M, int Cout, int K, int in_dtype);
+/* The shape-complete form: which kernel mega_conv2d_nhwc[_ws] really dispatches THIS layer to (same predicates as the
+ * launch path): kind 6 = conv3x3_c64_kernel (layer1's 3x3 64 -> 64 conv: 3x3, stride 1, pad 1, bf16 out, no residual,
+ * enough tiles), 7 = igemm8 streaming class (1x1, K <= 512), 8 = igemm8 matrix class, 0 = igemm_kernel.  -1: bad shape. */
+int mega_conv2d_nhwc_plan_ex(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int ldo,
+                             int has_residual, int in_dtype, int out_dtype);
 
 /* mega_conv2d_nhwc with a caller-owned workspace of mega_conv2d_nhwc_workspace_bytes(M, Cout, K) bytes (M = N*Ho*Wo,
  * K = R*S*Cin; 0 for most layers).  With it, layers with K >= 32768 (the box head's first FC, K = 100352) run
@@ -230,6 +235,11 @@ int mega_copy_segments(const void* segs, int n, void* stream);
  * of the head's f32 activation stream that the bf16 Wq / Wk / Wv projections read
  * (roi_box_feature_extractors.py:584-597 run in one dtype; this is the mixed-precision seam of the bf16 mode). */
 int mega_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+
+/* dst [rows][3K] bf16 = [hi | lo | hi] of src [rows][K] f32 (hi = bf16(v), lo = bf16(v - hi); K % 8 == 0): the A operand
+ * of a split-precision GEMM on the bf16 matrix cores against weight rows [Wh | Wh | Wl] -- v.W to ~2^-16.  Used for the
+ * stage FCs of the aggregation head (roi_box_feature_extractors.py:826-827) when the activation stream is f32. */
+int mega_split_f32_to_bf16x3(const float* src, void* dst_bf16, int rows, int K, void* stream);
 
 /* hipGetErrorString of the last launch failure any entry point of this library reported (MEGA_ERR_LAUNCH). */
 const char* mega_last_error_string(void);

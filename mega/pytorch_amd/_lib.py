@@ -52,6 +52,7 @@ SIGNATURES = {
     "mega_position_logits_tiled_batched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mega_conv2d_nhwc_tile": (c_int, [c_int] * 3),
     "mega_conv2d_nhwc_plan": (c_int, [c_int] * 4),
+    "mega_conv2d_nhwc_plan_ex": (c_int, [c_int] * 14),
     "mega_preprocess_frames": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
     "mega_dff_warp_scale": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "mega_resize_bilinear_u8": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p,
@@ -60,6 +61,7 @@ SIGNATURES = {
     "mega_fgfa_warp_aggregate_ring": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_int, c_void_p]),
     "mega_copy_segments": (c_int, [c_void_p, c_int, c_void_p]),
     "mega_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mega_split_f32_to_bf16x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mega_last_error_string": (ctypes.c_char_p, []),
 }
 

@@ -32,6 +32,25 @@ if os.environ.get("MEGA_BUILD_EXPERIMENTS") == "1":      # tools/gpu/ablate8.py:
     BASE_FLAGS.append("-DMEGA_EXPERIMENTS")
 
 
+def _probe_flags(flags):
+    """Per-file extra flags the installed hipcc accepts: `-mllvm -amdgpu-mfma-vgpr-form=1` is an internal LLVM option
+    (a speed tweak: no AGPR <-> VGPR moves around the attention's accumulators) with no stability guarantee -- a compiler
+    that does not know it would fail the whole build with 'Unknown command line argument' (ADVICE r03).  Probe once with
+    an empty translation unit and drop what is rejected."""
+    if not flags or not os.path.exists(HIPCC):
+        return list(flags)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "probe.hip")
+        with open(src, "w") as f:
+            f.write("#include <hip/hip_runtime.h>\n__global__ void mega_probe() {}\n")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O1"] + list(flags) + ["-c", src, "-o", os.path.join(td, "probe.o")]
+        if subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode == 0:
+            return list(flags)
+    sys.stderr.write("build.py: hipcc rejects %s -- building without it\n" % " ".join(flags))
+    return []
+
+
 def _digest():
     h = hashlib.sha256()
     for fn in sorted(os.listdir(CSRC)):
@@ -40,6 +59,7 @@ def _digest():
             h.update(open(os.path.join(CSRC, fn), "rb").read())
     h.update(" ".join(BASE_FLAGS).encode())
     h.update(repr(sorted(SOURCES.items())).encode())
+    h.update(open(os.path.abspath(__file__), "rb").read())      # (the flag probe lives here)
     return h.hexdigest()
 
 
@@ -58,6 +78,8 @@ def build(force=False, verbose=False):
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             continue
+        if "-mllvm" in extra:
+            extra = _probe_flags(extra)
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [HIPCC] + BASE_FLAGS + extra + ["-c", path, "-o", obj]
         if verbose:

@@ -59,7 +59,47 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     for (size_t i = n8 * 8 + threadIdx.x; i < n; i += 256) dst[i] = f32_to_bf16(src[i]);
 }
 
+// f32 row [K] -> bf16 row [3K] = [hi | lo | hi], hi = bf16(v), lo = bf16(v - hi): with the weight rows laid out
+// [Wh | Wh | Wl] a plain bf16 GEMM over 3K computes hi.Wh + lo.Wh + hi.Wl = v.W to ~2^-16 (f32 accumulation of exact
+// bf16 products; only the lo.Wl term, 2^-18, is dropped) at the bf16 MFMA rate.  8 elements per thread.
+__global__ __launch_bounds__(256) void split3_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows,
+                                                              int K8) {
+  const size_t total = (size_t)rows * K8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / K8;
+    const int c = (int)(i - r * K8);
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    u32x4_t hi, lo;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const unsigned h = pack_bf16x2(v[2 * d], v[2 * d + 1]);
+      hi[d] = h;
+      lo[d] = pack_bf16x2(v[2 * d] - __uint_as_float(h << 16), v[2 * d + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+    u32x4_t* row = reinterpret_cast<u32x4_t*>(dst + r * (size_t)(K8 * 24));
+    row[c] = hi;
+    row[K8 + c] = lo;
+    row[2 * K8 + c] = hi;
+  }
+}
+
 }  // namespace
+
+// dst[r][0:K] = hi, dst[r][K:2K] = lo, dst[r][2K:3K] = hi of src[r][0:K] (f32, K a multiple of 8, 16-byte aligned): the A
+// operand of a split-precision bf16 GEMM against weights [Wh | Wh | Wl] (the stage FCs of the head's f32 activation
+// stream, roi_box_feature_extractors.py:826-827).
+extern "C" int mega_split_f32_to_bf16x3(const float* src, void* dst, int rows, int K, void* stream) {
+  mega_clear_error();
+  if (rows == 0) return MEGA_OK;
+  if (!src || !dst || rows < 0 || K <= 0 || K % 8 || (reinterpret_cast<size_t>(src) & 15) || (reinterpret_cast<size_t>(dst) & 15))
+    return MEGA_ERR_ARG;
+  const size_t total = (size_t)rows * (K / 8);
+  size_t nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(split3_f32_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K / 8);
+  return mega_check_launch();
+}
 
 // dst[i] = bf16(src[i]) for n contiguous elements (both 16-byte aligned).  The aggregation head keeps its activation
 // stream in f32 (cfg.HEAD_STREAM) and feeds the bf16 projections (Wq / Wk / Wv) a rounded copy: the rounding the bf16

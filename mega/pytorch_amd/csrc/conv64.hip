@@ -139,10 +139,18 @@ __global__ __launch_bounds__(C64_NT, 2) void conv3x3_c64_kernel(ConvParams p, in
     for (int r = 0; r < 16; ++r) {
       const int pix = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       float v0 = acc0[r] * sc0 + bi0, v1 = acc1[r] * sc1 + bi1;
-      v0 = v0 > 0.f ? v0 : v0 * neg_slope;
-      v1 = v1 > 0.f ? v1 : v1 * neg_slope;
-      *reinterpret_cast<bf16_t*>(sl + pix * 128 + l31 * 2) = f32_to_bf16(v0);
-      *reinterpret_cast<bf16_t*>(sl + pix * 128 + (32 + l31) * 2) = f32_to_bf16(v1);
+      bf16_t h0, h1;
+      if (p.relu == 1) {       // ReLU on the ROUNDED value, as the igemm / igemm8 fast epilogues do it (max of the packed bits
+        h0 = f32_to_bf16(v0);  // with 0: a negative input gives +0, never -0; a NaN with the sign bit set gives 0 as well) --
+        h1 = f32_to_bf16(v1);  // bit identity with the generic tiles includes the sign of zero
+        h0 = (short)h0 < 0 ? (bf16_t)0 : h0;
+        h1 = (short)h1 < 0 ? (bf16_t)0 : h1;
+      } else {
+        h0 = f32_to_bf16(v0 > 0.f ? v0 : v0 * neg_slope);
+        h1 = f32_to_bf16(v1 > 0.f ? v1 : v1 * neg_slope);
+      }
+      *reinterpret_cast<bf16_t*>(sl + pix * 128 + l31 * 2) = h0;
+      *reinterpret_cast<bf16_t*>(sl + pix * 128 + (32 + l31) * 2) = h1;
     }
     __syncthreads();
     // ---- 3. read-out: 16-byte stores, a tile row = 2 KB of contiguous memory; then request the patch after next
@@ -182,15 +190,14 @@ int mega_conv64_launch(const ConvParams& p, hipStream_t st) {
   if (tiles > 0x7FFFFFFF) return MEGA_ERR_ARG;
   int cus = 256;
   {
-    static int cached = 0;
-    if (!cached) {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-        cached = n;
-      else
-        cached = 256;
+    static int cached[64] = {0};       // per device id: a multi-GPU process may hold devices with different CU counts
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cached[dev]) {
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cached[dev] = n;
+      else cached[dev] = 256;
     }
-    cus = cached;
+    cus = cached[dev];
   }
   const int grid = (int)(tiles < cus ? tiles : cus);
   (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);

@@ -484,18 +484,43 @@ int dispatch_tile(const ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mega_conv2d_nhwc_plan(int M, int Cout, int K, int in_dtype) {
+// kind * 1e6 + bm * 1e3 + bn of the kernel a launch is dispatched to.  kinds: 0 igemm_kernel (this file), 8 igemm8 matrix
+// class, 7 igemm8 streaming class (1x1, K <= 512), 6 conv64.hip.  The shape-complete form asks the SAME predicates the
+// launch path uses (mega_conv64_supports, mega_igemm8_supports): profiler families, the roofline attribution and
+// mega_conv2d_nhwc_tile name the kernel that really runs (the (M, Cout, K) form guessed conv64 from K = 576).
+static int plan_of(const ConvParams& p, bool bf16_in, bool f32_out) {
+  if (bf16_in && !f32_out && !getenv("MEGA_IGEMM_TILE") && mega_conv64_supports(p, 0)) return 6 * 1000000 + 256 * 1000 + 64;
   int kind = 0, bm = 0, bn = 0;
-  // (kind 6: conv64.hip -- the only K = 576 / Cout = 64 bf16 layer of these models is layer1's 3x3 conv; the real
-  // routing, mega_conv2d_nhwc_ws, also checks the kernel shape and the tile count)
-  if (in_dtype == MEGA_BF16 && Cout == 64 && K == 576 && M >= 16384 && !getenv("MEGA_IGEMM_TILE") &&
-      !(getenv("MEGA_CONV64") && getenv("MEGA_CONV64")[0] == '0'))
-    return 6 * 1000000 + 256 * 1000 + 64;
-  choose_tile(M, Cout, K, choose_ksplit(K), in_dtype == MEGA_BF16, kind, bm, bn);
-  if (kind == 8 && (K >> 6) < 1) { kind = 0; bm = 128; bn = 128; }
-  // kind 7 = igemm8's streaming class (K <= 512 implies a 1x1 layer here: Cin is a multiple of 64, so a 3x3 has K >= 576)
-  if (kind == 8 && mega_igemm8_streaming(1, K) && choose_ksplit(K) == 1) kind = 7;
+  choose_tile(p.M, p.Cout, p.K, choose_ksplit(p.K), bf16_in, kind, bm, bn);
+  if (kind == 8 && !(bf16_in && mega_igemm8_supports(p))) { kind = 0; bm = 128; bn = 128; }
+  if (kind == 8 && mega_igemm8_streaming(p.R * p.S, p.K) && choose_ksplit(p.K) == 1) kind = 7;
   return kind * 1000000 + bm * 1000 + bn;
+}
+
+extern "C" int mega_conv2d_nhwc_plan_ex(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil,
+                                        int ldo, int has_residual, int in_dtype, int out_dtype) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || dil <= 0 || pad < 0) return -1;
+  ConvParams p = {};
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) return -1;
+  p.M = N * p.Ho * p.Wo;
+  p.K = R * S * Cin;
+  p.ldo = ldo > 0 ? ldo : Cout;
+  p.ldr = p.ldo;
+  p.res = has_residual ? (const void*)&p : nullptr;      // (only tested against null)
+  p.ksplit = 1;
+  const size_t esz = in_dtype == MEGA_BF16 ? 2 : 4;
+  const size_t ib = (size_t)N * H * W * Cin * esz, wb = (size_t)Cout * p.K * esz;
+  p.in_bytes = ib >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned)ib;
+  p.w_bytes = wb >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned)wb;
+  return plan_of(p, in_dtype == MEGA_BF16, out_dtype == MEGA_F32);
+}
+
+// the (M, Cout, K) form: a 1x1 layer / linear of that GEMM shape (bf16 or f32 output does not change the tile)
+extern "C" int mega_conv2d_nhwc_plan(int M, int Cout, int K, int in_dtype) {
+  return mega_conv2d_nhwc_plan_ex(M, 1, 1, K, Cout, 1, 1, 1, 0, 1, Cout, 0, in_dtype, in_dtype);
 }
 
 extern "C" int mega_conv2d_nhwc_tile(int M, int Cout, int K) { return mega_conv2d_nhwc_plan(M, Cout, K, MEGA_BF16) % 1000000; }

@@ -159,6 +159,7 @@ class ClipEngine(object):
         self.keep_logits = keep_logits    # tests: logits_log[i] = predictor class logits of the i-th key frame stepped
         self.logits_log = []
         self.key_boxes_log = []           # and the key frame's proposal boxes (rows of logits_log[i])
+        self.key_index_log = []           # and their flat anchor indices (only with model.rpn.keep_index)
         self.static_steps = 0
         self._rec_cache = {}              # frame id -> record (reuse_records)
         self._rec_pending = set()         # frame ids whose record is being computed by an enqueued batch
@@ -330,8 +331,11 @@ class ClipEngine(object):
         self.graph_stats["replayed"] += 1
         st = ent["st"]
         # the graph's outputs are overwritten by the next replay: hand out copies (6 MB per 16-frame batch)
-        return {"props": st["props"].clone(), "scores": st["scores"].clone(), "cnt": cnt,
-                "feats": st["feats"].clone(), "want": st["want"]}
+        out = {"props": st["props"].clone(), "scores": st["scores"].clone(), "cnt": cnt,
+               "feats": st["feats"].clone(), "want": st["want"]}
+        if "index" in st:
+            out["index"] = st["index"].clone()
+        return out
 
     def shard_plan(self, jobs, rank=None, world=None):
         """How a frame-stage batch is dealt to the ranks.  Jobs are grouped by their row count (local-window frames:
@@ -595,6 +599,7 @@ class ClipEngine(object):
                     if self.keep_logits:     # (sharded: only this rank's own key frames have logits here)
                         self.logits_log += [None if x is None else x.float().clone() for x in m.last_logits_batch]
                         self.key_boxes_log += [f["rois_key"].clone() for f in frames]
+                        self.key_index_log += [None if f.get("index_key") is None else f["index_key"].clone() for f in frames]
                     del prepared[:]
 
                 for i, js in zip(range(b[0], b[1]), per_step):

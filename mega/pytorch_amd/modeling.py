@@ -340,14 +340,17 @@ class RPNWithRefModule(nn.Module):
         self.post_nms_top_n = {"key": c.POST_NMS_TOP_N_TEST, "ref": cfg.MODEL.VID.RPN.REF_POST_NMS_TOP_N}
         self.nms_thresh, self.min_size = c.NMS_THRESH, c.MIN_SIZE
         self.strict_gt = bool(getattr(cfg, "NMS_STRICT_GT", True))
+        self.keep_index = False       # tests: frame records also carry the kept proposals' flat anchor indices
 
-    def propose(self, feat_nhwc, im_w, im_h, version="key"):
-        """Batched, sync-free: -> (proposals [B,post,4], objectness [B,post], counts [B] i32) on device."""
+    def propose(self, feat_nhwc, im_w, im_h, version="key", want_index=False):
+        """Batched, sync-free: -> (proposals [B,post,4], objectness [B,post], counts [B] i32[, anchor index [B,post] i32])
+        on device."""
         rpn_out = self.head.run(feat_nhwc)
         B, H, W, _ = feat_nhwc.shape
         cell = next(iter(self.anchor_generator.cell_anchors)).to(feat_nhwc.device).float().contiguous()
         return ops.rpn_select(rpn_out, cell, H, W, self.anchor_generator.strides[0], self.pre_nms_top_n[version],
-                              self.post_nms_top_n[version], self.nms_thresh, self.min_size, im_w, im_h, self.strict_gt)
+                              self.post_nms_top_n[version], self.nms_thresh, self.min_size, im_w, im_h, self.strict_gt,
+                              want_index=want_index)
 
     def forward(self, images, features, targets=None, version="key"):
         if self.training:
@@ -455,9 +458,9 @@ class MEGAFeatureExtractor(_Packed):
         pk["fc_w"] = [w0.contiguous().to(dtype).to(device)] + [self.l_fcs[i].weight.detach().to(dtype).to(device).contiguous()
                                                                 for i in range(1, self.stage)]
         pk["fc_b"] = [self.l_fcs[i].bias.detach().float().to(device).contiguous() for i in range(self.stage)]
-        if self.stream != dtype:      # f32 activation stream in bf16 mode: the stage FCs read and write it in exact f32
-            for i in range(1, self.stage):
-                pk["fc_w"][i] = self.l_fcs[i].weight.detach().float().to(device).contiguous()
+        if self.stream != dtype:      # f32 activation stream in bf16 mode: the stage FCs read and write it at ~2^-16 --
+            for i in range(1, self.stage):     # split-precision operands on the bf16 matrix cores (ops.split_bf16x3)
+                pk["fc_w"][i] = ops.split_weight_bf16x3(self.l_fcs[i].weight.detach().float()).to(device)
         if self.conv is not None:
             pk["rc_w"] = _pack_conv(self.conv, dtype).to(device)
             pk["rc_b"] = self.conv.bias.detach().float().to(device).contiguous()
@@ -530,6 +533,14 @@ class MEGAFeatureExtractor(_Packed):
         pk = self._packed(self.dtype, feats.device)
         return relation_attention_forward(pk["global"][i], feats, self.global_cache[-1]["feats"], residual=True)
 
+    def _stage_fc(self, pk, i, x):
+        """relu(l_fcs[i](x)) (:826-827) on the activation stream: in the stream's dtype; an f32 stream over bf16 compute
+        goes through the bf16 matrix cores with split operands ([hi | lo | hi] . [Wh | Wh | Wl]: x . W to ~2^-16)."""
+        if self.stream != self.dtype:
+            return ops.linear(ops.split_bf16x3(x.contiguous()), pk["fc_w"][i], pk["fc_b"][i], relu=True,
+                              out_dtype=torch.float32)
+        return ops.linear(x, pk["fc_w"][i], pk["fc_b"][i], relu=True)
+
     # ---- aggregation for one key frame (:898-933 after the fc0 line)
     def aggregate(self, x, rois_key, rois, rois_dis, x_ref, dis_index=None, x_ref_dis=None):
         """x [nk,1024] key-frame fc0 features, rois_key [nk,4]; rois [Nl,4] / x_ref [Nl,1024] the local window
@@ -580,7 +591,7 @@ class MEGAFeatureExtractor(_Packed):
             elif self.memory_enable and self.cache_memory_kv:
                 self._remember_kv(i, k_loc, vt_loc)
             if i != self.stage - 1:
-                feats_cur = ops.linear(feats_cur, pk["fc_w"][i + 1], pk["fc_b"][i + 1], relu=True)
+                feats_cur = self._stage_fc(pk, i + 1, feats_cur)
             if i == self.stage - 1:
                 x = feats_cur
             elif i == self.stage - 2:
@@ -772,7 +783,7 @@ class MEGAFeatureExtractor(_Packed):
             feats_cur, feats_ref = {}, {}
             if own:
                 ncur = [outs[t].shape[0] for t in own]
-                fc = ops.linear(cat_rows([outs[t] for t in own]), pk["fc_w"][i + 1], pk["fc_b"][i + 1], relu=True)
+                fc = self._stage_fc(pk, i + 1, cat_rows([outs[t] for t in own]))
                 o = 0
                 for j, t in enumerate(own):
                     nx = fc[o:o + ncur[j]]
@@ -998,8 +1009,11 @@ class GeneralizedRCNNMEGA(nn.Module):
 
     @torch.no_grad()
     def frame_stage_a1(self, c4, W, H):
-        props, scores, cnt = self.rpn.propose(c4, W, H, "key")           # [B,K,4], [B,K], [B] (device)
-        return {"c4": c4, "props": props, "scores": scores, "cnt": cnt}
+        res = self.rpn.propose(c4, W, H, "key", want_index=self.rpn.keep_index)   # [B,K,4], [B,K], [B] (device)
+        a = {"c4": c4, "props": res[0], "scores": res[1], "cnt": res[2]}
+        if self.rpn.keep_index:
+            a["index"] = res[3]
+        return a
 
     @torch.no_grad()
     def frame_stage_b1(self, c4):
@@ -1033,7 +1047,10 @@ class GeneralizedRCNNMEGA(nn.Module):
         boxes = props.view(-1, 4).index_select(0, cache[1])
         rois5 = torch.cat([cache[2], boxes], dim=1)
         feats = fe.pooled_fc(x5, rois5)
-        return {"props": props, "scores": a["scores"], "cnt": a["cnt"], "feats": feats, "want": want}
+        st = {"props": props, "scores": a["scores"], "cnt": a["cnt"], "feats": feats, "want": want}
+        if "index" in a:
+            st["index"] = a["index"]
+        return st
 
     @torch.no_grad()
     def frame_stage_async(self, imgs, want):
@@ -1051,6 +1068,8 @@ class GeneralizedRCNNMEGA(nn.Module):
         for b, w in enumerate(st["want"]):
             n = min(int(counts[b]), w)
             out.append({"boxes": st["props"][b, :n], "scores": st["scores"][b, :n], "feats": st["feats"][o:o + n]})
+            if "index" in st:
+                out[-1]["index"] = st["index"][b, :n]
             o += w
         return out
 
@@ -1192,7 +1211,7 @@ class GeneralizedRCNNMEGA(nn.Module):
             a, b = max(0, e - cap) - lo0, e - lo0
             key = used[a + self.key_frame_location]
             nsj = tuple(ns[a:b])
-            frames.append({"x": key["feats"], "rois_key": key["boxes"], "scores": key["scores"],
+            frames.append({"x": key["feats"], "rois_key": key["boxes"], "scores": key["scores"], "index_key": key.get("index"),
                            "rois": tape_r[offc[a]:offc[b]], "rois_dis": tape_d[offd[a]:offd[b]],
                            "x_ref": tape_f[offc[a]:offc[b]], "dis_index": self._dis_index(nsj, tape_f.device),
                            "dis_key": nsj, "glob": globs[j]})

@@ -91,9 +91,15 @@ def _pe(tok):
 
 
 # ------------------------------------------------------------------------------------------------ conv / linear
-def _igemm_family(lib, M, Cout, K, dtype):
-    """name of the kernel instantiation a conv / linear of this GEMM shape is dispatched to (profiler families)"""
-    t = lib.mega_conv2d_nhwc_plan(M, Cout, K, _DT[dtype])
+def _igemm_family(lib, M, Cout, K, dtype, shape=None):
+    """name of the kernel instantiation a conv / linear is dispatched to (profiler families).  shape = (N, H, W, Cin, R,
+    S, stride, pad, dil, ldo, has_residual, out dtype): the layer itself, asked through the launch path's own predicates;
+    without it the (M, Cout, K) GEMM shape of a 1x1 layer / linear."""
+    if shape is not None:
+        N, H, W, Cin, R, S, stride, pad, dil, ldo, has_res, odt = shape
+        t = lib.mega_conv2d_nhwc_plan_ex(N, H, W, Cin, Cout, R, S, stride, pad, dil, ldo, int(has_res), _DT[dtype], _DT[odt])
+    else:
+        t = lib.mega_conv2d_nhwc_plan(M, Cout, K, _DT[dtype])
     kind, t = t // 1000000, t % 1000000
     if kind == 6:
         return "conv64_bf16_3x3"
@@ -123,7 +129,8 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
     _tok = None
     if _PROF is not None:      # family = the kernel symbol rocprofv3 would report for this launch
-        _tok = _pb(_igemm_family(lib, N * Ho * Wo, Cout, R * S * Cin, x.dtype),
+        _tok = _pb(_igemm_family(lib, N * Ho * Wo, Cout, R * S * Cin, x.dtype,
+                                 (N, H, W, Cin, R, S, stride, pad, dil, Cout, residual is not None, odt)),
                    2.0 * N * Ho * Wo * Cout * R * S * Cin,
                    x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size()
                    + (0 if residual is None else residual.numel() * residual.element_size()),
@@ -611,6 +618,29 @@ def cast_bf16(x):
     _pe(_tok)
     _lib.check(rc, "mega_cast_f32_to_bf16")
     return out
+
+
+def split_bf16x3(x):
+    """f32 [M,K] -> bf16 [M,3K] = [hi | lo | hi] (hi = bf16(x), lo = bf16(x - hi)): A operand of a split-precision bf16
+    GEMM against weights packed by split_weight_bf16x3."""
+    _gpu(x)
+    lib = _lib.load()
+    M, K = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and K % 8 == 0
+    out = torch.empty((M, 3 * K), dtype=torch.bfloat16, device=x.device)
+    _tok = _pb("assemble", 0.0, x.numel() * 10.0)
+    rc = lib.mega_split_f32_to_bf16x3(_ptr(x), _ptr(out), M, K, _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_split_f32_to_bf16x3")
+    return out
+
+
+def split_weight_bf16x3(w32):
+    """f32 [N,K] -> bf16 [N,3K] = [Wh | Wh | Wl]: with split_bf16x3(x) as the other operand, the K = 3K contraction is
+    x_hi.Wh + x_lo.Wh + x_hi.Wl = x.W to ~2^-16 (host-side packing, once per model)."""
+    wh = w32.to(torch.bfloat16)
+    wl = (w32 - wh.float()).to(torch.bfloat16)
+    return torch.cat([wh, wh, wl], dim=1).contiguous()
 
 
 def linear_transposed(w, x, ld, residual=None):

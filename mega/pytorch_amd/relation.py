@@ -36,7 +36,7 @@ class RelationWeights(object):
         # roundings of ref / V do: 3.3e-4 of the bf16 head's 6.5e-4 median logit error (tools/head_precision_cpu.py).
         self.wv_lo = None
         if split_v and dtype != torch.float32:
-            self.wv_lo = (wv32 - self.wv.float().cpu()).to(device=device, dtype=dtype).contiguous()
+            self.wv_lo = (wv32 - self.wv.float().to(wv32.device)).to(device=device, dtype=dtype).contiguous()
         self.bv = g(("Wvs", ".bias")).to(device).contiguous()
         self.with_pos = with_pos
         if with_pos:

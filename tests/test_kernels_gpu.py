@@ -709,7 +709,12 @@ def test_conv64_persistent_bit_equal_to_generic_tiles(dev, shape, monkeypatch):
     sc = (torch.rand((64,), generator=g) + 0.5).to(dev)
     bi = (torch.randn((64,), generator=g) * 0.1).to(dev)
     from mega.pytorch_amd import _lib
-    assert _lib.load().mega_conv2d_nhwc_plan(N * H * W, 64, 576, 1) // 1000000 == 6      # dispatched to conv64
+    lib = _lib.load()
+    assert lib.mega_conv2d_nhwc_plan_ex(N, H, W, 64, 64, 3, 3, 1, 1, 1, 64, 0, 1, 1) // 1000000 == 6      # dispatched to conv64
+    # the plan asks the launch path's own predicate: a residual, an f32 output or a stride keep the layer on the generic tiles
+    assert lib.mega_conv2d_nhwc_plan_ex(N, H, W, 64, 64, 3, 3, 1, 1, 1, 64, 1, 1, 1) // 1000000 != 6
+    assert lib.mega_conv2d_nhwc_plan_ex(N, H, W, 64, 64, 3, 3, 1, 1, 1, 64, 0, 1, 0) // 1000000 != 6
+    assert lib.mega_conv2d_nhwc_plan_ex(1, 16, 16, 64, 64, 3, 3, 1, 1, 1, 64, 0, 1, 1) // 1000000 != 6    # one tile: too few
     for relu in (True, False, 2):
         y = ops.conv2d_nhwc(x, w, sc, bi, pad=1, relu=relu)
         monkeypatch.setenv("MEGA_IGEMM_TILE", "128x64")
@@ -717,7 +722,103 @@ def test_conv64_persistent_bit_equal_to_generic_tiles(dev, shape, monkeypatch):
         monkeypatch.delenv("MEGA_IGEMM_TILE")
         torch.cuda.synchronize()
         assert torch.equal(y, y_ref), "relu=%s: %d elements differ" % (relu, (y != y_ref).sum().item())
+        # bit level (torch.equal treats -0 and +0 as equal): the ReLU epilogues agree on the sign of zero as well
+        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), "relu=%s: bit patterns differ" % (relu,)
     ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), padding=1)
     ref = F.relu(ref * sc.cpu().view(1, -1, 1, 1) + bi.cpu().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
     y = ops.conv2d_nhwc(x, w, sc, bi, pad=1, relu=True)
     assert _relerr(y.float().cpu(), ref) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ f32 head stream (round 4)
+@pytest.mark.parametrize("n", [8, 1024 * 675, 1024 * 3 + 5, 7])
+def test_cast_f32_to_bf16(dev, n):
+    """ops.cast_bf16 == torch's float -> bfloat16 (round to nearest even), bit for bit, incl. a tail that is not a
+    multiple of the 8-element vectors."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn((n,), generator=g) * 3
+    x[:4] = torch.tensor([0.0, -0.0, 1e-40, 65504.0])[:min(4, n)] if n >= 4 else x[:4]
+    got = ops.cast_bf16(x.to(dev))
+    assert got.dtype == torch.bfloat16 and torch.equal(got.cpu().view(torch.int16), x.to(torch.bfloat16).view(torch.int16))
+
+
+@pytest.mark.parametrize("shape", [(300, 750), (129, 70), (40, 1500)])     # last: split keys + combine
+def test_relation_attention_f32_stream(dev, shape):
+    """io_f32 (cfg.HEAD_STREAM float32): bf16 operands, f32 residual and f32 output.  The attention term is the bf16
+    kernel's own (same MFMAs, same softmax): out_f32 - resid == the bare bf16-mode output before its final rounding, so
+    rounding it to bf16 reproduces the bare call's bits up to one bf16 ulp of a double rounding; and it is close to the
+    f32 formula."""
+    ops = _ops()
+    Nq, Nk = shape
+    g = torch.Generator().manual_seed(Nq + 7 * Nk)
+    q = (torch.randn((Nq, 1024), generator=g) * 0.3).to(torch.bfloat16)
+    k = (torch.randn((Nk, 1024), generator=g) * 0.3).to(torch.bfloat16)
+    ld = (Nk + 31) // 32 * 32
+    vt = torch.zeros((1024, ld), dtype=torch.bfloat16)
+    vt[:, :Nk] = (torch.randn((1024, Nk), generator=g) + 0.5).to(torch.bfloat16)
+    resid = torch.randn((Nq, 1024), generator=g) * 4
+    bv = torch.randn((1024,), generator=g) * 0.1
+    bare = ops.relation_attention(q.to(dev), k.to(dev), vt.to(dev), Nk, resid=None, bias_v=bv.to(dev))
+    out = ops.relation_attention(q.to(dev), k.to(dev), vt.to(dev), Nk, resid=resid.to(dev), bias_v=bv.to(dev))
+    assert out.dtype == torch.float32 and bare.dtype == torch.bfloat16
+    att = out.cpu() - resid                  # (carries the f32 rounding of resid + att: ~1e-6 relative to |resid|)
+    assert (att - bare.float().cpu()).abs().max() <= 1.02 * 2.0 ** -8 * bare.float().abs().max().item() + 4e-6 * resid.abs().max().item()
+    # the literal formula on the same (bf16-valued) operands
+    qh = q.float().view(Nq, 16, 64).permute(1, 0, 2)
+    kh = k.float().view(Nk, 16, 64).permute(1, 0, 2)
+    p = F.softmax(torch.bmm(qh, kh.transpose(1, 2)) / 8.0, dim=2)
+    ref = torch.bmm(p, vt.float()[:, :Nk].view(16, 64, Nk).transpose(1, 2)).permute(1, 0, 2).reshape(Nq, 1024) + bv + resid
+    assert _relerr(out.cpu(), ref) < 2e-3
+    # the batched entry gives the same bits
+    both = ops.relation_attention_batched([{"q": q.to(dev), "k": k.to(dev), "vt": vt.to(dev), "Nk": Nk, "resid": resid.to(dev),
+                                            "bias_v": bv.to(dev)} for _ in range(2)])
+    assert torch.equal(both[0], out) and torch.equal(both[1], out)
+
+
+def test_attention_row_sum_uses_the_rounded_p(dev):
+    """bf16 mode: softmax weights are rounded to bf16 for the PV MFMA and the row sum is taken over the ROUNDED values,
+    so the output is an exact weighted mean of the values: with every value row equal to a constant c the output is c to
+    f32 round-off whatever the weights are (with the sum over the unrounded weights it was off by ~1e-3 c / sqrt(keys))."""
+    ops = _ops()
+    Nq, Nk = 200, 333
+    g = torch.Generator().manual_seed(5)
+    q = (torch.randn((Nq, 1024), generator=g)).to(torch.bfloat16)
+    k = (torch.randn((Nk, 1024), generator=g)).to(torch.bfloat16)
+    ld = (Nk + 31) // 32 * 32
+    c = (torch.randn((1024,), generator=g) * 3).to(torch.bfloat16)
+    vt = torch.zeros((1024, ld), dtype=torch.bfloat16)
+    vt[:, :Nk] = c[:, None]
+    zero = torch.zeros((Nq, 1024))
+    out = ops.relation_attention(q.to(dev), k.to(dev), vt.to(dev), Nk, resid=zero.to(dev))
+    assert (out.cpu() - c.float()[None, :]).abs().max() <= 2e-6 * c.float().abs().max()
+
+
+def test_linear_transposed_residual_and_split_v(dev):
+    """ops.linear_transposed(residual=...) and relation.project_v with split weights: V'^T = Wv . ref rounded ONCE per
+    element -- the error against the f32 product has no component common to all keys (the mean over the keys of the error
+    is ~sqrt(keys) below a single rounding), unlike the one-pass projection with bf16 weights."""
+    ops = _ops()
+    from types import SimpleNamespace
+    from mega.pytorch_amd.relation import project_v
+    g = torch.Generator().manual_seed(9)
+    M, K, N = 1111, 1024, 1024
+    ld = (M + 31) // 32 * 32
+    w32 = torch.randn((N, K), generator=g) * 0.02
+    x = (torch.rand((M, K), generator=g) + 0.2).to(torch.bfloat16)      # post-ReLU-like: a large common part
+    wh = w32.to(torch.bfloat16)
+    wl = (w32 - wh.float()).to(torch.bfloat16)
+    exact = (x.double() @ w32.double().t()).t()
+    r = (torch.randn((N, ld), generator=g)).to(torch.bfloat16)
+    got = ops.linear_transposed(wh.to(dev), x.to(dev), ld, residual=r.to(dev)).float().cpu()
+    want = ((x.float() @ wh.float().t()).t() + r.float()[:, :M]).to(torch.bfloat16).float()
+    assert (got[:, :M] - want).abs().max() <= 2.0 ** -7 * want.abs().max() and torch.equal(got[:, M:], r.float()[:, M:] * 0)
+    one = project_v(SimpleNamespace(wv=wh.to(dev), wv_lo=None), x.to(dev), ld).float().cpu()[:, :M]
+    two = project_v(SimpleNamespace(wv=wh.to(dev), wv_lo=wl.to(dev)), x.to(dev), ld).float().cpu()[:, :M]
+    e1, e2 = (one.double() - exact), (two.double() - exact)
+    scale = exact.abs().mean()
+    # per-element error: both a bf16 rounding of the result; error of the MEAN over the keys: the split form averages out
+    assert e2.abs().max() <= 1.1 * 2.0 ** -8 * exact.abs().max()      # (bf16 half-ulp of the largest element)
+    m1, m2 = e1.mean(dim=1).abs().mean() / scale, e2.mean(dim=1).abs().mean() / scale
+    print("common-mode error of V'^T over %d keys: one pass %.2e, split %.2e (relative to mean |V|)" % (M, m1, m2))
+    assert m2 < 1.5e-4 and m2 < 0.35 * m1
