@@ -85,9 +85,11 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true", help="launch the frame stage kernel by kernel (no hipGraph)")
     ap.add_argument("--reuse-records", action="store_true",
                     help="compute each frame's record once per video (engine option; NOT the headline configuration)")
-    ap.add_argument("--aggregation", default="batched", choices=["batched", "static", "per-frame"],
+    ap.add_argument("--aggregation", default="batched", choices=["batched", "batched-eager", "static", "per-frame"],
                     help="batched (default): the aggregation of a step-batch runs stage by stage over all its key "
-                         "frames; static: one hipGraph replay per key frame on fixed-address pools; per-frame: eager steps")
+                         "frames, replayed from one hipGraph on fixed-address state once the pools are full; batched-eager: "
+                         "the same launched kernel by kernel (round 3); static: one hipGraph replay per key frame on "
+                         "fixed-address pools; per-frame: eager steps")
     ap.add_argument("--ramp", action="store_true",
                     help="short first / last step-batch inside a timed block (ClipEngine ramp; measured slower: 555 vs 585 FPS)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="steady key frames timed by the CPU baseline (memory full)")
@@ -285,13 +287,14 @@ def f32_parity_leg(args, device, clip, gfor, T, spb):
     while pos < pre:
         runner.run(clip, T, gfor, first=pos, last=pos + spb)
         pos += spb
-    for _ in range(4):
+    for _ in range(6):
         before = dict(runner.graph_stats)
         runner.run(clip, T, gfor, first=pos, last=pos + spb)
         torch.cuda.synchronize()
         pos += spb
         if runner.steady_state()["steady"] and runner.graph_stats["eager"] == before["eager"] and \
-                runner.graph_stats["captured"] == before["captured"]:
+                runner.graph_stats["captured"] == before["captured"] and \
+                runner.graph_stats.get("agg_captured", 0) == before.get("agg_captured", 0):
             break
     st0 = runner.steady_state()
     g0 = dict(runner.graph_stats)
@@ -311,7 +314,8 @@ def f32_parity_leg(args, device, clip, gfor, T, spb):
            "frac_of_157TF": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / 157.3e12, 4) if args.arch == "R-101" else None,
            "peak_tflops": 157.3, "key_frames_per_block": spb, "timed_blocks": len(blocks),
            "timed_blocks_ms": [round(1e3 * b, 2) for b in blocks], "pools_full": bool(st0["pools_full"]),
-           "graph_captures_in_timed_region": (g1["captured"] - g0["captured"]) + (g1["eager"] - g0["eager"]),
+           "graph_captures_in_timed_region": (g1["captured"] - g0["captured"]) + (g1["eager"] - g0["eager"])
+           + (g1.get("agg_captured", 0) - g0.get("agg_captured", 0)),
            "parity": "logits within 1e-3 of the reference / oracle, identical detections (tests/test_e2e_gpu.py: "
                      "test_r101_600x1000_f32_vs_oracle, test_f32_long_clip_vs_reference_fixture)"}
     del runner, model
@@ -378,7 +382,8 @@ def main():
     runner = eng.ClipEngine(model, steps_per_batch=spb, dist_group=group, overlap=not args.no_overlap,
                             graphs=not args.no_graphs, reuse_records=args.reuse_records,
                             static_aggregation=args.aggregation == "static",
-                            batch_aggregation=args.aggregation == "batched", ramp=args.ramp)
+                            batch_aggregation=args.aggregation in ("batched", "batched-eager"), ramp=args.ramp,
+                            graph_aggregation=args.aggregation == "batched")
 
     def barrier():
         torch.cuda.synchronize()
@@ -410,8 +415,9 @@ def main():
         barrier()
         pos += KF
         after = runner.graph_stats
-        if runner.steady_state()["steady"] and (args.no_graphs or (after["eager"] == before["eager"] and
-                                                                   after["captured"] == before["captured"])):
+        if runner.steady_state()["steady"] and (args.no_graphs or (
+                after["eager"] == before["eager"] and after["captured"] == before["captured"]
+                and after.get("agg_captured", 0) == before.get("agg_captured", 0))):
             break
     st0 = engine_state()
     log("pre-roll done at key frame %d: %s" % (pos, st0))
@@ -455,7 +461,8 @@ def main():
     log("timed region: %d blocks of %d steps (%d key frames), median %.4fs (%.2f frames/s), min %.4f max %.4f, total %.2fs" % (
         len(blocks), K, KF, elapsed, fps, srt[0], srt[-1], sum(blocks)))
     captures_in_region = (st1["graph_stats"]["captured"] - st0["graph_stats"]["captured"]
-                          + st1["graph_stats"]["eager"] - st0["graph_stats"]["eager"])
+                          + st1["graph_stats"]["eager"] - st0["graph_stats"]["eager"]
+                          + st1["graph_stats"].get("agg_captured", 0) - st0["graph_stats"].get("agg_captured", 0))
     log("engine state after the timed region: %s" % (st1,))
     if not args.no_graphs:
         assert captures_in_region == 0, "a frame-stage batch ran eagerly / was captured inside the timed region: %s -> %s" % (st0, st1)

@@ -79,6 +79,13 @@ int mega_stem_conv_bn_relu(const float* in, const float* w_tap64, const float* s
  * Image pixels and weights are rounded to bf16, accumulation is f32. */
 int mega_stem_conv_bn_relu_bf16(const float* in, const void* w_n176_bf16, const float* scale, const float* bias,
                                 void* out, int N, int H, int W, void* stream);
+/* The bf16 stem fed by the uint8 frames themselves, [N][H][W][3] RGB: the preprocessing of mega_preprocess_frames
+ * (data/transforms/transforms.py:83-129: ToTensor, to_bgr255, Normalize with std 1) is applied on the patch load --
+ * (float)byte - mean[c] for output channel c -- so the f32 image never exists in HBM.  Same bits as
+ * mega_preprocess_frames followed by mega_stem_conv_bn_relu_bf16. */
+int mega_stem_conv_bn_relu_bf16_u8(const void* frames_u8, const void* w_n176_bf16, const float* scale, const float* bias,
+                                   void* out, int N, int H, int W, float mean0, float mean1, float mean2, int to_bgr,
+                                   void* stream);
 
 /* F.max_pool2d(kernel 3, stride 2, padding 1) on NHWC (resnet.py:365). */
 int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);

@@ -504,10 +504,18 @@ __host__ __device__ constexpr int stem_group_off(int g) {   // LDS element offse
   return (gg / 7) * (SM_PH * SM_PS) + (gg % 7) * SM_PS;
 }
 
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ in, const bf16_t* __restrict__ w,
+// U8: the input is the uint8 HWC RGB frame batch itself and the preprocessing (ToTensor, to_bgr255, Normalize:
+// mega_core/data/transforms/transforms.py:83-129 = frames.hip's preprocess_kernel) happens on the patch load:
+// value = (float)byte - mean[c], the same f32 subtraction, then the same f32 -> bf16 conversion -- identical bits, a quarter
+// of the input bytes, no f32 image in HBM and no preprocess launch.
+template <bool U8>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const void* __restrict__ in_, const bf16_t* __restrict__ w,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out,
-                                                        int N, int H, int W, int Ho, int Wo) {
+                                                        int N, int H, int W, int Ho, int Wo, float m0, float m1, float m2,
+                                                        int to_bgr) {
+  const float* __restrict__ in = reinterpret_cast<const float*>(in_);
+  const unsigned char* __restrict__ in8 = reinterpret_cast<const unsigned char*>(in_);
   // one buffer: [patch | weights] while the MFMAs run, then the block's 8 x 32 x 64 output tile (144-B pixel stride)
   constexpr int SM_PATCH_B = (3 * SM_PH * SM_PS * 2 + 15) / 16 * 16, SM_OUT_PS = 144;
   constexpr int SM_LDS_B = SM_TY * SM_TX * SM_OUT_PS > SM_PATCH_B + 64 * SM_WS * 2 ? SM_TY * SM_TX * SM_OUT_PS
@@ -535,8 +543,14 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     const int y = rem / SM_PS, x = rem - y * SM_PS;
     const int iy = iy0 + y, ix = ix0 + x;
     pv[i] = 0.f;
-    if (e < 3 * SM_PH * SM_PS && x < SM_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-      pv[i] = in[((size_t)(n * 3 + c) * H + iy) * W + ix];
+    if (e < 3 * SM_PH * SM_PS && x < SM_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+      if (U8) {
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+        pv[i] = (float)in8[(((size_t)n * H + iy) * W + ix) * 3 + (to_bgr ? 2 - c : c)] - mean;
+      } else {
+        pv[i] = in[((size_t)(n * 3 + c) * H + iy) * W + ix];
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < NWL; ++i) {
@@ -622,8 +636,23 @@ extern "C" int mega_stem_conv_bn_relu_bf16(const float* in, const void* w_n176_b
   if (!in || !w_n176_bf16 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   dim3 grid(cdiv(Wo, SM_TX), cdiv(Ho, SM_TY), N);
-  hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)w_n176_bf16, scale,
-                     bias, (bf16_t*)out, N, H, W, Ho, Wo);
+  hipLaunchKernelGGL(stem_mfma_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const void*)in,
+                     (const bf16_t*)w_n176_bf16, scale, bias, (bf16_t*)out, N, H, W, Ho, Wo, 0.f, 0.f, 0.f, 0);
+  return mega_check_launch();
+}
+
+// The same layer fed by the uint8 frames [N][H][W][3] (RGB): preprocessing fused into the patch load (see the kernel).
+// mean[c] is subtracted from OUTPUT channel c of the preprocessed image (to_bgr: channel 0 = B).  Same bits as
+// mega_preprocess_frames + mega_stem_conv_bn_relu_bf16.
+extern "C" int mega_stem_conv_bn_relu_bf16_u8(const void* frames_u8, const void* w_n176_bf16, const float* scale,
+                                              const float* bias, void* out, int N, int H, int W, float mean0, float mean1,
+                                              float mean2, int to_bgr, void* stream) {
+  mega_clear_error();
+  if (!frames_u8 || !w_n176_bf16 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  dim3 grid(cdiv(Wo, SM_TX), cdiv(Ho, SM_TY), N);
+  hipLaunchKernelGGL(stem_mfma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, frames_u8, (const bf16_t*)w_n176_bf16,
+                     scale, bias, (bf16_t*)out, N, H, W, Ho, Wo, mean0, mean1, mean2, to_bgr);
   return mega_check_launch();
 }
 

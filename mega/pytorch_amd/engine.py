@@ -109,7 +109,8 @@ class KeyFrameShard(object):
 
 class ClipEngine(object):
     def __init__(self, model, steps_per_batch=8, dist_group=None, overlap=True, graphs=True, reuse_records=False,
-                 static_aggregation=False, keep_logits=False, batch_aggregation=True, ramp=False, frame_model=None):
+                 static_aggregation=False, keep_logits=False, batch_aggregation=True, ramp=False, frame_model=None,
+                 graph_aggregation=True):
         """steps_per_batch: key-frame steps whose frame jobs are computed in one frame-stage batch
         (steady state: 2 frames per step).  dist_group: torch.distributed group to shard the frame stage over
         (None = single process).  overlap: use the two-stream pipeline (see module docstring).
@@ -147,6 +148,11 @@ class ClipEngine(object):
         # experimental, opt-in: steady-state aggregation steps on fixed-address pools, replayed from one hipGraph
         self._static = StaticAggregation(model, use_graph=graphs) if static_aggregation else None
         self.use_static = True            # False: step eagerly even when a StaticAggregation exists (instrumented passes)
+        # graph_aggregation (round 4, default with graphs + batched aggregation, single process): in steady state -- all
+        # pools full, every frame with all its proposals -- the BATCHED aggregation of a step-batch (prepare_batch +
+        # step_batch: ~100 launches, ~6 ms of Python) runs on fixed-address state and is replayed from one hipGraph
+        self._sbatch = None
+        self.graph_aggregation = bool(graph_aggregation and graphs)
         # batch_aggregation: the aggregation of all key frames of a step-batch runs stage by stage over the whole batch
         # (model.step_batch: projections / stage FCs as one GEMM each); off = one model.step() per key frame
         fe = getattr(getattr(getattr(model, "roi_heads", None), "box", None), "feature_extractor", None)
@@ -193,6 +199,8 @@ class ClipEngine(object):
             warm = self.graph_stats["replayed"] >= 1
             if self._static is not None and self.use_static:
                 warm = warm and self._static.replays >= 1
+            if self._sbatch is not None and self._sbatch.active:
+                warm = warm and self._sbatch.replays >= 1
         return {"pools_full": bool(full), "graphs_warm": bool(warm), "steady": bool(full and warm)}
 
     # ------------------------------------------------------------------ schedule
@@ -264,10 +272,19 @@ class ClipEngine(object):
         exist 40 % of the stage before its features do."""
         m = self.frame_model
         raw = imgs if isinstance(imgs, self._RawFrames) else None
+        # bf16 mode on the device: the stem reads the uint8 frames itself (preprocessing on its patch load: no f32 image
+        # in HBM, no preprocess launch -- same bits); everything else gets the preprocessed f32 batch
+        from .modeling import compute_dtype
+        u8 = (raw is not None and raw.is_cuda and compute_dtype(m.cfg) == torch.bfloat16
+              and getattr(m, "stem_reads_u8", False))
+        norm = (raw.mean, raw.to_bgr) if u8 else None
+
+        def stage_a(x):
+            if u8:
+                return m.frame_stage_a1(m.frame_stage_a0(x, norm), raw.shape[3], raw.shape[2])
+            return m.frame_stage_a(x)
         if not (self.use_graphs and imgs.is_cuda):
-            if raw is not None:
-                imgs = raw.materialize()
-            a = m.frame_stage_a(imgs)
+            a = stage_a(raw.u8 if u8 else (raw.materialize() if raw is not None else imgs))
             if on_counts is not None:
                 on_counts(a["cnt"])
             return m.frame_stage_b(a, want)
@@ -276,14 +293,12 @@ class ClipEngine(object):
         if ent is None:
             self._fgraphs[key] = {}
             self.graph_stats["eager"] += 1
-            if raw is not None:
-                imgs = raw.materialize()
-            a = m.frame_stage_a(imgs)
+            a = stage_a(raw.u8 if u8 else (raw.materialize() if raw is not None else imgs))
             if on_counts is not None:
                 on_counts(a["cnt"])
             return m.frame_stage_b(a, want)
         if "graph" not in ent:
-            ent["static_in"] = raw.materialize() if raw is not None else imgs.clone()
+            ent["static_in"] = raw.u8.clone() if u8 else (raw.materialize() if raw is not None else imgs.clone())
             torch.cuda.current_stream().synchronize()
             if self._graph_pool is None:          # all frame-stage graphs replay one after the other on one stream:
                 self._graph_pool = torch.cuda.graph_pool_handle()    # they can share one activation pool
@@ -300,7 +315,7 @@ class ClipEngine(object):
             g0, g1, gr, gb = (torch.cuda.CUDAGraph() for _ in range(4))
             W, H = imgs.shape[3], imgs.shape[2]
             with torch.cuda.graph(g0, pool=self._graph_pool, capture_error_mode="thread_local"):
-                ent["c4"] = m.frame_stage_a0(ent["static_in"])
+                ent["c4"] = m.frame_stage_a0(ent["static_in"], norm) if u8 else m.frame_stage_a0(ent["static_in"])
             with torch.cuda.graph(g1, pool=self._graph_pool, capture_error_mode="thread_local"):
                 ent["a"] = m.frame_stage_a1(ent["c4"], W, H)
             with torch.cuda.graph(gr, pool=self._graph_pool_r, capture_error_mode="thread_local"):
@@ -311,7 +326,9 @@ class ClipEngine(object):
             ent["e0"], ent["e1"] = torch.cuda.Event(), torch.cuda.Event()
             self.graph_stats["captured"] += 1
         cur = torch.cuda.current_stream()
-        if raw is not None:
+        if u8:
+            ent["static_in"].copy_(raw.u8)              # 1.8 MB per frame (the f32 image was 7.2 MB)
+        elif raw is not None:
             raw.materialize(out=ent["static_in"])       # (the capture batch: written twice, once)
         else:
             ent["static_in"].copy_(imgs)
@@ -583,6 +600,8 @@ class ClipEngine(object):
                            and m.roi_heads.box.feature_extractor.cache_memory_kv)
                 if batched and self._static is not None:
                     self._static.leave()          # the pools go back into the model's deques
+                if not batched and self._sbatch is not None:
+                    self._sbatch.leave()
                 prepared = []                     # (key frame index, (new local record, new global records)) of
                                                   # the steps awaiting prepare_batch() + step_batch()
 
@@ -592,8 +611,27 @@ class ClipEngine(object):
                     shard = None
                     if self.world > 1 or self.force_sharded:
                         shard = KeyFrameShard(self.dist, self.group, self.rank, self.world)
-                    frames = m.prepare_batch([st for _, st in prepared])
-                    outs = m.step_batch(frames, (W, H), shard)
+                    steps = [st for _, st in prepared]
+                    sb = self._sbatch
+                    if (self.graph_aggregation and self.use_static and shard is None and clip.is_cuda and prepared[0][0] > 0
+                            and len(steps) == self.steps_per_batch):
+                        if sb is None:
+                            sb = self._sbatch = StaticBatchAggregation(m, len(steps))
+                        if sb.ready(steps):
+                            c0 = sb.captures
+                            outs, frames = sb.step(steps, (W, H))
+                            self.graph_stats["agg_captured"] = self.graph_stats.get("agg_captured", 0) + sb.captures - c0
+                            self.graph_stats["agg_replayed"] = sb.replays
+                        else:
+                            sb.leave()
+                            sb = None
+                    else:
+                        if sb is not None:
+                            sb.leave()
+                        sb = None
+                    if sb is None:
+                        frames = m.prepare_batch(steps)
+                        outs = m.step_batch(frames, (W, H), shard)
                     for (i2, _), pd in zip(prepared, outs):
                         pending.append((i2, pd))
                     if self.keep_logits:     # (sharded: only this rank's own key frames have logits here)
@@ -617,6 +655,8 @@ class ClipEngine(object):
                     if i == 0:
                         if self._static is not None:
                             self._static.reset()
+                        if self._sbatch is not None:
+                            self._sbatch.reset()
                         m._reset(T)
                         for _ in range(m.key_frame_location + 1):
                             m.records.append(loc[0])
@@ -858,6 +898,192 @@ class StaticAggregation(object):
         self.fe.static_pools = None
         self.active = False
         self.graph = None
+
+
+class StaticBatchAggregation(object):
+    """The BATCHED aggregation of a step-batch (GeneralizedRCNNMEGA.prepare_batch + step_batch: tapes, 7 batched attention
+    stages, stage FCs, predictor, post-processing of S key frames; ~100 launches and ~6 ms of Python per 20 key frames) on
+    FIXED-ADDRESS state, captured once as a hipGraph and replayed with one host call per step-batch.
+
+    A driver-CLI block is one frame-stage batch followed by its aggregation: the aggregation's kernels are short, so the
+    host could not keep the queue full (0.5 ms of gaps per 22.5 ms block in round 3, more with the f32 head stream's extra
+    launches) -- a replay has none.
+
+    Steady state = the local window, the global pool and all memory pools are full and every record involved has all its
+    proposals: every tensor of the batch then has a fixed shape.  The per-video state (last 25 frame records, global
+    pool, memory pools with their cached K / V^T projections) lives in state tensors; a step copies the S new records into
+    input buffers (one launch), runs / replays the UNCHANGED prepare_batch + step_batch on deques that are views of the
+    state, and -- inside the captured region -- writes the state the batch leaves behind back into the state tensors.  The
+    kernels and their operand values are those of the eager path: identical bits (tests/test_e2e_gpu.py::
+    test_graph_aggregation_is_bit_identical; the host logic on the CPU twins in tests/test_host_logic.py).
+    Anything else (a ragged record, a short last batch, a new video, sharding) leaves: the state goes back into the
+    model's own deques and the eager path continues."""
+
+    def __init__(self, model, S, use_graph=True):
+        self.m = model
+        self.fe = model.roi_heads.box.feature_extractor
+        self.S = S
+        self.use_graph = use_graph
+        self.active = False
+        self.graph = None
+        self.replays = 0
+        self.captures = 0
+
+    # ---- conditions
+    def ready(self, steps):
+        m, fe = self.m, self.fe
+        if not (m.memory_enable and m.global_enable and fe.cache_memory_kv and fe.static_pools is None):
+            return False
+        if len(steps) != self.S:
+            return False
+        for new_local, new_globals in steps:
+            if new_local is None or len(new_globals) != 1 or new_local["boxes"].shape[0] != m.key_num:
+                return False
+            if new_globals[0]["feats"].shape[0] < m.base_num:
+                return False
+        if self.active:
+            return True
+        if len(m.records) != m.all_frame_interval or any(r["boxes"].shape[0] != m.key_num for r in m.records):
+            return False
+        gq = fe.global_queue_list[0]["feats"]
+        if len(gq) != fe.global_size or any(g.shape[0] != m.base_num for g in gq):
+            return False
+        for i in range(fe.stage):
+            q = fe.mem_queue_list[i]
+            n = m.base_num if i == 0 else m.advanced_num
+            if len(q["k"]) != fe.all_frame_interval or len(q["rois"]) != fe.all_frame_interval:
+                return False
+            if any(t.shape[0] != n for t in q["rois"]):
+                return False
+        return True
+
+    # ---- eager state -> state tensors
+    def enter(self, steps):
+        m, fe, S = self.m, self.fe, self.S
+        recs = list(m.records)
+        self.keys = [k for k in ("boxes", "scores", "feats", "index") if all(k in r for r in recs) and
+                     all(k in st[0] for st in steps)]
+        self.hist = {k: torch.stack([r[k] for r in recs]).contiguous() for k in self.keys}      # [25, 300, ...] oldest first
+        self.glob = torch.cat(list(fe.global_queue_list[0]["feats"]), dim=0).contiguous()
+        self.mem = [{"rois": torch.cat(list(fe.mem_queue_list[i]["rois"]), 0).contiguous(),
+                     "k": torch.cat(list(fe.mem_queue_list[i]["k"]), 0).contiguous(),
+                     "vt": torch.cat(list(fe.mem_queue_list[i]["vt"]), 1).contiguous()} for i in range(fe.stage)]
+        self.inp = {k: torch.zeros((S,) + tuple(self.hist[k].shape[1:]), dtype=self.hist[k].dtype, device=self.hist[k].device)
+                    for k in self.keys}
+        self.in_glob = torch.zeros((S, m.base_num, self.glob.shape[1]), dtype=self.glob.dtype, device=self.glob.device)
+        self.active = True
+        self.graph = None
+        self._rebind()
+
+    def _rebind(self):
+        """the model's deques / caches as views of the state tensors (the configuration the graph was captured in)"""
+        m, fe = self.m, self.fe
+        n25 = m.all_frame_interval
+        m.records = deque(({k: self.hist[k][f] for k in self.keys} for f in range(n25)), maxlen=n25)
+        gq = fe.global_queue_list[0]["feats"]
+        gq.clear()
+        bn = m.base_num
+        for j in range(fe.global_size):
+            gq.append(self.glob[j * bn:(j + 1) * bn])
+        fe.global_cache[0]["feats"] = self.glob
+        for i in range(fe.stage):
+            n = m.base_num if i == 0 else m.advanced_num
+            q = fe.mem_queue_list[i]
+            for key in ("rois", "k", "vt"):
+                q[key].clear()
+            for f in range(fe.all_frame_interval):
+                q["rois"].append(self.mem[i]["rois"][f * n:(f + 1) * n])
+                q["k"].append(self.mem[i]["k"][f * n:(f + 1) * n])
+                q["vt"].append(self.mem[i]["vt"][:, f * n:(f + 1) * n])
+            fe.mem[i] = dict(self.mem[i])
+
+    # ---- state tensors -> eager state (leaving steady state)
+    def leave(self):
+        if not self.active:
+            return
+        m, fe = self.m, self.fe
+        self._rebind()
+        m.records = deque(({k: v.clone() for k, v in r.items()} for r in m.records), maxlen=m.records.maxlen)
+        gq = fe.global_queue_list[0]["feats"]
+        gl = [g.clone() for g in gq]
+        gq.clear()
+        for g in gl:
+            gq.append(g)
+        fe.global_cache[0]["feats"] = torch.cat(gl, dim=0)
+        for i in range(fe.stage):
+            q = fe.mem_queue_list[i]
+            for key in ("rois", "k", "vt"):
+                items = [t.clone() for t in q[key]]
+                q[key].clear()
+                for t in items:
+                    q[key].append(t)
+            fe.mem[i] = {"rois": torch.cat(list(q["rois"]), 0), "k": torch.cat(list(q["k"]), 0),
+                         "vt": torch.cat(list(q["vt"]), 1)}
+        self.active = False
+        self.graph = None
+
+    def reset(self):
+        """new video: the model re-creates its deques; drop the static state without writing it back"""
+        self.active = False
+        self.graph = None
+
+    # ---- one step-batch on the static state (this body is what the graph captures)
+    def _body(self, im_size):
+        m, fe, S = self.m, self.fe, self.S
+        steps = [({k: self.inp[k][t] for k in self.keys}, [{"feats": self.in_glob[t]}]) for t in range(S)]
+        frames = m.prepare_batch(steps)
+        outs = m.step_batch(frames, im_size)
+        # the state the batch leaves behind -> the state tensors, through temporaries (sources may be views of the state)
+        groups = [([r[k].reshape(r[k].shape[0], -1) for r in m.records], 0) for k in self.keys]
+        tmp = ops.multi_cat(groups)
+        pairs = [(self.hist[k].view(tmp[j].shape), tmp[j]) for j, k in enumerate(self.keys)]
+        pairs.append((self.glob, fe.global_cache[0]["feats"]))
+        for i in range(fe.stage):
+            for key in ("rois", "k", "vt"):
+                pairs.append((self.mem[i][key], fe.mem[i][key]))
+        # (global pool / memory pools: their new contents are tapes of this batch, never views of the state tensors)
+        ops.copy_blocks(pairs)
+        # the S padded outputs as four tensors: a replay hands out 4 clones, not 4 S
+        packed = tuple(torch.stack([o[j] for o in outs]) for j in range(4))
+        return packed, frames
+
+    @staticmethod
+    def _unpack(packed, clone):
+        ob, os_, ol, oc = (t.clone() for t in packed) if clone else packed
+        return [(ob[t], os_[t], ol[t], oc[t]) for t in range(ob.shape[0])]
+
+    @torch.no_grad()
+    def step(self, steps, im_size):
+        """steps = [(new local record, [new global record])] x S -> (padded post-processing outputs of the S key frames,
+        the frames list of prepare_batch: rois_key etc. for logging)."""
+        if not self.active:
+            self.enter(steps)
+        pairs = []
+        for t, (loc, globs) in enumerate(steps):
+            for k in self.keys:
+                pairs.append((self.inp[k][t].reshape(loc[k].shape[0], -1), loc[k].reshape(loc[k].shape[0], -1)))
+            pairs.append((self.in_glob[t], globs[0]["feats"][:self.m.base_num]))
+        ops.copy_blocks(pairs)
+        if not (self.use_graph and self.glob.is_cuda) or self.graph is None:
+            # no graphs (CPU twins) / the first steady batch: eager on the static state (warms every host-side cache --
+            # index tables, zero pads, packed weights -- before the capture)
+            if self.use_graph and self.glob.is_cuda:
+                self.graph = "armed"
+            packed, frames = self._body(im_size)
+            self._rebind()
+            return self._unpack(packed, False), frames
+        if self.graph == "armed":                   # second steady batch: capture
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (see ClipEngine._frame_stage)
+                self._out = self._body(im_size)
+            self._rebind()
+            self.graph = g
+            self.captures += 1
+        self.graph.replay()
+        self.replays += 1
+        packed, frames = self._out
+        return self._unpack(packed, True), frames
 
 
 class BoxListLike(object):

@@ -199,6 +199,11 @@ class BaseStem(_Packed):
         y = ops.stem(img_nchw_f32, pk["w"], pk["s"], pk["b"], dtype, w_n160=pk["w160"])
         return ops.maxpool3x3s2(y)
 
+    def run_u8(self, frames_u8, mean, to_bgr):
+        """bf16 mode: the stem reads the uint8 frames [N,H,W,3] themselves (preprocessing on the patch load)"""
+        pk = self._packed(torch.bfloat16, frames_u8.device)
+        return ops.maxpool3x3s2(ops.stem_u8(frames_u8, pk["w160"], pk["s"], pk["b"], mean, to_bgr))
+
 
 _STAGE_BLOCKS = {"R-50-C4": (3, 4, 6), "R-101-C4": (3, 4, 23)}
 
@@ -220,9 +225,14 @@ class ResNet(nn.Module):
             self.stages.append(name)
             in_ch = out
 
-    def forward(self, x):
-        """x [N,3,H,W] f32 image batch -> [C4] (logical NCHW, channels-last memory, compute dtype)."""
-        y = self.stem.run(x.float().contiguous(), self.dtype)
+    def forward(self, x, u8_norm=None):
+        """x [N,3,H,W] f32 image batch -> [C4] (logical NCHW, channels-last memory, compute dtype).
+        u8_norm = (mean, to_bgr) with x the uint8 frames [N,H,W,3] (bf16 mode): preprocessing fused into the stem."""
+        if u8_norm is not None:
+            assert self.dtype == torch.bfloat16 and x.dtype == torch.uint8
+            y = self.stem.run_u8(x.contiguous(), u8_norm[0], u8_norm[1])
+        else:
+            y = self.stem.run(x.float().contiguous(), self.dtype)
         for name in self.stages:
             for blk in getattr(self, name):
                 y = blk.run(y)
@@ -962,6 +972,7 @@ class GeneralizedRCNNMEGA(nn.Module):
     the key frame (generalized_rcnn_mega.py:211, roi_box_feature_extractors.py:901-907).
     """
     _ref_key = "ref_l"          # images[...] key of the frame entering the local window
+    stem_reads_u8 = True        # frame_stage_a0(frames_u8, u8_norm=(mean, to_bgr)): preprocessing fused into the bf16 stem
 
     def __init__(self, cfg):
         super().__init__()
@@ -1004,7 +1015,10 @@ class GeneralizedRCNNMEGA(nn.Module):
     #   a0: backbone -> C4        a1: RPN head + proposal selection (needs C4)
     #   b1: res5 on the full maps (needs C4 only)        b2: ROIAlign + fc0 (needs a1's proposals and b1's maps)
     @torch.no_grad()
-    def frame_stage_a0(self, imgs):
+    def frame_stage_a0(self, imgs, u8_norm=None):
+        """imgs: preprocessed f32 [B,3,H,W]; or, with u8_norm = (mean, to_bgr) in bf16 mode, the uint8 frames [B,H,W,3]"""
+        if u8_norm is not None:
+            return _nhwc(self.backbone.body(imgs, u8_norm=u8_norm)[0])
         return _nhwc(self.backbone(imgs)[0])
 
     @torch.no_grad()

@@ -181,6 +181,25 @@ def stem(x_nchw, w_tap64, scale, bias, out_dtype, w_n160=None):
     return out
 
 
+def stem_u8(frames_u8, w_n160, scale, bias, mean, to_bgr=True):
+    """uint8 frames [N,H,W,3] RGB -> preprocess (BGR*255 - mean) + conv7x7 s2 + BN + ReLU -> NHWC bf16 [N,Ho,Wo,64] in ONE
+    kernel (the bf16 matrix-core stem with the preprocessing on its patch load): same bits as
+    stem(preprocess_frames(frames_u8), ...)."""
+    _gpu(frames_u8, w_n160, scale, bias)
+    lib = _lib.load()
+    N, H, W, C = frames_u8.shape
+    assert C == 3 and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+    assert w_n160.dtype == torch.bfloat16 and tuple(w_n160.shape) == (64, 176) and w_n160.is_contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, Ho, Wo, 64), dtype=torch.bfloat16, device=frames_u8.device)
+    _tok = _pb("stem", 2.0 * N * Ho * Wo * 64 * 147, frames_u8.numel() + out.numel() * 2)
+    rc = lib.mega_stem_conv_bn_relu_bf16_u8(_ptr(frames_u8), _ptr(w_n160), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
+                                            float(mean[0]), float(mean[1]), float(mean[2]), int(to_bgr), _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_stem_conv_bn_relu_bf16_u8")
+    return out
+
+
 def pack_stem_weight_bf16(w_oihw):
     """conv1.weight [64,3,7,7] -> bf16 [64,176]: column k = ((c*7+r)*8 + s for the 7 taps s of kernel row (c, r); the
     8th column of every group and columns 168..175 are zero (the kernel reads 8 consecutive patch pixels per group)."""

@@ -622,3 +622,73 @@ def test_fgfa_window_override_matches_oracle(monkeypatch):
                                            frame_loader=lambda i: frames[i][None])
         assert len(det) == wb.shape[0] and torch.equal(det.get_field("labels"), wl)
         assert (det.bbox - wb).abs().max() < 5e-3 and (det.get_field("scores") - ws).abs().max() < 1e-5
+
+
+def test_static_batch_aggregation_equals_eager(monkeypatch):
+    """engine.StaticBatchAggregation (the batched aggregation on fixed-address state -- what the hipGraph captures) on the
+    CPU twins, without a graph: same padded outputs as the eager prepare_batch + step_batch for every key frame over
+    several steady step-batches, the same model state afterwards, and a clean hand-back (leave) to the eager path."""
+    from mega.pytorch_amd import engine
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    cfg = _small_cfg()
+    cfg.merge_from_list(["MODEL.VID.MEGA.ALL_FRAME_INTERVAL", 7, "MODEL.VID.MEGA.KEY_FRAME_LOCATION", 3,
+                         "MODEL.VID.MEGA.MIN_OFFSET", -3, "MODEL.VID.MEGA.MAX_OFFSET", 3, "MODEL.VID.MEGA.GLOBAL.SIZE", 3,
+                         "MODEL.RPN.POST_NMS_TOP_N_TEST", 24, "MODEL.VID.RPN.REF_POST_NMS_TOP_N", 8,
+                         "MODEL.VID.MEGA.RATIO", 0.25])
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    g = torch.Generator().manual_seed(21)
+
+    def record(n):
+        c = torch.rand((n, 2), generator=g) * torch.tensor([100., 70.]) + 10
+        wh = torch.rand((n, 2), generator=g) * 30 + 4
+        return {"boxes": torch.cat([c - wh / 2, c + wh / 2], dim=1), "scores": torch.rand((n,), generator=g),
+                "feats": torch.randn((n, 1024), generator=g).relu()}
+    models = []
+    for _ in range(2):
+        m = modeling.build_detection_model(cfg)
+        m.load_state_dict(sd)
+        m._reset(200)
+        models.append(m)
+    a, b = models
+    kn, bn = a.key_num, a.base_num
+    recs = [record(kn) for _ in range(60)]
+    globs = [[record(bn)] for _ in range(60)]
+    for m in models:
+        for r in recs[:7]:
+            m.records.append(r)
+    pos = 7
+    S = 3
+    with torch.no_grad():
+        for _ in range(4):                    # eager on both until every pool is full (memory: 7 entries, global: 3)
+            steps = [(recs[pos + j], globs[pos + j]) for j in range(S)]
+            pos += S
+            for m in models:
+                m.step_batch(m.prepare_batch(steps), (128, 96))
+        sb = engine.StaticBatchAggregation(b, S, use_graph=False)
+        for it in range(4):
+            steps = [(recs[pos + j], globs[pos + j]) for j in range(S)]
+            pos += S
+            assert sb.ready(steps)
+            want = a.step_batch(a.prepare_batch(steps), (128, 96))
+            got, frames = sb.step(steps, (128, 96))
+            for t in range(S):
+                for j in range(4):
+                    assert torch.equal(want[t][j], got[t][j]), (it, t, j)
+            assert len(b.records) == len(a.records) == 7
+            for ra, rb in zip(a.records, b.records):
+                assert all(torch.equal(ra[k], rb[k]) for k in ("boxes", "scores", "feats"))
+            fa, fb = a.roi_heads.box.feature_extractor, b.roi_heads.box.feature_extractor
+            assert torch.equal(fa.global_cache[0]["feats"], fb.global_cache[0]["feats"])
+            for i in range(fa.stage):
+                for k in ("rois", "k", "vt"):
+                    assert torch.equal(fa.mem[i][k], fb.mem[i][k]), (it, i, k)
+        # a ragged record ends the steady state: hand back, continue eagerly, still equal
+        steps = [(record(kn - 5), globs[pos]), (recs[pos + 1], globs[pos + 1]), (recs[pos + 2], globs[pos + 2])]
+        assert not sb.ready(steps)
+        sb.leave()
+        want = a.step_batch(a.prepare_batch(steps), (128, 96))
+        got = b.step_batch(b.prepare_batch(steps), (128, 96))
+        for t in range(S):
+            for j in range(4):
+                assert torch.equal(want[t][j], got[t][j])

@@ -822,3 +822,24 @@ def test_linear_transposed_residual_and_split_v(dev):
     m1, m2 = e1.mean(dim=1).abs().mean() / scale, e2.mean(dim=1).abs().mean() / scale
     print("common-mode error of V'^T over %d keys: one pass %.2e, split %.2e (relative to mean |V|)" % (M, m1, m2))
     assert m2 < 1.5e-4 and m2 < 0.35 * m1
+
+
+@pytest.mark.parametrize("shape", [(3, 61, 77), (2, 600, 1000), (1, 7, 9)])
+@pytest.mark.parametrize("to_bgr", [True, False])
+def test_stem_u8_bit_equal_to_preprocess_plus_stem(dev, shape, to_bgr):
+    """ops.stem_u8 (the bf16 matrix-core stem reading the uint8 frames, preprocessing on its patch load) ==
+    ops.stem(ops.preprocess_frames(frames)) bit for bit: same f32 subtraction of the mean, same f32 -> bf16 conversion,
+    same MFMAs (data/transforms/transforms.py:83-129 + backbone/resnet.py:347-366)."""
+    ops = _ops()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H)
+    u8 = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8).to(dev)
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.05
+    sc = (torch.rand((64,), generator=g) + 0.5).to(dev)
+    bi = (torch.randn((64,), generator=g) * 0.1).to(dev)
+    mean = (102.9801, 115.9465, 122.7717)
+    w160 = ops.pack_stem_weight_bf16(w).to(dev)
+    wt = w.permute(1, 2, 3, 0).reshape(147, 64).contiguous().to(dev)
+    ref = ops.stem(ops.preprocess_frames(u8, mean, to_bgr), wt, sc, bi, torch.bfloat16, w_n160=w160)
+    got = ops.stem_u8(u8, w160, sc, bi, mean, to_bgr)
+    assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))

@@ -5,7 +5,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 root=$(pwd)
-args="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --min-seconds 0.01 --max-blocks 4"
+args="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --min-seconds 0.01 --max-blocks 4 ${TRACE_ARGS:-}"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $root/$out/t -o t -- python $root/bench.py $args > $root/$out/t.json 2> $root/$out/t.err)
 python - $out <<'PY'
 import sys,csv,glob,re
@@ -18,7 +18,7 @@ K=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r.get('Stream_Id',''),r['K
 with open(d+'/cli_tail.csv','w') as o:
     w=csv.writer(o)
     for r in K: w.writerow([r[0],r[1],r[2],r[3][:110]])
-pre=[i for i,r in enumerate(K) if 'preprocess' in r[3]]
+pre=[i for i,r in enumerate(K) if 'preprocess' in r[3] or 'stem_mfma' in r[3]]      # first kernel of a frame stage
 seg=K[pre[-1]:]
 t0=seg[0][0]
 def nm(n): return re.sub(r'void |\(anonymous namespace\)::|at::native::','',n)[:44]
