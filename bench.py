@@ -79,6 +79,8 @@ def parse():
                     help="cfg.HEAD_STREAM of the bf16 mode (default: the product's default, float32 = the parity-preserving head; "
                          "bfloat16 = the round-3 head with 8 bf16 hand-offs, ~2 %% faster)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-f32 parity-mode leg (config.f32_parity_mode)")
+    ap.add_argument("--no-whole-clip", action="store_true", help="skip the whole-clip (cold start + K key frames) measurement "
+                    "after the timed region (kernel traces: the tail of the stream is then a steady timed block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run frame stage and aggregation on one stream")
@@ -590,6 +592,8 @@ def main():
     # while the pools fill) plus the same K steady key frames -- on the warmed-up engine.  Reported beside `value`.
     whole_clip = None
     try:
+        if args.no_whole_clip:
+            raise RuntimeError("--no-whole-clip")
         runner.use_graphs, runner.overlap = not args.no_graphs, not args.no_overlap   # (the instrumented pass turned them off)
         runner.use_static = True
         barrier()

@@ -338,9 +338,8 @@ template <> struct Mma32<float> {
   }
 };
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-}
+// (pack_bf16x2 is common.h's: ONE v_cvt_pk_bf16_f32 per pair -- the element-wise form this file used until round 4
+//  compiled to two conversions + shift + or)
 
 struct AttnParams {
   const void* Q; int ldq;     // [Nq][ldq], head h in columns h*64 .. h*64+63  (u already folded in)
@@ -501,17 +500,26 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
     const float alpha = ex(m_run - m_new);
     float psum = 0.f;
     unsigned pk[8];              // bf16 mode: P packed for the PV MFMA (two keys per dword)
+    if (sizeof(T) == 2) {        // e^(s - m) = 2^(s log2e - m log2e): one FMA + v_exp_f32 per score (was sub, mul, exp)
+      const float kL2E = 1.44269504088896340736f, mneg = -m_new * kL2E;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = ex(s[r] - m_new);
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], kL2E, mneg));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = ex(s[r] - m_new);
+    }
     if (sizeof(T) == 2) {
       // P reaches the PV MFMA rounded to bf16; the row sum is taken over the SAME rounded values, so that
       // out = sum p'_j v_j / sum p'_j is an exact weighted mean of the v_j with slightly perturbed weights.  With the sum
       // over the unrounded p_j the rounding errors times the COMMON part of the values (bias + the mean of the post-ReLU
       // features) did not cancel: 2.6e-4 of the 6.5e-4 median logit error of the bf16 head (tools/head_precision_cpu.py).
+      typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+      const unsigned ones = 0x3f803f80u;       // (1.0, 1.0) in bf16: v_dot2c_f32_bf16 sums a rounded pair in one instruction
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
         pk[d] = pack_bf16x2(s[2 * d], s[2 * d + 1]);
-        psum += __uint_as_float(pk[d] << 16) + __uint_as_float(pk[d] & 0xffff0000u);
+        psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_v, pk[d]), __builtin_bit_cast(bf16x2_v, ones), psum,
+                                               false);
       }
     } else {
 #pragma unroll

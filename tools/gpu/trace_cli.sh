@@ -5,7 +5,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 root=$(pwd)
-args="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --min-seconds 0.01 --max-blocks 4 ${TRACE_ARGS:-}"
+args="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-whole-clip --min-seconds 0.01 --max-blocks 4 ${TRACE_ARGS:-}"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $root/$out/t -o t -- python $root/bench.py $args > $root/$out/t.json 2> $root/$out/t.err)
 python - $out <<'PY'
 import sys,csv,glob,re
@@ -26,7 +26,10 @@ out=open(d+'/cli_summary.txt','w')
 def P(*a):
     s=' '.join(str(x) for x in a); print(s); out.write(s+'\n')
 roi=[i for i,r in enumerate(seg) if 'roi_align' in r[3]][-1]
-fend=seg[roi+1][1]
+fe=roi+1
+if fe+1<len(seg) and 'splitk_finalize' in seg[fe+1][3]: fe+=1
+fend=seg[fe][1]
+roi=fe-1
 P("last block: %d kernels, span %.2f ms; frame stage (preprocess -> first FC) span %.2f ms"%(len(seg),(max(r[1] for r in seg)-t0)/1e6,(fend-t0)/1e6))
 busy=sum(r[1]-r[0] for r in seg[:roi+2])
 P("frame stage busy %.2f ms"%(busy/1e6))

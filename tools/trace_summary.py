@@ -16,11 +16,14 @@ def name(n):
 
 def main(path):
     rows = [(int(a), int(b), n) for a, b, q, s, n in csv.reader(open(path))]
-    pre = [i for i, r in enumerate(rows) if 'preprocess' in r[2]]
+    pre = [i for i, r in enumerate(rows) if 'preprocess' in r[2] or 'stem_mfma' in r[2]]    # first kernel of a frame stage
     seg = rows[pre[-1]:]
     roi = [i for i, r in enumerate(seg) if 'roi_align' in r[2]][-1]
-    # the frame stage ends with the first FC (one igemm launch after ROIAlign)
-    f, b = seg[:roi + 2], seg[roi + 2:]
+    # the frame stage ends with the first FC (one igemm launch after ROIAlign, + its split-K finalize)
+    end = roi + 2
+    if end < len(seg) and 'splitk_finalize' in seg[end][2]:
+        end += 1
+    f, b = seg[:end], seg[end:]
     for title, part, div in (("frame stage of one step-batch", f, 1), ("aggregation, per step-batch (two batches traced, halved)", b, 2)):
         agg = defaultdict(lambda: [0, 0])
         for r in part:
