@@ -243,6 +243,16 @@ int mega_copy_segments(const void* segs, int n, void* stream);
  * (roi_box_feature_extractors.py:584-597 run in one dtype; this is the mixed-precision seam of the bf16 mode). */
 int mega_cast_f32_to_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
 
+/* The identity bottleneck of the backbone's full-resolution stage -- layer1 blocks 1, 2 of ResNet-50/101-C4
+ * (backbone/resnet.py:324-344: 256 -> 64 (1x1) -> 64 (3x3, pad 1) -> 256 (1x1) channels, stride 1, FrozenBN as f32
+ * scale / bias vectors (layers/batch_norm.py:19-31), residual = the block's input) -- in ONE persistent kernel:
+ *   out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + x),   x, out: NHWC bf16 [N][H][W][256],
+ * w1 [64][256], w2 [64][3][3][64], w3 [256][64] bf16 (OHWI).  The 64-channel intermediates never leave the CU.  Same MFMA,
+ * K order, roundings and epilogue arithmetic as the three mega_conv2d_nhwc launches it replaces: bit-identical. */
+int mega_bottleneck64_fwd(const void* x, const void* w1, const float* s1, const float* b1, const void* w2, const float* s2,
+                          const float* b2, const void* w3, const float* s3, const float* b3, void* out, int N, int H, int W,
+                          void* stream);
+
 /* dst [rows][3K] bf16 = [hi | lo | hi] of src [rows][K] f32 (hi = bf16(v), lo = bf16(v - hi); K % 8 == 0): the A operand
  * of a split-precision GEMM on the bf16 matrix cores against weight rows [Wh | Wh | Wl] -- v.W to ~2^-16.  Used for the
  * stage FCs of the aggregation head (roi_box_feature_extractors.py:826-827) when the activation stream is f32. */

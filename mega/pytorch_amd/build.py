@@ -25,6 +25,7 @@ SOURCES = {
     "fgfa.hip": [],
     "assemble.hip": [],
     "conv64.hip": [],
+    "bneck64.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

@@ -149,6 +149,31 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
     return out
 
 
+def bottleneck64(x, w1, s1, b1, w2, s2, b2, w3, s3, b3):
+    """The fused identity bottleneck 256 -> 64 -> 64 (3x3) -> 256 (layer1 blocks 1, 2): x NHWC bf16 [N,H,W,256] ->
+    relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + x) in one persistent kernel; same bits as the three conv2d_nhwc
+    launches.  w1 [64,1,1,256], w2 [64,3,3,64], w3 [256,1,1,64] (OHWI bf16), s / b f32 FrozenBN scale / bias."""
+    _gpu(x, w1, s1, b1, w2, s2, b2, w3, s3, b3)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    assert C == 256 and x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert tuple(w1.shape) == (64, 1, 1, 256) and tuple(w2.shape) == (64, 3, 3, 64) and tuple(w3.shape) == (256, 1, 1, 64)
+    for t in (w1, w2, w3):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    for v, n in ((s1, 64), (b1, 64), (s2, 64), (b2, 64), (s3, 256), (b3, 256)):
+        assert v.dtype == torch.float32 and v.numel() == n and v.is_contiguous()
+    if x.numel() * 2 >= 0x7FF00000:
+        raise ValueError("bottleneck64: operand of %.2f GiB; 32-bit buffer offsets (< 2 GiB)" % (x.numel() * 2 / 2.0 ** 30))
+    out = torch.empty_like(x)
+    px = float(N * H * W)
+    _tok = _pb("bneck64_fused", 2.0 * px * (256 * 64 + 576 * 64 + 64 * 256), px * 1024.0)
+    rc = lib.mega_bottleneck64_fwd(_ptr(x), _ptr(w1), _ptr(s1), _ptr(b1), _ptr(w2), _ptr(s2), _ptr(b2), _ptr(w3), _ptr(s3),
+                                   _ptr(b3), _ptr(out), N, H, W, _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_bottleneck64_fwd")
+    return out
+
+
 def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None):
     """x [M,K], w [Nout,K] (nn.Linear layout) -> [M,Nout]."""
     M, K = x.shape

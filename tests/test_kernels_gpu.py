@@ -843,3 +843,35 @@ def test_stem_u8_bit_equal_to_preprocess_plus_stem(dev, shape, to_bgr):
     ref = ops.stem(ops.preprocess_frames(u8, mean, to_bgr), wt, sc, bi, torch.bfloat16, w_n160=w160)
     got = ops.stem_u8(u8, w160, sc, bi, mean, to_bgr)
     assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("shape", [(2, 150, 250), (3, 37, 53), (1, 8, 16), (5, 64, 48), (40, 9, 17)])
+def test_fused_bottleneck64_bit_equal_to_unfused(dev, shape):
+    """ops.bottleneck64 (bneck64.hip: layer1's identity bottleneck 256 -> 64 -> 64 (3x3) -> 256 + residual in one persistent
+    kernel, the 64-channel intermediates in LDS) against the three conv2d_nhwc launches it replaces (backbone/resnet.py:
+    324-344): same MFMA, same ascending K order, same bf16 roundings of the intermediates, same epilogue arithmetic ->
+    the same BITS, including partial edge tiles, single-tile images and the zero padding of the 3x3 conv at the border
+    (t1 = 0 outside the image, not relu(bias)); and close to F.conv2d in f32."""
+    ops = _ops()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn((N, H, W, 256), generator=g).relu().to(torch.bfloat16).to(dev)
+    w1 = (torch.randn((64, 1, 1, 256), generator=g) * 0.06).to(torch.bfloat16).to(dev)
+    w2 = (torch.randn((64, 3, 3, 64), generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    w3 = (torch.randn((256, 1, 1, 64), generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    sb = [((torch.rand((n,), generator=g) + 0.5).to(dev), (torch.randn((n,), generator=g) * 0.2).to(dev)) for n in (64, 64, 256)]
+    t1 = ops.conv2d_nhwc(x, w1, sb[0][0], sb[0][1], relu=True)
+    t2 = ops.conv2d_nhwc(t1, w2, sb[1][0], sb[1][1], pad=1, relu=True)
+    ref = ops.conv2d_nhwc(t2, w3, sb[2][0], sb[2][1], residual=x, relu=True)
+    got = ops.bottleneck64(x, w1, sb[0][0], sb[0][1], w2, sb[1][0], sb[1][1], w3, sb[2][0], sb[2][1])
+    torch.cuda.synchronize()
+    nd = (got.view(torch.int16) != ref.view(torch.int16)).sum().item()
+    assert nd == 0, "%d of %d elements differ (max |d| %.3g)" % (nd, got.numel(), (got.float() - ref.float()).abs().max().item())
+    # f32 reference of the whole block
+    xf = x.float().cpu().permute(0, 3, 1, 2)
+    def bn(y, i):
+        return y * sb[i][0].cpu().view(1, -1, 1, 1) + sb[i][1].cpu().view(1, -1, 1, 1)
+    y = F.relu(bn(F.conv2d(xf, w1.float().cpu().permute(0, 3, 1, 2)), 0))
+    y = F.relu(bn(F.conv2d(y, w2.float().cpu().permute(0, 3, 1, 2), padding=1), 1))
+    y = F.relu(bn(F.conv2d(y, w3.float().cpu().permute(0, 3, 1, 2)), 2) + xf).permute(0, 2, 3, 1)
+    assert _relerr(got.float().cpu(), y) < 2e-2
