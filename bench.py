@@ -169,6 +169,7 @@ def dry_run(args, world, rank, local_rank, json_fd):
         cfg = type("C", (), {"INPUT": type("I", (), {"PIXEL_MEAN": (0, 0, 0), "TO_BGR255": True})})
     e = eng.ClipEngine(_M())
     e.rank, e.world = rank, live
+    e.owner_aligned = True        # (the product's dealing with the batched aggregation: frame f -> rank f mod world)
     T = 64 + 2 * KF
     gfor = eng.global_schedule(T, 10, seed=0)
     jobs = [j for i in range(40, 40 + spb) for j in e.jobs_for_step(i, T, gfor)]

@@ -258,6 +258,11 @@ int mega_bottleneck64_fwd(const void* x, const void* w1, const float* s1, const 
  * stage FCs of the aggregation head (roi_box_feature_extractors.py:826-827) when the activation stream is f32. */
 int mega_split_f32_to_bf16x3(const float* src, void* dst_bf16, int rows, int K, void* stream);
 
+/* mega_copy_segments with an f32 -> bf16 conversion on the way (source blocks f32, destination blocks bf16; row_bytes =
+ * SOURCE bytes per row, a multiple of 32; 16-byte aligned on both sides): a concatenation of f32 row blocks delivered as the
+ * rounded copy the bf16 projections read (roi_box_feature_extractors.py:812-814 pools with an f32 activation stream). */
+int mega_copy_cast_segments(const void* segs, int n, void* stream);
+
 /* hipGetErrorString of the last launch failure any entry point of this library reported (MEGA_ERR_LAUNCH). */
 const char* mega_last_error_string(void);
 

@@ -59,6 +59,28 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     for (size_t i = n8 * 8 + threadIdx.x; i < n; i += 256) dst[i] = f32_to_bf16(src[i]);
 }
 
+// copy_segments with an f32 -> bf16 conversion on the way: a concatenation of f32 row blocks delivered as bf16 (the key / value
+// sources of the relation modules when the head's activation stream is f32: only their rounded copy is ever read).  A segment
+// is [rows][8 * units_per_row] f32 elements; each thread converts 8 elements (32 B in, 16 B out).
+__global__ __launch_bounds__(256) void copy_cast_segments_kernel(CopyBatch b) {
+  const unsigned total = b.ubase[b.n];
+  for (unsigned unit = blockIdx.x * 256u + threadIdx.x; unit < total; unit += gridDim.x * 256u) {
+    int lo = 0, hi = b.n;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (b.ubase[mid] <= unit) lo = mid; else hi = mid;
+    }
+    const CopySeg& s = b.s[lo];
+    const unsigned u = unit - b.ubase[lo];
+    const unsigned r = u / (unsigned)s.units_per_row, c = u - r * (unsigned)s.units_per_row;
+    const float4* src = reinterpret_cast<const float4*>(s.src + (long long)r * s.src_stride + (size_t)c * 32);
+    const float4 a = src[0], q = src[1];
+    u32x4_t o;
+    o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w); o[2] = pack_bf16x2(q.x, q.y); o[3] = pack_bf16x2(q.z, q.w);
+    *reinterpret_cast<u32x4_t*>(s.dst + (long long)r * s.dst_stride + (size_t)c * 16) = o;
+  }
+}
+
 // f32 row [K] -> bf16 row [3K] = [hi | lo | hi], hi = bf16(v), lo = bf16(v - hi): with the weight rows laid out
 // [Wh | Wh | Wl] a plain bf16 GEMM over 3K computes hi.Wh + lo.Wh + hi.Wl = v.W to ~2^-16 (f32 accumulation of exact
 // bf16 products; only the lo.Wl term, 2^-18, is dropped) at the bf16 MFMA rate.  8 elements per thread.
@@ -119,6 +141,53 @@ extern "C" int mega_cast_f32_to_bf16(const float* src, void* dst, size_t n, void
 struct MegaCopySegC {
   const void* src; void* dst; long long src_stride, dst_stride; int rows, row_bytes;
 };
+
+// segs[n] as for mega_copy_segments, but the source blocks are f32 and the destination blocks bf16: row_bytes counts the
+// SOURCE bytes of a row (a multiple of 32: 8 elements per thread), strides are bytes of the respective tensor, both sides
+// 16-byte aligned.  dst = bf16(src), round to nearest even.
+extern "C" int mega_copy_cast_segments(const void* segs, int n, void* stream) {
+  mega_clear_error();
+  if (n == 0) return MEGA_OK;
+  if (!segs || n < 0) return MEGA_ERR_ARG;
+  const MegaCopySegC* d = (const MegaCopySegC*)segs;
+  for (int i = 0; i < n; ++i) {
+    const MegaCopySegC& g = d[i];
+    if (g.rows < 0 || g.row_bytes < 0 || (g.row_bytes & 31)) return MEGA_ERR_ARG;
+    if (g.rows > 0 && g.row_bytes > 0) {
+      if (!g.src || !g.dst || ((size_t)g.src & 15) || ((size_t)g.dst & 15)) return MEGA_ERR_ARG;
+      if (g.rows > 1 && ((g.src_stride & 15) || (g.dst_stride & 15))) return MEGA_ERR_ARG;
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  CopyBatch b;
+  b.n = 0;
+  unsigned long long units = 0;
+  auto flush = [&]() {
+    if (b.n == 0) return;
+    b.ubase[b.n] = (unsigned)units;
+    unsigned long long nb = (units + 1023) / 1024;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(copy_cast_segments_kernel, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, st, b);
+    b.n = 0;
+    units = 0;
+  };
+  for (int i = 0; i < n; ++i) {
+    const MegaCopySegC& g = d[i];
+    if (g.rows == 0 || g.row_bytes == 0) continue;
+    const unsigned long long u = (unsigned long long)g.rows * (unsigned long long)(g.row_bytes / 32);
+    if (u >= 0xFFFFFFFFull) return MEGA_ERR_ARG;
+    if (b.n == COPY_MAXSEG || units + u >= 0xFFFFFFFFull) flush();
+    CopySeg& sg = b.s[b.n];
+    sg.src = (const unsigned char*)g.src; sg.dst = (unsigned char*)g.dst;
+    sg.src_stride = g.src_stride; sg.dst_stride = g.dst_stride;
+    sg.rows = g.rows; sg.units_per_row = (int)(g.row_bytes / 32);
+    b.ubase[b.n] = (unsigned)units;
+    units += u;
+    ++b.n;
+  }
+  flush();
+  return mega_check_launch();
+}
 
 // segs[n]: copy rows x row_bytes bytes from src (+ r * src_stride) to dst (+ r * dst_stride).  Segments must not
 // overlap each other's destinations.  Any n (launched in groups of 56 segments).

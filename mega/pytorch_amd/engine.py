@@ -57,16 +57,23 @@ class _On(object):
 
 
 class KeyFrameShard(object):
-    """Multi-GPU form of the batched aggregation (MEGAFeatureExtractor.aggregate_batch): the key frames of a
-    step-batch are dealt round-robin to the ranks (owner(t) = t mod world).  What crosses ranks: per stage, the memory
-    entries (75 / 15 / 15 feature rows) of every key frame of the batch -- one all-gather each -- and at the end the
-    padded detections.  Nothing of the per-key-frame step is replicated any more."""
+    """Multi-GPU form of the batched aggregation (MEGAFeatureExtractor.aggregate_batch): key frame i of the video belongs
+    to rank i mod world -- the rank that also ran the frame stage of FRAME i (ClipEngine.shard_plan), so the 225 proposal
+    rows only the key frame's own aggregation reads (rows 75-299 of its record, generalized_rcnn_mega.py:154-158,:213-216)
+    never leave the GPU that produced them.  `base` = the video index of the batch's first key frame: position t of the
+    batch is key frame base + t.  What crosses ranks: per stage, the memory entries (75 / 15 / 15 feature rows) of every key
+    frame of the batch -- one all-gather each -- and at the end the padded detections.  Nothing of the per-key-frame step is
+    replicated.  `wire` (optional dict) accumulates the bytes this rank contributes to each collective."""
 
-    def __init__(self, dist, group, rank, world):
-        self.dist, self.group, self.rank, self.world = dist, group, rank, world
+    def __init__(self, dist, group, rank, world, base=0, wire=None):
+        self.dist, self.group, self.rank, self.world, self.base, self.wire = dist, group, rank, world, base, wire
 
     def owner(self, t):
-        return t % self.world
+        return (self.base + t) % self.world
+
+    def _count(self, key, t):
+        if self.wire is not None:
+            self.wire[key] = self.wire.get(key, 0) + t.numel() * t.element_size()
 
     def gather_rows(self, own, nrows, like):
         """own {t: [n_t, D] rows of my key frames}, nrows[t] for ALL key frames -> list of [n_t, D] for all of them."""
@@ -76,8 +83,9 @@ class KeyFrameShard(object):
         for t, x in own.items():
             buf[t // W, :x.shape[0]] = x
         out = like.new_empty((W * per, R, D))
+        self._count("memory_rows", buf)
         self.dist.all_gather_into_tensor(out, buf, group=self.group)
-        return [out[(t % W) * per + t // W, :nrows[t]] for t in range(S)]
+        return [out[self.owner(t) * per + t // W, :nrows[t]] for t in range(S)]
 
     def gather_detections(self, outs, S, max_det, device):
         """outs[t] = PostProcessor.run output of my key frames (None elsewhere) -> the same for all S key frames.
@@ -99,10 +107,11 @@ class KeyFrameShard(object):
             buf[t // W, :n, 5] = ol[:n].float()
             buf[t // W, cap2, 0] = oc.float()[0]      # the TRUE count: finish() raises if it exceeds the rows sent
         out = torch.empty((W * per, cap2 + 1, 6), dtype=torch.float32, device=device)
+        self._count("detections", buf)
         self.dist.all_gather_into_tensor(out, buf, group=self.group)
         res = []
         for t in range(S):
-            r = out[(t % W) * per + t // W]
+            r = out[self.owner(t) * per + t // W]
             res.append((r[:cap2, :4], r[:cap2, 4], r[:cap2, 5].long(), r[cap2, 0:1].int()))
         return res
 
@@ -157,6 +166,14 @@ class ClipEngine(object):
         # (model.step_batch: projections / stage FCs as one GEMM each); off = one model.step() per key frame
         fe = getattr(getattr(getattr(model, "roi_heads", None), "box", None), "feature_extractor", None)
         self.batch_aggregation = batch_aggregation and hasattr(fe, "aggregate_batch")      # (RDN: per-frame steps)
+        # multi-GPU wire format: with the batched aggregation a key frame is aggregated by ONE rank, the one
+        # that ran its frame stage, and only the base_num rows every window reads travel (shard_plan / records_async)
+        self.owner_aligned = bool(self.batch_aggregation and static_aggregation is False and hasattr(model, "base_num")
+                                  and getattr(fe, "cache_memory_kv", False))
+        self.wire = {}                    # bytes this rank contributed to each kind of collective (tests, diagnostics)
+        self.group_agg = dist_group       # the aggregation's collectives run on another stream than the frame stage's:
+        if dist_group is not None and self.world > 1:      # their own communicator
+            self.group_agg = self.dist.new_group(list(range(self.world)))
         # ramp: every run() call is its own pipeline fill / drain (the first batch's frame stage and the last batch's
         # aggregation have nothing to overlap with).  With ramp=True a call's key frames are split into a SHORT first
         # and last batch (steps_per_batch // 4) around equal middle batches, so the un-overlapped head and tail shrink
@@ -355,33 +372,71 @@ class ClipEngine(object):
         return out
 
     def shard_plan(self, jobs, rank=None, world=None):
-        """How a frame-stage batch is dealt to the ranks.  Jobs are grouped by their row count (local-window frames:
-        key_num rows, global-pool frames: base_num rows); each group, largest rows first, is cut into `world` contiguous
-        slices (padded by repeating its last job).  -> (plan, mine): plan = [(want, positions of the group's jobs, slice
-        length, offset of this rank's slice in its launch)], mine = positions (into jobs) this rank computes, in launch
-        order.  The ONE definition of the slicing: records_async and the host-side prefetch both use it."""
+        """How a frame-stage batch is dealt to the ranks.  -> (plan, mine).
+
+        Owner-aligned form (the batched aggregation): local-window frame f goes to rank f mod world -- the
+        rank that aggregates KEY FRAME f twelve steps later (KeyFrameShard.owner), so only the 75 rows every rank's window
+        needs travel and rows 75-299 stay where they were computed; global-pool frames (75 rows) are dealt round-robin.
+        Every rank runs ONE launch of nl local + ng global frames (short lists padded by repeating a job of that kind; a
+        padded slot's record is never consumed).  plan = {"place": [(rank, slot in that rank's launch)] per job, "nl", "ng"},
+        mine = positions (into jobs) this rank computes, in launch order (locals, then globals).
+        Legacy form (per-frame aggregation: every rank steps every key frame and needs whole records): jobs grouped by row
+        count, each group cut into contiguous slices; plan = [(want, positions, slice length, first slot)].
+        The ONE definition of the dealing: records_async and the host-side prefetch both use it."""
         rank = self.rank if rank is None else rank
         world = self.world if world is None else world
-        groups = {}
+        if not self.owner_aligned:
+            groups = {}
+            for pos, j in enumerate(jobs):
+                groups.setdefault(int(j[1]), []).append(pos)
+            plan, mine = [], []
+            for want, poss in sorted(groups.items(), reverse=True):
+                per = (len(poss) + world - 1) // world
+                padded = poss + [poss[-1]] * (per * world - len(poss))
+                plan.append((want, poss, per, len(mine)))
+                mine += padded[rank * per:(rank + 1) * per]
+            return plan, mine
+        loc = [[] for _ in range(world)]
+        glo = [[] for _ in range(world)]
+        ng_seen = 0
         for pos, j in enumerate(jobs):
-            groups.setdefault(int(j[1]), []).append(pos)
-        plan, mine = [], []
-        for want, poss in sorted(groups.items(), reverse=True):
-            per = (len(poss) + world - 1) // world
-            padded = poss + [poss[-1]] * (per * world - len(poss))
-            plan.append((want, poss, per, len(mine)))
-            mine += padded[rank * per:(rank + 1) * per]
-        return plan, mine
+            if j[2] == "g":
+                glo[ng_seen % world].append(pos)
+                ng_seen += 1
+            else:
+                loc[int(j[0]) % world].append(pos)
+        nl, ng = max(len(x) for x in loc), max(len(x) for x in glo)
+        place = [None] * len(jobs)
+        launches = []
+        for r in range(world):
+            for lst, n in ((loc[r], nl), (glo[r], ng)):
+                if len(lst) < n:      # pad: a job of the same kind (its record lands in a slot nobody reads)
+                    same = lst or next(x for x in (loc if lst is loc[r] else glo) if x)
+                    lst = lst + [same[-1]] * (n - len(lst))
+                launches.append(lst)
+        for r in range(world):
+            l, g = launches[2 * r], launches[2 * r + 1]
+            for slot, pos in enumerate(loc[r]):
+                place[pos] = (r, slot)
+            for slot, pos in enumerate(glo[r]):
+                place[pos] = (r, nl + slot)
+        mine = launches[2 * rank] + launches[2 * rank + 1]
+        return {"place": place, "nl": nl, "ng": ng}, mine
 
     @staticmethod
     def count_index(plan, njobs, nm):
         """Where job p's proposal count sits in the all-gathered count vector [world x nm] (nm = frames per rank and
-        launch): the job in slot s of its group was computed by rank s // per as frame first + s % per of that rank's launch."""
+        launch)."""
+        if isinstance(plan, dict):
+            return [r * nm + slot for r, slot in plan["place"]]
         idx = [0] * njobs
         for _, poss, per, first in plan:
             for slot, pos in enumerate(poss):
                 idx[pos] = (slot // per) * nm + first + slot % per
         return idx
+
+    def _count_wire(self, key, t):
+        self.wire[key] = self.wire.get(key, 0) + t.numel() * t.element_size()
 
     def records_async(self, clip, jobs, on_counts=None):
         """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
@@ -389,11 +444,6 @@ class ClipEngine(object):
         two halves of the frame stage (one tiny collective) and handed to on_counts in job order."""
         if self.world == 1 and not self.force_sharded:
             return {"st": self._frame_stage(self._frames(clip, [j[0] for j in jobs]), [j[1] for j in jobs], on_counts)}
-        # ---- sharded.  Jobs are grouped by their row count (local-window frames: key_num rows, global-pool frames:
-        # base_num rows -- a global frame's record is 4x smaller on the wire); each group is dealt to the ranks in
-        # contiguous slices (padded by repeating its last job); a rank runs ONE frame-stage launch over its slices of
-        # all groups and the records of a group travel in ONE all-gather of a packed byte buffer
-        # [boxes+score f32 | feats | count], fixed size per frame.
         plan, mine = self.shard_plan(jobs)
         mine_ids = [jobs[p][0] for p in mine]
         mine_want = [int(jobs[p][1]) for p in mine]
@@ -401,17 +451,63 @@ class ClipEngine(object):
         if on_counts is not None:
             def early(c):      # this rank's counts -> every rank, re-ordered to job order (index table cached per plan)
                 nm = c.shape[0]
-                sig = (tuple(int(j[1]) for j in jobs), self.world, str(c.device))
+                sig = (tuple((int(j[0]) % self.world, int(j[1]), j[2]) for j in jobs), self.world, str(c.device))
                 tab = getattr(self, "_cnt_index", None)
                 if tab is None or tab[0] != sig:
                     tab = self._cnt_index = (sig, torch.tensor(self.count_index(plan, len(jobs), nm), dtype=torch.int64,
                                                                device=c.device))
                 allc = torch.empty((self.world * nm,), dtype=c.dtype, device=c.device)
+                self._count_wire("counts", c)
                 self.dist.all_gather_into_tensor(allc, c.contiguous(), group=self.group)
                 on_counts(allc.index_select(0, tab[1]))
         st = self._frame_stage(self._frames(clip, mine_ids), mine_want, early)
         dev, D, fdt = st["props"].device, st["feats"].shape[1], st["feats"].dtype
         esz = st["feats"].element_size()
+        if isinstance(plan, dict):
+            # ---- owner-aligned: every frame contributes ONE record of the rows every rank's window reads -- base_num (75)
+            # boxes, scores and feature rows + its count -- whatever its role; the whole batch travels in ONE all-gather of
+            # a packed byte buffer.  Packed by one block-copy launch (mega_copy_segments); the receivers' records are VIEWS
+            # of the gathered buffer.  Rows base_num .. key_num - 1 of a local frame stay on this rank: only key frame f's
+            # aggregation reads them, and this rank owns it.
+            bn = self.model.base_num
+            nb_box, nb_sc, nb_feat = bn * 16, (bn * 4 + 15) // 16 * 16, bn * D * esz
+            rec_bytes = nb_box + nb_sc + nb_feat + 16
+            nrec = plan["nl"] + plan["ng"]
+            buf = torch.zeros((nrec, rec_bytes), dtype=torch.uint8, device=dev)
+            pairs, row = [], 0
+            for slot, w in enumerate(mine_want):
+                pairs.append((buf[slot:slot + 1, :nb_box], st["props"][slot, :bn].reshape(1, -1).view(torch.uint8)))
+                pairs.append((buf[slot:slot + 1, nb_box:nb_box + bn * 4], st["scores"][slot, :bn].reshape(1, -1).view(torch.uint8)))
+                pairs.append((buf[slot:slot + 1, nb_box + nb_sc:nb_box + nb_sc + nb_feat],
+                              st["feats"][row:row + bn].reshape(1, -1).view(torch.uint8)))
+                row += w
+            cnt_bytes = st["cnt"].contiguous().view(torch.uint8).view(nrec, 4)
+            pairs.append((buf[:, nb_box + nb_sc + nb_feat:nb_box + nb_sc + nb_feat + 4], cnt_bytes))
+            ops.copy_blocks(pairs)
+            out = torch.empty((self.world * nrec, rec_bytes), dtype=torch.uint8, device=dev)
+            self._count_wire("frame_records", buf)
+            self.dist.all_gather_into_tensor(out, buf, group=self.group)
+            c_all = out[:, nb_box + nb_sc + nb_feat:nb_box + nb_sc + nb_feat + 4].contiguous().view(torch.int32).view(-1)
+            # my own frames keep their full records (views of this rank's frame-stage output)
+            own_rows, row = {}, 0
+            for slot, w in enumerate(mine_want):
+                own_rows[slot] = (row, w)
+                row += w
+            order = []
+            for pos, (r, slot) in enumerate(plan["place"]):
+                g = r * nrec + slot
+                if r == self.rank:
+                    ro, w = own_rows[slot]
+                    order.append((st["props"][slot, :w], st["scores"][slot, :w], st["feats"][ro:ro + w], c_all[g:g + 1], w))
+                else:
+                    rec = out[g]
+                    order.append((rec[:nb_box].view(torch.float32).view(bn, 4), rec[nb_box:nb_box + bn * 4].view(torch.float32),
+                                  rec[nb_box + nb_sc:nb_box + nb_sc + nb_feat].view(fdt).view(bn, D), c_all[g:g + 1], bn))
+            g = {"recs": [o[:4] for o in order], "cnt": torch.cat([o[3] for o in order]), "want": [o[4] for o in order]}
+            if "index" in st:
+                g["index"] = {pos: st["index"][slot] for pos, (r, slot) in enumerate(plan["place"]) if r == self.rank}
+            return {"gathered": g}
+        # ---- legacy: whole records, one all-gather per row-count group
         got = {}
         row_off = 0
         for want, poss, per, first in plan:
@@ -425,6 +521,7 @@ class ClipEngine(object):
             buf[:, nb_box + nb_feat:nb_box + nb_feat + 4] = st["cnt"][first:first + per].contiguous().view(per, 1).view(torch.uint8)
             row_off += per * want
             out = torch.empty((self.world * per, rec_bytes), dtype=torch.uint8, device=dev)
+            self._count_wire("frame_records", buf)
             self.dist.all_gather_into_tensor(out, buf, group=self.group)
             bs_all = out[:, :nb_box].contiguous().view(torch.float32).view(-1, want, 5)
             f_all = out[:, nb_box:nb_box + nb_feat].contiguous().view(fdt).view(-1, want, D)
@@ -610,7 +707,9 @@ class ClipEngine(object):
                         return
                     shard = None
                     if self.world > 1 or self.force_sharded:
-                        shard = KeyFrameShard(self.dist, self.group, self.rank, self.world)
+                        # (legacy dealing: batch position t -> rank t mod world, whole records are everywhere)
+                        shard = KeyFrameShard(self.dist, self.group_agg, self.rank, self.world,
+                                              base=prepared[0][0] if self.owner_aligned else 0, wire=self.wire)
                     steps = [st for _, st in prepared]
                     sb = self._sbatch
                     if (self.graph_aggregation and self.use_static and shard is None and clip.is_cuda and prepared[0][0] > 0

@@ -612,6 +612,31 @@ def multi_cat(groups):
     return outs
 
 
+def cat_rows_cast_bf16(pieces):
+    """torch.cat(pieces, 0).to(bfloat16) for f32 row blocks [n_i, K] (K % 8 == 0, unit column stride) in ONE launch that
+    never writes the f32 concatenation: the K / V sources of the relation modules under an f32 activation stream."""
+    pieces = [p for p in pieces if p.shape[0] > 0]
+    lib = _lib.load()
+    K = pieces[0].shape[1]
+    out = torch.empty((sum(p.shape[0] for p in pieces), K), dtype=torch.bfloat16, device=pieces[0].device)
+    arr = (_CopySeg * len(pieces))()
+    o, nbytes = 0, 0
+    for i, p in enumerate(pieces):
+        _gpu(p)
+        assert p.dtype == torch.float32 and p.dim() == 2 and p.shape[1] == K and K % 8 == 0 and p.stride(1) == 1
+        d = out[o:o + p.shape[0]]
+        arr[i].src, arr[i].dst = p.data_ptr(), d.data_ptr()
+        arr[i].src_stride, arr[i].dst_stride = p.stride(0) * 4, K * 2
+        arr[i].rows, arr[i].row_bytes = p.shape[0], K * 4
+        o += p.shape[0]
+        nbytes += p.numel() * 6
+    _tok = _pb("assemble", 0.0, nbytes)
+    rc = lib.mega_copy_cast_segments(ctypes.addressof(arr), len(pieces), _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_copy_cast_segments")
+    return out
+
+
 def resize_bilinear_u8(frames_u8, out_hw, tables):
     """uint8 [N,Hi,Wi,3] -> [N,Ho,Wo,3], Pillow-exact BILINEAR.  tables = feed.ResizeTables (device coefficient tables)."""
     _gpu(frames_u8)

@@ -186,11 +186,18 @@ def relation_project_batched(w, xs, refs, want_x=False, also_cat=(), pad_refs=Fa
     else:
         rf, nr = _flat(refs)
         npad = nr
-    cats = cat_rows_many([rf, xf] + [list(c) for c in also_cat])
-    r_all, x_all = cats[0], cats[1]
-    r_op = op_dtype(w, r_all)             # (f32 activation stream: one rounded copy per concatenation, not per problem)
+    if rf[0].dtype != w.wq.dtype and _rows_view(rf) is None:
+        # f32 activation stream: the key / value sources are only ever read as their bf16 copy -- concatenate AND round in one
+        # launch, the f32 concatenation is never written (ops.cat_rows_cast_bf16)
+        cats = cat_rows_many([xf] + [list(c) for c in also_cat])
+        x_all, cats = cats[0], [None] + cats
+        r_op = ops.cat_rows_cast_bf16(rf)
+    else:
+        cats = cat_rows_many([rf, xf] + [list(c) for c in also_cat])
+        x_all = cats[1]
+        r_op = op_dtype(w, cats[0])       # (f32 activation stream: one rounded copy per concatenation, not per problem)
     k_all = ops.linear(r_op, w.wk, w.bk)
-    vt_all = project_v(w, r_op, (r_all.shape[0] + 31) // 32 * 32)
+    vt_all = project_v(w, r_op, (r_op.shape[0] + 31) // 32 * 32)
     q_all = ops.linear(op_dtype(w, x_all), w.wq, w.bq)
     qs, ks, vts, xc = [], [], [], []
     oq = orr = 0

@@ -145,6 +145,10 @@ def cast_bf16(x):
     return x.to(torch.bfloat16)
 
 
+def cat_rows_cast_bf16(pieces):
+    return torch.cat([p for p in pieces if p.shape[0] > 0], dim=0).to(torch.bfloat16)
+
+
 def split_bf16x3(x):
     hi = x.to(torch.bfloat16)
     lo = (x - hi.float()).to(torch.bfloat16)
@@ -200,7 +204,7 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
     return (out, w[:, 0]) if want_weights else out
 
 
-ALL = ["cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+ALL = ["cast_bf16", "cat_rows_cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames", "position_logits_batched",
        "relation_attention_batched", "postprocess_batched"]
 

@@ -65,7 +65,10 @@ def test_more_gpus_than_devices_is_refused():
 
 
 def test_prefetch_slice_is_the_frame_stage_slice():
-    """ClipEngine.run's prefetch and records_async use ONE slicing (shard_plan): per row-count group, contiguous slices."""
+    """ClipEngine.run's prefetch and records_async use ONE dealing (shard_plan).  Owner-aligned form: local
+    frame f is computed by rank f mod world -- the owner of KEY FRAME f (KeyFrameShard.owner) -- global frames round-robin;
+    every rank's launch is nl locals then ng globals; every job has exactly one (rank, slot).  The legacy form (per-frame
+    aggregation) keeps contiguous slices per row-count group."""
     sys.path.insert(0, ROOT)
     from mega.pytorch_amd import engine
 
@@ -76,34 +79,56 @@ def test_prefetch_slice_is_the_frame_stage_slice():
     T = 200
     gfor = engine.global_schedule(T, 10, seed=0)
     for world in (2, 3, 4, 8):
-        for spb in (5, 10, 7):
+        for spb in (5, 10, 7, 16):
             eng = engine.ClipEngine(M(), steps_per_batch=spb)
             eng.world = world
-            jobs = [j for i in range(40, 40 + spb) for j in eng.jobs_for_step(i, T, gfor)]
-            covered = {}
-            for rank in range(world):
-                plan, mine = eng.shard_plan(jobs, rank=rank, world=world)
-                assert len(mine) == sum(per for _, _, per, _ in plan)          # one launch: the slices of all groups
-                for want, poss, per, first in plan:
-                    sl = mine[first:first + per]
-                    assert all(int(jobs[p][1]) == want for p in sl)            # a slice holds one row count only
-                    for slot, p in enumerate(sl):
-                        covered.setdefault(want, {})[rank * per + slot] = p
-            for want, slots in covered.items():                                 # the ranks' slices tile each group
-                poss = [p for p, j in enumerate(jobs) if int(j[1]) == want]
-                got = [slots[i] for i in range(len(slots))]
-                assert got[:len(poss)] == poss and all(p == poss[-1] for p in got[len(poss):])
-            # the early count all-gather: rank r sends the counts of ITS launch (here: the job position itself, as a
-            # stand-in); count_index must pick every job's own count out of the concatenation of the ranks' vectors
-            vecs = []
-            for rank in range(world):
-                plan_r, mine_r = eng.shard_plan(jobs, rank=rank, world=world)
-                vecs.append(list(mine_r))
-            nm = len(vecs[0])
-            assert all(len(v) == nm for v in vecs)
-            flat = [x for v in vecs for x in v]
-            idx = eng.count_index(eng.shard_plan(jobs, rank=0, world=world)[0], len(jobs), nm)
-            assert [flat[i] for i in idx] == list(range(len(jobs)))
+            for first in (40, 0, T - 6):
+                jobs = [j for i in range(first, min(T, first + spb)) for j in eng.jobs_for_step(i, T, gfor)]
+                # ---- owner-aligned
+                eng.owner_aligned = True
+                plans = [eng.shard_plan(jobs, rank=r, world=world) for r in range(world)]
+                plan = plans[0][0]
+                nl, ng = plan["nl"], plan["ng"]
+                assert all(p[0] == plan for p in plans)                           # the placement does not depend on the rank
+                assert sorted(set(plan["place"])) == sorted(plan["place"])         # one (rank, slot) per job
+                for pos, (r, slot) in enumerate(plan["place"]):
+                    mine = plans[r][1]
+                    assert len(mine) == nl + ng and mine[slot] == pos              # the owner's launch computes it, at that slot
+                    if jobs[pos][2] == "l":
+                        assert r == jobs[pos][0] % world and slot < nl             # frame f -> rank f mod world = owner of key frame f
+                        ks = engine.KeyFrameShard(None, None, r, world, base=first)
+                        if first <= jobs[pos][0] < first + spb:                    # (when key frame f is in this very batch)
+                            assert ks.owner(jobs[pos][0] - first) == r
+                    else:
+                        assert slot >= nl
+                for r in range(world):                                             # padding repeats a job of the same kind
+                    mine = plans[r][1]
+                    assert all(jobs[p][2] != "g" for p in mine[:nl]) and all(jobs[p][2] == "g" for p in mine[nl:])
+                # the early count all-gather: rank r sends the counts of ITS launch (here: the job position itself, as a
+                # stand-in); count_index must pick every job's own count out of the concatenation of the ranks' vectors
+                flat = [x for r in range(world) for x in plans[r][1]]
+                idx = eng.count_index(plan, len(jobs), nl + ng)
+                assert [flat[i] for i in idx] == list(range(len(jobs)))
+                # ---- legacy (whole records everywhere: per-frame aggregation)
+                eng.owner_aligned = False
+                covered = {}
+                for rank in range(world):
+                    plan_l, mine = eng.shard_plan(jobs, rank=rank, world=world)
+                    assert len(mine) == sum(per for _, _, per, _ in plan_l)
+                    for want, poss, per, first_slot in plan_l:
+                        sl = mine[first_slot:first_slot + per]
+                        assert all(int(jobs[p][1]) == want for p in sl)
+                        for slot, p in enumerate(sl):
+                            covered.setdefault(want, {})[rank * per + slot] = p
+                for want, slots in covered.items():
+                    poss = [p for p, j in enumerate(jobs) if int(j[1]) == want]
+                    got = [slots[i] for i in range(len(slots))]
+                    assert got[:len(poss)] == poss and all(p == poss[-1] for p in got[len(poss):])
+                vecs = [list(eng.shard_plan(jobs, rank=r, world=world)[1]) for r in range(world)]
+                nm = len(vecs[0])
+                flat = [x for v in vecs for x in v]
+                idx = eng.count_index(eng.shard_plan(jobs, rank=0, world=world)[0], len(jobs), nm)
+                assert [flat[i] for i in idx] == list(range(len(jobs)))
     # and run()'s prefetch asks the source for exactly those frames
     asked = []
 
@@ -118,6 +143,7 @@ def test_prefetch_slice_is_the_frame_stage_slice():
 
     eng = engine.ClipEngine(M(), steps_per_batch=10)
     eng.world, eng.rank = 4, 1
+    eng.owner_aligned = True
     import torch
     Src.dtype = torch.uint8
     with pytest.raises(StopIteration):

@@ -53,11 +53,12 @@ def _worker(rank, world, port, outdir, spb):
     from mega.pytorch_amd import engine
     cfg, model, frames = _build()
     gfor = engine.global_schedule(T, 3, seed=0)
-    eng = engine.ClipEngine(model, steps_per_batch=spb, dist_group=dist.group.WORLD)
+    eng = engine.ClipEngine(model, steps_per_batch=spb, dist_group=dist.group.WORLD, keep_logits=True)
     dets = eng.run(frames, T, gfor, first=0, last=NKEY)
     fe = model.roi_heads.box.feature_extractor
     torch.save({"dets": [(d.bbox, d.get_field("scores"), d.get_field("labels")) for d in dets],
-                "mem": [fe.mem[i]["k"].clone() for i in range(fe.stage)], "frames_computed": eng.frames_computed},
+                "mem": [fe.mem[i]["k"].clone() for i in range(fe.stage)], "frames_computed": eng.frames_computed,
+                "wire": dict(eng.wire), "own_logits": sum(1 for x in eng.logits_log if x is not None)},
                os.path.join(outdir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -92,6 +93,23 @@ def test_sharded_engine_matches_single_process(world, spb):
             assert a.shape == b.shape and (a.float() - b.float()).abs().max() < 1e-4
     # frame-stage work is divided: a rank computes about 1/world of the frames
     assert ranks[0]["frames_computed"] <= single_eng.frames_computed
+    # ---- bytes on the wire: a frame travels as ONE record of the REF_POST_NMS_TOP_N (here 10) rows every
+    # rank's window reads -- boxes, scores, feature rows, count -- never as its 40-row key-role record (rows 10-39 stay on
+    # the rank that owns key frame f); a key frame's aggregation runs on exactly one rank
+    bn, D, esz = 10, 1024, 4                                   # (CPU twins: f32 stream)
+    rec = bn * 16 + (bn * 4 + 15) // 16 * 16 + bn * D * esz + 16
+    nbatch = 1 + -(-(NKEY - 1) // spb)
+    njobs = 13 + 3 + 2 * (NKEY - 1)                            # cold start: 13 local + 3 global frames; then 1 + 1 per key frame
+    slots = sum(r["wire"]["frame_records"] for r in ranks) / float(rec)
+    assert slots == int(slots) and njobs <= slots <= njobs + nbatch * 2 * (world - 1), (slots, njobs)
+    per_kf = sum(r["wire"]["frame_records"] for r in ranks) / NKEY
+    print("world %d: %.0f bytes of frame records per key frame on the wire (2 records = %d), memory rows %.0f B, detections %.0f B"
+          % (world, per_kf, 2 * rec, sum(r["wire"].get("memory_rows", 0) for r in ranks) / NKEY,
+             sum(r["wire"].get("detections", 0) for r in ranks) / NKEY))
+    # memory entries: (10 + 2 + 2) feature rows per key frame and stage set, padded to the batch's per-rank slot count
+    mem_rows = sum(r["wire"]["memory_rows"] for r in ranks) / (D * esz)
+    assert mem_rows <= nbatch * world * -(-spb // world) * (10 + 10 + 10), mem_rows
+    assert sum(r["own_logits"] for r in ranks) == NKEY         # every key frame aggregated by exactly ONE rank
 
 
 def test_job_schedule_matches_reference_feed():

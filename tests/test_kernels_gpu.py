@@ -875,3 +875,17 @@ def test_fused_bottleneck64_bit_equal_to_unfused(dev, shape):
     y = F.relu(bn(F.conv2d(y, w2.float().cpu().permute(0, 3, 1, 2), padding=1), 1))
     y = F.relu(bn(F.conv2d(y, w3.float().cpu().permute(0, 3, 1, 2)), 2) + xf).permute(0, 2, 3, 1)
     assert _relerr(got.float().cpu(), y) < 2e-2
+
+
+def test_cat_rows_cast_bf16(dev):
+    """ops.cat_rows_cast_bf16 == torch.cat(pieces, 0).to(bfloat16), bit for bit: contiguous pieces, row slices of wider
+    buffers (row stride > K), single-row and empty pieces, more pieces than one launch's 56 segments."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    big = (torch.randn((700, 2048), generator=g) * 3).to(dev)
+    pieces = [big[:300, :1024], big[300:301, 1024:], torch.zeros((0, 1024), device=dev), big[301:700, 1024:].contiguous(),
+              (torch.randn((5, 1024), generator=g)).to(dev)]
+    pieces += [big[i:i + 2, :1024] for i in range(0, 140, 2)]         # 70 more segments
+    got = ops.cat_rows_cast_bf16(pieces)
+    want = torch.cat(pieces, dim=0).to(torch.bfloat16)
+    assert got.shape == want.shape and torch.equal(got.view(torch.int16), want.view(torch.int16))
