@@ -525,7 +525,7 @@ def main():
         else:
             sym = "igemm_kernel<%s, %s, %s, %s>" % (tag if tag == "bf16" else "float", tag if tag == "bf16" else "float",
                                                     tile[0], tile[1])
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
             if os.path.exists(pmc):
                 ks = json.load(open(pmc))["kernels"]
