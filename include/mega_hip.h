@@ -253,6 +253,15 @@ int mega_bottleneck64_fwd(const void* x, const void* w1, const float* s1, const 
                           const float* b2, const void* w3, const float* s3, const float* b3, void* out, int N, int H, int W,
                           void* stream);
 
+/* The stage's first block with the 1x1 downsample branch on the residual (layer1 block 0: 64 -> 64 -> 64 (3x3) -> 256,
+ * backbone/resnet.py:266-276,:324-344), one persistent kernel:
+ *   out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + bnd(convd(x))),  x NHWC bf16 [N][H][W][64], out [N][H][W][256];
+ * w1 [64][64], w2 [64][3][3][64], w3 / wd [256][64].  The identity branch is computed from the x patch already in LDS and
+ * rounded to bf16 before the add (as the separate launch would): bit-identical to the four mega_conv2d_nhwc launches. */
+int mega_bottleneck64_ds_fwd(const void* x, const void* w1, const float* s1, const float* b1, const void* w2, const float* s2,
+                             const float* b2, const void* w3, const float* s3, const float* b3, const void* wd, const float* sd,
+                             const float* bd, void* out, int N, int H, int W, void* stream);
+
 /* dst [rows][3K] bf16 = [hi | lo | hi] of src [rows][K] f32 (hi = bf16(v), lo = bf16(v - hi); K % 8 == 0): the A operand
  * of a split-precision GEMM on the bf16 matrix cores against weight rows [Wh | Wh | Wl] -- v.W to ~2^-16.  Used for the
  * stage FCs of the aggregation head (roi_box_feature_extractors.py:826-827) when the activation stream is f32. */

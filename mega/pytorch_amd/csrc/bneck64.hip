@@ -313,6 +313,260 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_kernel(Bneck64Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The stage's FIRST block (layer1 block 0: 64 -> 64 -> 64 (3x3) -> 256 channels with the 1x1 downsample branch on the
+// residual, backbone/resnet.py:266-276,:324-344):
+//     y = relu( bn3(conv3(t2)) + bnd(convd(x)) ),   t2 = relu(bn2(conv2_3x3(relu(bn1(conv1 x)))))
+// Unfused it is FOUR launches and 2.2 KB per pixel (x read twice, t1 / t2 written and read, the 256-channel identity
+// written and read, y written); fused the 64-channel x patch is read once (1.41 x 128 B) and y written (512 B) -- the
+// identity branch is computed in the kernel from the patch that is already in LDS.
+// Same tile, wave roles and layouts as bneck64_kernel; differences: the patch is ONE 64-channel chunk that stays in LDS
+// (the downsample GEMM reads its centre pixels as MFMA rows), t2 re-uses t1's area (one more barrier), and ONE 36 KB
+// region holds w1, then wd, then w3 in turn.  The identity is rounded to bf16 before it is added (it is a tensor of its
+// own in the unfused path), then the igemm8 epilogue arithmetic: bit-identical to the four launches.
+constexpr int BD_OFF_W2 = 0;
+constexpr int BD_OFF_T1 = 64 * BK_W2ROW;                        // 74752: t1 patch [180][128 B]; t2 [128][128 B] after conv2
+constexpr int BD_OFF_XP = BD_OFF_T1 + BK_NP * 128;              // 97792: x patch [192][128 B], alive until the downsample GEMM
+constexpr int BD_OFF_WR = BD_OFF_XP + BK_M1 * 128;              // 122368: w1 [64][144 B] -> wd [256][144 B] -> w3 [256][144 B]
+constexpr int BD_LDS = BD_OFF_WR + 256 * BK_WROW;               // 159232
+static_assert(BD_OFF_T1 + 128 * BK_SBROW <= BD_LDS, "output staging must fit over t1 / x patch / weight region");
+
+struct Bneck64DsParams {
+  const bf16_t* x;      // [N][H][W][64]
+  const bf16_t* w1;     // [64][64]
+  const bf16_t* w2;     // [64][3][3][64]
+  const bf16_t* w3;     // [256][64]
+  const bf16_t* wd;     // [256][64]
+  const float *s1, *b1, *s2, *b2, *s3, *b3, *sd, *bd;
+  bf16_t* out;          // [N][H][W][256]
+  int N, H, W, tiles_y, tiles_x, ntiles;
+};
+
+__global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const w2l = smem + BD_OFF_W2;
+  unsigned char* const t1l = smem + BD_OFF_T1;
+  unsigned char* const t2l = smem + BD_OFF_T1;      // (after conv2)
+  unsigned char* const xpl = smem + BD_OFF_XP;
+  unsigned char* const wrl = smem + BD_OFF_WR;
+  unsigned char* const sbl = smem + BD_OFF_T1;      // (after the last MFMA)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  {
+    const uint4* wg = reinterpret_cast<const uint4*>(p.w2);
+    for (int e = tid; e < 64 * 72; e += BK_NT) {
+      const int n = e / 72, c = e - n * 72;
+      *reinterpret_cast<uint4*>(w2l + n * BK_W2ROW + c * 16) = wg[e];
+    }
+  }
+  const unsigned xbytes = (unsigned)((size_t)p.N * p.H * p.W * 128), obytes = (unsigned)((size_t)p.N * p.H * p.W * 512);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (int)xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)obytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  auto tile_origin = [&](int t, int& n, int& y0, int& x0) {
+    const int per_img = p.tiles_y * p.tiles_x;
+    n = t / per_img;
+    const int r = t - n * per_img;
+    const int ty = r / p.tiles_x;
+    y0 = ty * BK_TY;
+    x0 = (r - ty * p.tiles_x) * BK_TX;
+  };
+  // ---- the next tile's x patch: 192 rows x 8 pieces of 16 B = 3 per thread
+  u32x4_t px[3];
+  auto prefetch = [&](int t) {
+    int n, y0, x0;
+    const bool live = t < p.ntiles;
+    tile_origin(live ? t : 0, n, y0, x0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int v = tid + BK_NT * i;
+      const int row = v >> 3, j = v & 7;
+      const int py = row / BK_PX, pxx = row - py * BK_PX;
+      const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
+      const bool ok = live && row < BK_NP && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      px[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * 128 + j * 16) : OOB, 0, 0);
+    }
+  };
+  // ---- per-lane constants (igemm layout: a lane owns one output channel and 16 pixels of its 32-pixel block)
+  const int r1 = 32 * wave + l31;
+  const unsigned a1_base = (unsigned)(r1 * 128), a1_sw = (unsigned)((r1 >> 1) & 7);
+  const unsigned bw_base = (unsigned)(l31 * BK_WROW + h * 16);           // weight-region row l31 (+ 32 nb / + 32 wave rows)
+  const int mb2 = wave >> 1, nb2 = wave & 1;
+  const int ay = 2 * mb2 + (l31 >> 4), ax = l31 & 15;
+  const unsigned a2_base = (unsigned)((ay * BK_PX + ax) * 128);
+  const int b2_off = (32 * nb2 + l31) * BK_W2ROW + h * 16;
+  const unsigned a3_base = (unsigned)(l31 * 128), a3_sw = (unsigned)((l31 >> 1) & 7);
+  const float s1a = p.s1[l31], s1b = p.s1[32 + l31], b1a = p.b1[l31], b1b = p.b1[32 + l31];
+  const float s2v = p.s2[32 * nb2 + l31], b2v = p.b2[32 * nb2 + l31];
+  const float s3v = p.s3[32 * wave + l31], b3v = p.b3[32 * wave + l31];
+  const float sdv = p.sd[32 * wave + l31], bdv = p.bd[32 * wave + l31];
+
+  int t = blockIdx.x;
+  prefetch(t);
+  __syncthreads();                              // w2 is in LDS
+  for (; t < p.ntiles; t += gridDim.x) {
+    int n, y0, x0;
+    tile_origin(t, n, y0, x0);
+    int ho = h, lo = l31;                       // (opaque copies: keeps the epilogues' index arithmetic out of the loop-invariant set)
+    asm volatile("" : "+v"(ho), "+v"(lo));
+    // ================= the patch and w1 into LDS
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int v = tid + BK_NT * i;
+      const int row = v >> 3, j = v & 7;
+      *reinterpret_cast<u32x4_t*>(xpl + row * 128 + ((j ^ ((row >> 1) & 7)) * 16)) = px[i];
+    }
+    *reinterpret_cast<u32x4_t*>(wrl + (tid >> 3) * BK_WROW + (tid & 7) * 16) =
+        *reinterpret_cast<const u32x4_t*>(p.w1 + (tid >> 3) * 64 + (tid & 7) * 8);
+    u32x4_t pwd[4];                             // wd for this tile: requested now, stored after conv1 is done with w1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pwd[i] = reinterpret_cast<const u32x4_t*>(p.wd)[tid + BK_NT * i];
+    __syncthreads();
+    // ================= conv1 (K = 64: one chunk)
+    f32x16_t c1a, c1b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c1a[r] = 0.f; c1b[r] = 0.f; }
+    if (wave < 6) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4*>(xpl + a1_base + (((unsigned)(2 * ks + h) ^ a1_sw) << 4));
+        const uint4 b0 = *reinterpret_cast<const uint4*>(wrl + bw_base + ks * 32);
+        const uint4 b1 = *reinterpret_cast<const uint4*>(wrl + 32 * BK_WROW + bw_base + ks * 32);
+        c1a = bk_mma(c1a, a, b0);
+        c1b = bk_mma(c1b, a, b1);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int R = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * ho;
+        if (R < BK_NP) {
+          const int py = R / BK_PX, pxx = R - py * BK_PX;
+          const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
+          const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+          const bf16_t va = in ? bk_relu1(c1a[r] * s1a + b1a) : (bf16_t)0;
+          const bf16_t vb = in ? bk_relu1(c1b[r] * s1b + b1b) : (bf16_t)0;
+          unsigned char* base = t1l + R * 128;
+          const int sw = (pxx >> 1) & 7;
+          *reinterpret_cast<bf16_t*>(base + (((lo >> 3) ^ sw) * 16) + (lo & 7) * 2) = va;
+          *reinterpret_cast<bf16_t*>(base + ((((32 + lo) >> 3) ^ sw) * 16) + (lo & 7) * 2) = vb;
+        }
+      }
+    }
+    __syncthreads();                            // t1 is visible; every wave is done with w1
+    // ---- wd into the weight region; w3 and the next tile's patch start travelling
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + BK_NT * i;
+      *reinterpret_cast<u32x4_t*>(wrl + (v >> 3) * BK_WROW + (v & 7) * 16) = pwd[i];
+    }
+    u32x4_t pw3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw3[i] = reinterpret_cast<const u32x4_t*>(p.w3)[tid + BK_NT * i];
+    prefetch(t + gridDim.x);
+    // ================= conv2
+    f32x16_t c2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c2[r] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const unsigned sw2 = (unsigned)(((ax + kw) >> 1) & 7);
+          const uint4 a = *reinterpret_cast<const uint4*>(t1l + a2_base + (kh * BK_PX + kw) * 128 +
+                                                          (((unsigned)(2 * ks + h) ^ sw2) << 4));
+          const uint4 b = *reinterpret_cast<const uint4*>(w2l + b2_off + (kh * 3 + kw) * 128 + ks * 32);
+          c2 = bk_mma(c2, a, b);
+        }
+    __syncthreads();                            // every wave is done with t1 (t2 takes its place); wd is visible
+    {
+      const int c = 32 * nb2 + lo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int P = 32 * mb2 + (r & 3) + 8 * (r >> 2) + 4 * ho;
+        *reinterpret_cast<bf16_t*>(t2l + P * 128 + (((c >> 3) ^ ((P >> 1) & 7)) * 16) + (c & 7) * 2) = bk_relu1(c2[r] * s2v + b2v);
+      }
+    }
+    // ================= the identity branch: bnd(convd(x)) on the patch's centre pixels, rounded to bf16 (two per register)
+    unsigned pk[4][8];
+    {
+      uint4 bf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bf[ks] = *reinterpret_cast<const uint4*>(wrl + 32 * wave * BK_WROW + bw_base + ks * 32);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const int R = (2 * mb + (l31 >> 4) + 1) * BK_PX + (l31 & 15) + 1;      // patch row of tile pixel 32 mb + l31
+        const unsigned xa = (unsigned)(R * 128), xs = (unsigned)((R >> 1) & 7);
+        f32x16_t cd;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cd[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const uint4 a = *reinterpret_cast<const uint4*>(xpl + xa + (((unsigned)(2 * ks + h) ^ xs) << 4));
+          cd = bk_mma(cd, a, bf[ks]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pk[mb][q] = pack_bf16x2(cd[2 * q] * sdv + bdv, cd[2 * q + 1] * sdv + bdv);
+      }
+    }
+    __syncthreads();                            // t2 is visible; every wave is done with wd
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + BK_NT * i;
+      *reinterpret_cast<u32x4_t*>(wrl + (v >> 3) * BK_WROW + (v & 7) * 16) = pw3[i];
+    }
+    __syncthreads();                            // w3 is visible
+    // ================= conv3 + bn3 + identity + ReLU (igemm8's epilogue arithmetic), in place over the packed identity
+    {
+      uint4 bf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bf[ks] = *reinterpret_cast<const uint4*>(wrl + 32 * wave * BK_WROW + bw_base + ks * 32);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        f32x16_t c3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c3[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const uint4 a = *reinterpret_cast<const uint4*>(t2l + mb * 4096 + a3_base + (((unsigned)(2 * ks + h) ^ a3_sw) << 4));
+          c3 = bk_mma(c3, a, bf[ks]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v0 = c3[2 * q] * s3v + b3v, v1 = c3[2 * q + 1] * s3v + b3v;
+          v0 += __uint_as_float(pk[mb][q] << 16);
+          v1 += __uint_as_float(pk[mb][q] & 0xffff0000u);
+          pk[mb][q] = bk_relu_pack(v0, v1);
+        }
+      }
+    }
+    __syncthreads();                            // every wave is done with t2 / w3 / the patch: the staging area may overwrite them
+    {
+      const int c3ch = 32 * wave + lo;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int P = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * ho;
+          const unsigned v = pk[mb][r >> 1];
+          *reinterpret_cast<bf16_t*>(sbl + P * BK_SBROW + c3ch * 2) = (bf16_t)((r & 1) ? (v >> 16) : (v & 0xffffu));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int id = tid + BK_NT * i;
+      const int P = id >> 5, cv = id & 31;
+      const int yy = y0 + (P >> 4), xx = x0 + (P & 15);
+      const uint4 v = *reinterpret_cast<const uint4*>(sbl + P * BK_SBROW + cv * 16);
+      const u32x4_t q = {v.x, v.y, v.z, v.w};
+      const unsigned o = (yy < p.H && xx < p.W) ? (unsigned)(((n * p.H + yy) * p.W + xx) * 512 + cv * 16) : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(q, rs_o, o, 0, 0);
+    }
+    __syncthreads();                            // the staging area is free again
+  }
+}
+
 }  // namespace
 
 // y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + x) for a 256 -> 64 -> 64 (3x3, pad 1) -> 256 identity bottleneck,
@@ -347,5 +601,42 @@ extern "C" int mega_bottleneck64_fwd(const void* x, const void* w1, const float*
   const int grid = (int)(tiles < cus ? tiles : cus);
   (void)hipFuncSetAttribute((const void*)bneck64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS);
   hipLaunchKernelGGL(bneck64_kernel, dim3(grid), dim3(BK_NT), BK_LDS, (hipStream_t)stream, p);
+  return mega_check_launch();
+}
+
+// The stage's first block with the 1x1 downsample branch: x NHWC bf16 [N][H][W][64] -> out [N][H][W][256],
+//   out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + bnd(convd(x))).  Bit-identical to the four launches it replaces.
+extern "C" int mega_bottleneck64_ds_fwd(const void* x, const void* w1, const float* s1, const float* b1, const void* w2,
+                                        const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
+                                        const void* wd, const float* sd, const float* bd, void* out, int N, int H, int W,
+                                        void* stream) {
+  mega_clear_error();
+  if (!x || !w1 || !s1 || !b1 || !w2 || !s2 || !b2 || !w3 || !s3 || !b3 || !wd || !sd || !bd || !out || N <= 0 || H <= 0 || W <= 0)
+    return MEGA_ERR_ARG;
+  if ((size_t)N * H * W * 256 * 2 >= 0x7FF00000ull) return MEGA_ERR_ARG;          // 32-bit buffer offsets
+  Bneck64DsParams p;
+  p.x = (const bf16_t*)x; p.w1 = (const bf16_t*)w1; p.w2 = (const bf16_t*)w2; p.w3 = (const bf16_t*)w3; p.wd = (const bf16_t*)wd;
+  p.s1 = s1; p.b1 = b1; p.s2 = s2; p.b2 = b2; p.s3 = s3; p.b3 = b3; p.sd = sd; p.bd = bd;
+  p.out = (bf16_t*)out;
+  p.N = N; p.H = H; p.W = W;
+  p.tiles_y = cdiv(H, BK_TY);
+  p.tiles_x = cdiv(W, BK_TX);
+  const long tiles = (long)N * p.tiles_y * p.tiles_x;
+  if (tiles > 0x7FFFFFFF) return MEGA_ERR_ARG;
+  p.ntiles = (int)tiles;
+  int cus = 256;
+  {
+    static int cached[64] = {0};
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cached[dev]) {
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cached[dev] = n;
+      else cached[dev] = 256;
+    }
+    cus = cached[dev];
+  }
+  const int grid = (int)(tiles < cus ? tiles : cus);
+  (void)hipFuncSetAttribute((const void*)bneck64_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BD_LDS);
+  hipLaunchKernelGGL(bneck64_ds_kernel, dim3(grid), dim3(BK_NT), BD_LDS, (hipStream_t)stream, p);
   return mega_check_launch();
 }

@@ -169,10 +169,21 @@ class Bottleneck(_Packed):
                 and self.conv3.out_channels == 256 and x.shape[0] * (-(-x.shape[1] // 8)) * (-(-x.shape[2] // 16)) >= 128
                 and os.environ.get("MEGA_FUSE_BOTTLENECK", "1") != "0")
 
+    def _fusable_ds(self, x):
+        import os
+        return (self.fuse and x.dtype == torch.bfloat16 and x.is_cuda and self.downsample is not None and self.stride == 1
+                and self.down_stride == 1 and self.dilation == 1 and self.conv1.in_channels == 64
+                and self.conv1.out_channels == 64 and self.conv3.out_channels == 256
+                and x.shape[0] * (-(-x.shape[1] // 8)) * (-(-x.shape[2] // 16)) >= 128
+                and os.environ.get("MEGA_FUSE_BOTTLENECK", "1") not in ("0", "id"))
+
     def run(self, x):
         pk = self._packed(x.dtype, x.device)
         if self._fusable(x):
             return ops.bottleneck64(x, pk["w1"], pk["s1"], pk["b1"], pk["w2"], pk["s2"], pk["b2"], pk["w3"], pk["s3"], pk["b3"])
+        if self._fusable_ds(x):
+            return ops.bottleneck64_ds(x, pk["w1"], pk["s1"], pk["b1"], pk["w2"], pk["s2"], pk["b2"], pk["w3"], pk["s3"],
+                                       pk["b3"], pk["wd"], pk["sd"], pk["bd"])
         identity = x
         if self.downsample is not None:
             identity = ops.conv2d_nhwc(x, pk["wd"], pk["sd"], pk["bd"], stride=self.down_stride)

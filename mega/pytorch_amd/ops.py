@@ -174,6 +174,32 @@ def bottleneck64(x, w1, s1, b1, w2, s2, b2, w3, s3, b3):
     return out
 
 
+def bottleneck64_ds(x, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, bd):
+    """The fused FIRST block of layer1 (64 -> 64 -> 64 (3x3) -> 256 with the 1x1 downsample branch): x NHWC bf16 [N,H,W,64] ->
+    relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + bnd(convd(x))) [N,H,W,256]; same bits as the four conv2d_nhwc
+    launches.  w1 [64,1,1,64], w2 [64,3,3,64], w3 / wd [256,1,1,64]."""
+    _gpu(x, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, bd)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    assert C == 64 and x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert tuple(w1.shape) == (64, 1, 1, 64) and tuple(w2.shape) == (64, 3, 3, 64)
+    assert tuple(w3.shape) == (256, 1, 1, 64) and tuple(wd.shape) == (256, 1, 1, 64)
+    for t in (w1, w2, w3, wd):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    for v, n in ((s1, 64), (b1, 64), (s2, 64), (b2, 64), (s3, 256), (b3, 256), (sd, 256), (bd, 256)):
+        assert v.dtype == torch.float32 and v.numel() == n and v.is_contiguous()
+    out = torch.empty((N, H, W, 256), dtype=torch.bfloat16, device=x.device)
+    if out.numel() * 2 >= 0x7FF00000:
+        raise ValueError("bottleneck64_ds: output of %.2f GiB; 32-bit buffer offsets (< 2 GiB)" % (out.numel() * 2 / 2.0 ** 30))
+    px = float(N * H * W)
+    _tok = _pb("bneck64_fused", 2.0 * px * (64 * 64 + 576 * 64 + 2 * 64 * 256), px * 640.0)
+    rc = lib.mega_bottleneck64_ds_fwd(_ptr(x), _ptr(w1), _ptr(s1), _ptr(b1), _ptr(w2), _ptr(s2), _ptr(b2), _ptr(w3), _ptr(s3),
+                                      _ptr(b3), _ptr(wd), _ptr(sd), _ptr(bd), _ptr(out), N, H, W, _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_bottleneck64_ds_fwd")
+    return out
+
+
 def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None):
     """x [M,K], w [Nout,K] (nn.Linear layout) -> [M,Nout]."""
     M, K = x.shape

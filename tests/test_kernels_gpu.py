@@ -889,3 +889,27 @@ def test_cat_rows_cast_bf16(dev):
     got = ops.cat_rows_cast_bf16(pieces)
     want = torch.cat(pieces, dim=0).to(torch.bfloat16)
     assert got.shape == want.shape and torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("shape", [(2, 150, 250), (3, 37, 53), (1, 8, 16), (40, 9, 17)])
+def test_fused_bottleneck64_ds_bit_equal_to_unfused(dev, shape):
+    """ops.bottleneck64_ds (layer1's FIRST block: 64 -> 64 -> 64 (3x3) -> 256 with the 1x1 downsample branch on the residual,
+    backbone/resnet.py:266-276,:324-344, in one persistent kernel; the identity branch computed from the x patch in LDS and
+    rounded to bf16 before the add) against the four conv2d_nhwc launches it replaces: the same bits."""
+    ops = _ops()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * 11 + W)
+    x = torch.randn((N, H, W, 64), generator=g).relu().to(torch.bfloat16).to(dev)
+    w1 = (torch.randn((64, 1, 1, 64), generator=g) * 0.12).to(torch.bfloat16).to(dev)
+    w2 = (torch.randn((64, 3, 3, 64), generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    w3 = (torch.randn((256, 1, 1, 64), generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    wd = (torch.randn((256, 1, 1, 64), generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    sb = [((torch.rand((n,), generator=g) + 0.5).to(dev), (torch.randn((n,), generator=g) * 0.2).to(dev)) for n in (64, 64, 256, 256)]
+    ident = ops.conv2d_nhwc(x, wd, sb[3][0], sb[3][1])
+    t1 = ops.conv2d_nhwc(x, w1, sb[0][0], sb[0][1], relu=True)
+    t2 = ops.conv2d_nhwc(t1, w2, sb[1][0], sb[1][1], pad=1, relu=True)
+    ref = ops.conv2d_nhwc(t2, w3, sb[2][0], sb[2][1], residual=ident, relu=True)
+    got = ops.bottleneck64_ds(x, w1, sb[0][0], sb[0][1], w2, sb[1][0], sb[1][1], w3, sb[2][0], sb[2][1], wd, sb[3][0], sb[3][1])
+    torch.cuda.synchronize()
+    nd = (got.view(torch.int16) != ref.view(torch.int16)).sum().item()
+    assert nd == 0, "%d of %d elements differ (max |d| %.3g)" % (nd, got.numel(), (got.float() - ref.float()).abs().max().item())
