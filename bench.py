@@ -110,13 +110,20 @@ def key_frames_per_block(steps, world):
 
 def default_steps_per_batch(steps, world):
     """Key frames per engine step-batch when --steps-per-batch is not given: the largest divisor of the block's key
-    frames (steps x world) that is <= 20 x world.  One GPU: 20 key frames = a 40-frame frame stage (M = 95760 rows per
-    layer-3 launch = 1.95 rounds of 192-row tiles on the 256 CUs; measured 767 FPS against 753 with 10, round 3: the
-    small kernels of the aggregation amortise over twice the key frames).  N GPUs: 20 N whenever --steps is a multiple
-    of 20 -- every rank's slice of the frame stage is then the same 40 frames as on one GPU."""
+    frames (steps x world) that is <= 20 x world -- one GPU: 20 key frames = a 40-frame frame stage (M = 95760 rows per
+    layer-3 launch = 1.95 rounds of 192-row tiles on the 256 CUs), the aggregation's small kernels amortised over 20 key
+    frames; N GPUs: 20 N, every rank's slice of the frame stage the same 40 frames as on one GPU.
+    EXCEPT when that would make the block ONE batch (the driver's --steps 20): a block is bracketed by synchronisations,
+    so a single batch runs frame stage -> aggregation back to back with nothing overlapped; two batches of 10 x world
+    let the second frame stage (20 frames = 0.97 rounds of 192-row tiles) run beside the first aggregation.  Measured on
+    one box, round 4 (the aggregation replays a hipGraph, so halving the batch no longer doubles host work): [10, 10]
+    890.5 FPS, [20] 877.0, [5, 5, 5, 5] 713.2; round 3 (eager aggregation) had [20] ahead, 767 : 753."""
     world = max(world, 1)
     kf = key_frames_per_block(steps, world)
-    return max(d for d in range(1, kf + 1) if kf % d == 0 and d <= 20 * world)
+    d = max(d for d in range(1, kf + 1) if kf % d == 0 and d <= 20 * world)
+    if d == kf and d % (2 * world) == 0 and d // 2 >= 10 * world:
+        d //= 2
+    return d
 
 
 def free_port():
@@ -167,7 +174,7 @@ def dry_run(args, world, rank, local_rank, json_fd):
     class _M(object):        # the schedule only needs these constants (MEGA R-101 defaults)
         all_frame_interval, key_frame_location, key_num, base_num, global_enable = 25, 12, 300, 75, True
         cfg = type("C", (), {"INPUT": type("I", (), {"PIXEL_MEAN": (0, 0, 0), "TO_BGR255": True})})
-    e = eng.ClipEngine(_M())
+    e = eng.ClipEngine(_M(), steps_per_batch=spb)
     e.rank, e.world = rank, live
     e.owner_aligned = True        # (the product's dealing with the batched aggregation: frame f -> rank f mod world)
     T = 64 + 2 * KF
@@ -192,7 +199,7 @@ def dry_run(args, world, rank, local_rank, json_fd):
                 "value": None, "unit": "frames/s", "n_gpus": live, "steps": K, "warmup": args.warmup, "ms_per_step": None,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dry_run": True,
                 "config": {"key_frames_per_step": live, "key_frames_per_block": KF, "steps_per_batch": spb,
-                           "frames_per_batch": len(jobs), "frames_per_rank_per_batch": most,
+                           "batch_sizes_in_a_block": e.batch_sizes(KF), "frames_per_batch": len(jobs), "frames_per_rank_per_batch": most,
                            "backend": dist.get_backend() if live > 1 else None}}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if live > 1:

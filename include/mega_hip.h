@@ -87,6 +87,13 @@ int mega_stem_conv_bn_relu_bf16_u8(const void* frames_u8, const void* w_n176_bf1
                                    void* out, int N, int H, int W, float mean0, float mean1, float mean2, int to_bgr,
                                    void* stream);
 
+/* The whole stem of resnet.py:355-366 in one kernel (bf16): conv 7x7/2 + FrozenBN + ReLU + F.max_pool2d(3, 2, 1); `in` =
+ * the preprocessed f32 NCHW image (u8 = 0) or the uint8 RGB frames [N][H][W][3] with the preprocessing on the patch load
+ * (u8 = 1; mean / to_bgr as above); out NHWC bf16 [N][Hp][Wp][64], Hp = ((H - 1) / 2 + 1 - 1) / 2 + 1.  The stem's own
+ * 64-channel map is never written.  Same bits as mega_stem_conv_bn_relu_bf16[_u8] + mega_maxpool3x3s2_nhwc. */
+int mega_stem_pool_bf16(const void* in, int u8, const void* w_n176_bf16, const float* scale, const float* bias, void* out,
+                        int N, int H, int W, float mean0, float mean1, float mean2, int to_bgr, void* stream);
+
 /* F.max_pool2d(kernel 3, stride 2, padding 1) on NHWC (resnet.py:365). */
 int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
 

@@ -20,6 +20,7 @@ SIGNATURES = {
     "mega_stem_conv_bn_relu": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "mega_stem_conv_bn_relu_bf16": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "mega_stem_conv_bn_relu_bf16_u8": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
+    "mega_stem_pool_bf16": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
     "mega_maxpool3x3s2_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "mega_avgpool2x2_ceil_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "mega_roi_align_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] + [c_int] * 7 + [c_void_p]),

@@ -628,6 +628,155 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const void* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------- stem + 3x3/2 max-pool in one kernel (bf16)
+// The stem's output (300 x 500 x 64 per frame, 19 MB) was written by stem_mfma_kernel only to be read back by the max-pool
+// (resnet.py:361-366: F.max_pool2d(x, 3, 2, 1)).  Here a block owns a 4 x 16 tile of POOLED pixels: it computes the 9 x 33
+// stem pixels their windows cover (297 GEMM rows in ten 32-row MFMA blocks, pixel p = row * 33 + col), stages them in LDS as
+// bf16 with everything outside the stem map forced to 0 (every window holds at least one real pixel and all values are >= 0
+// after the ReLU, so 0 is the identity of this max), and writes max over the 3 x 3 windows: the 19 MB never reach HBM.
+// Same patch / weight layout, same MFMA and K order as stem_mfma_kernel; max of bf16 values is exact: bit-identical to
+// stem + max-pool (tests/test_kernels_gpu.py::test_stem_pool_bit_equal).
+constexpr int SP_PY = 4, SP_PX = 16;                       // pooled tile
+constexpr int SP_TY = 2 * SP_PY + 1, SP_TX = 2 * SP_PX + 1; // stem pixels it needs: 9 x 33
+constexpr int SP_NPIX = SP_TY * SP_TX;                     // 297
+constexpr int SP_NBLK = (SP_NPIX + 31) / 32;               // 10 MFMA row blocks
+constexpr int SP_PH = 2 * SP_TY + 5, SP_PW = 2 * SP_TX + 5, SP_PS = 72;   // input patch 23 x 71, row stride 72
+static_assert(SP_PW + 1 <= SP_PS, "the zero-weight 8th tap reads one column past the patch");
+
+__host__ __device__ constexpr int sp_group_off(int g) {
+  const int gg = g < 21 ? g : 20;
+  return (gg / 7) * (SP_PH * SP_PS) + (gg % 7) * SP_PS;
+}
+
+template <bool U8>
+__global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__ in_, const bf16_t* __restrict__ w,
+                                                        const float* __restrict__ scale, const float* __restrict__ bias,
+                                                        bf16_t* __restrict__ out, int N, int H, int W, int Ho, int Wo, int Hp,
+                                                        int Wp, float m0, float m1, float m2, int to_bgr) {
+  const float* __restrict__ in = reinterpret_cast<const float*>(in_);
+  const unsigned char* __restrict__ in8 = reinterpret_cast<const unsigned char*>(in_);
+  constexpr int PATCH_B = (3 * SP_PH * SP_PS * 2 + 15) / 16 * 16, OUT_PS = 144;
+  constexpr int LDS_B = SP_NBLK * 32 * OUT_PS > PATCH_B + 64 * SM_WS * 2 ? SP_NBLK * 32 * OUT_PS : PATCH_B + 64 * SM_WS * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_B];
+  unsigned short* patch = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* wl = reinterpret_cast<unsigned short*>(smem + PATCH_B);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.z;
+  const int py0 = blockIdx.y * SP_PY, px0 = blockIdx.x * SP_PX;
+  const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;          // first stem pixel of the tile (may be -1: outside)
+  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+  constexpr int NPL = (3 * SP_PH * SP_PS + 255) / 256, NWL = (64 * (SM_K / 8) + 255) / 256;
+  float pv[NPL];
+  uint4 wv[NWL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int e = tid + 256 * i;
+    const int c = e / (SP_PH * SP_PS);
+    const int rem = e - c * (SP_PH * SP_PS);
+    const int y = rem / SP_PS, x = rem - y * SP_PS;
+    const int iy = iy0 + y, ix = ix0 + x;
+    pv[i] = 0.f;
+    if (e < 3 * SP_PH * SP_PS && x < SP_PW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+      if (U8) {
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+        pv[i] = (float)in8[(((size_t)n * H + iy) * W + ix) * 3 + (to_bgr ? 2 - c : c)] - mean;
+      } else {
+        pv[i] = in[((size_t)(n * 3 + c) * H + iy) * W + ix];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    const int e = tid + 256 * i;
+    const int row = e / (SM_K / 8), v = e - row * (SM_K / 8);
+    if (e < 64 * (SM_K / 8)) wv[i] = *reinterpret_cast<const uint4*>(w + row * SM_K + v * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int e = tid + 256 * i;
+    if (e < 3 * SP_PH * SP_PS) patch[e] = f32_to_bf16(pv[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NWL; ++i) {
+    const int e = tid + 256 * i;
+    const int row = e / (SM_K / 8), v = e - row * (SM_K / 8);
+    if (e < 64 * (SM_K / 8)) *reinterpret_cast<uint4*>(&wl[row * SM_WS + v * 8]) = wv[i];
+  }
+  __syncthreads();
+
+  const int p = lane & 31, half = lane >> 5;
+  // wave w owns MFMA row blocks w, w + 4, w + 8 (waves 0 and 1: three blocks, 2 and 3: two)
+  constexpr int NB = 3;
+  f32x16_t acc[NB][2];
+  int pbase[NB];                       // patch element offset of this lane's pixel (row * 33 + col -> stem (r, c) -> patch (2 r, 2 c))
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int pix = min(32 * (wave + 4 * b) + p, SP_NPIX - 1);
+    const int r = pix / SP_TX, c = pix - r * SP_TX;
+    pbase[b] = 2 * r * SP_PS + 2 * c;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[b][j][q] = 0.f;
+  }
+#pragma unroll
+  for (int ks = 0; ks < SM_K / 16; ++ks) {
+    uint4 bfr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const uint4*>(&wl[(j * 32 + p) * SM_WS + ks * 16 + half * 8]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (wave + 4 * b < SP_NBLK) {    // (wave-uniform)
+        const unsigned* base = reinterpret_cast<const unsigned*>(patch + pbase[b] + (half ? sp_group_off(2 * ks + 1) : sp_group_off(2 * ks)));
+        const uint4 a = make_uint4(base[0], base[1], base[2], base[3]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bfr[j]),
+                                                              acc[b][j], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                     // every wave is done with the patch / weights
+  // ---- stem pixels -> LDS as bf16 [pixel][64 ch] (144-B stride); 0 outside the stem map
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ch = j * 32 + p;
+    const float sc = scale[ch], bi = bias[ch];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (wave + 4 * b < SP_NBLK) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int pix = 32 * (wave + 4 * b) + (q & 3) + 8 * (q >> 2) + 4 * half;
+          const int r = pix / SP_TX, c = pix - r * SP_TX;
+          const int oy = oy0 + r, ox = ox0 + c;
+          const bool ok = pix < SP_NPIX && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo;
+          *reinterpret_cast<unsigned short*>(smem + pix * OUT_PS + ch * 2) = ok ? f32_to_bf16(fmaxf(acc[b][j][q] * sc + bi, 0.f)) : (unsigned short)0;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3 x 3 / 2 max over the staged tile: pooled (y, x) of the tile = stem rows 2 y .. 2 y + 2, cols 2 x .. 2 x + 2 of the tile
+#pragma unroll
+  for (int i = 0; i < SP_PY * SP_PX * 8 / 256; ++i) {
+    const int v = tid + 256 * i;
+    const int pl = v >> 3, cv = v & 7;
+    const int ty = pl / SP_PX, tx = pl - ty * SP_PX;
+    const int oy = py0 + ty, ox = px0 + tx;
+    typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+    u16x8_t m = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const u16x8_t q = *reinterpret_cast<const u16x8_t*>(smem + ((2 * ty + dy) * SP_TX + 2 * tx + dx) * OUT_PS + cv * 16);
+        m = __builtin_elementwise_max(m, q);      // (non-negative bf16 values order like their bit patterns)
+      }
+    if (oy < Hp && ox < Wp) *reinterpret_cast<u16x8_t*>(out + (((size_t)n * Hp + oy) * Wp + ox) * 64 + cv * 8) = m;
+  }
+}
+
 }  // namespace
 
 extern "C" int mega_stem_conv_bn_relu_bf16(const float* in, const void* w_n176_bf16, const float* scale,
@@ -772,5 +921,26 @@ extern "C" int mega_avgpool2x2_ceil_nhwc(const void* in, void* out, int N, int H
                        C, Ho, Wo);
   else
     return MEGA_ERR_ARG;
+  return mega_check_launch();
+}
+
+// 7x7/2 stem conv + FrozenBN + ReLU + 3x3/2 max-pool (pad 1) in one kernel, bf16: in = preprocessed f32 NCHW [N][3][H][W]
+// (u8 = 0) or the uint8 frames [N][H][W][3] RGB with the preprocessing on the patch load (u8 = 1, as
+// mega_stem_conv_bn_relu_bf16_u8); out: NHWC bf16 [N][Hp][Wp][64], Hp = (Ho - 1) / 2 + 1 with Ho = (H - 1) / 2 + 1.
+// Bit-identical to mega_stem_conv_bn_relu_bf16[_u8] followed by mega_maxpool3x3s2_nhwc.
+extern "C" int mega_stem_pool_bf16(const void* in, int u8, const void* w_n176_bf16, const float* scale, const float* bias,
+                                   void* out, int N, int H, int W, float mean0, float mean1, float mean2, int to_bgr,
+                                   void* stream) {
+  mega_clear_error();
+  if (!in || !w_n176_bf16 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+  dim3 grid(cdiv(Wp, SP_PX), cdiv(Hp, SP_PY), N);
+  if (u8)
+    hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)w_n176_bf16, scale,
+                       bias, (bf16_t*)out, N, H, W, Ho, Wo, Hp, Wp, mean0, mean1, mean2, to_bgr);
+  else
+    hipLaunchKernelGGL(stem_pool_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)w_n176_bf16, scale,
+                       bias, (bf16_t*)out, N, H, W, Ho, Wo, Hp, Wp, 0.f, 0.f, 0.f, 0);
   return mega_check_launch();
 }

@@ -15,6 +15,7 @@ Layout contract at the seams: feature maps are logical NCHW tensors in channels-
 (``x.permute(0,2,3,1)`` is contiguous), dtype = the compute dtype (cfg.DTYPE: float32 | bfloat16).
 There is no CPU path: modules raise if the kernels are unavailable.
 """
+import os
 from collections import OrderedDict, deque
 
 import torch
@@ -163,14 +164,12 @@ class Bottleneck(_Packed):
     fuse = True        # layer1's identity blocks as ONE kernel (ops.bottleneck64); False / MEGA_FUSE_BOTTLENECK=0: three launches
 
     def _fusable(self, x):
-        import os
         return (self.fuse and x.dtype == torch.bfloat16 and x.is_cuda and self.downsample is None and self.stride == 1
                 and self.dilation == 1 and self.conv1.in_channels == 256 and self.conv1.out_channels == 64
                 and self.conv3.out_channels == 256 and x.shape[0] * (-(-x.shape[1] // 8)) * (-(-x.shape[2] // 16)) >= 128
                 and os.environ.get("MEGA_FUSE_BOTTLENECK", "1") != "0")
 
     def _fusable_ds(self, x):
-        import os
         return (self.fuse and x.dtype == torch.bfloat16 and x.is_cuda and self.downsample is not None and self.stride == 1
                 and self.down_stride == 1 and self.dilation == 1 and self.conv1.in_channels == 64
                 and self.conv1.out_channels == 64 and self.conv3.out_channels == 256
@@ -200,6 +199,10 @@ def _make_stage(in_channels, bottleneck_channels, out_channels, block_count, fir
     return nn.Sequential(*blocks)
 
 
+# MEGA_STEM_POOL=0: the stem and its max-pool as two kernels (A/B leg; same bits)
+_FUSE_STEM_POOL = os.environ.get("MEGA_STEM_POOL", "1") != "0"
+
+
 class BaseStem(_Packed):
     """backbone/resnet.py:347-366: 7x7/2 conv + FrozenBN + ReLU (one direct-conv kernel), 3x3/2 max-pool."""
 
@@ -218,12 +221,16 @@ class BaseStem(_Packed):
 
     def run(self, img_nchw_f32, dtype):
         pk = self._packed(dtype, img_nchw_f32.device)
+        if pk["w160"] is not None and _FUSE_STEM_POOL:
+            return ops.stem_pool(img_nchw_f32, pk["w160"], pk["s"], pk["b"])
         y = ops.stem(img_nchw_f32, pk["w"], pk["s"], pk["b"], dtype, w_n160=pk["w160"])
         return ops.maxpool3x3s2(y)
 
     def run_u8(self, frames_u8, mean, to_bgr):
         """bf16 mode: the stem reads the uint8 frames [N,H,W,3] themselves (preprocessing on the patch load)"""
         pk = self._packed(torch.bfloat16, frames_u8.device)
+        if _FUSE_STEM_POOL:
+            return ops.stem_pool(frames_u8, pk["w160"], pk["s"], pk["b"], mean, to_bgr)
         return ops.maxpool3x3s2(ops.stem_u8(frames_u8, pk["w160"], pk["s"], pk["b"], mean, to_bgr))
 
 

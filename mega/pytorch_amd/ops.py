@@ -251,6 +251,33 @@ def stem_u8(frames_u8, w_n160, scale, bias, mean, to_bgr=True):
     return out
 
 
+def stem_pool(x, w_n160, scale, bias, mean=None, to_bgr=True):
+    """resnet.py:355-366 in ONE kernel (bf16): conv7x7 s2 + BN + ReLU + max_pool2d(3, 2, 1) -> NHWC bf16 [N,Hp,Wp,64].  x =
+    uint8 frames [N,H,W,3] RGB (preprocessing on the patch load, `mean` required) or the preprocessed f32 NCHW image.  Same
+    bits as maxpool3x3s2(stem[_u8](...)); the stem's own map never reaches HBM."""
+    _gpu(x, w_n160, scale, bias)
+    lib = _lib.load()
+    u8 = x.dtype == torch.uint8
+    if u8:
+        N, H, W, C = x.shape
+        assert mean is not None
+    else:
+        N, C, H, W = x.shape
+        assert x.dtype == torch.float32
+        mean = (0.0, 0.0, 0.0)
+    assert C == 3 and x.is_contiguous()
+    assert w_n160.dtype == torch.bfloat16 and tuple(w_n160.shape) == (64, 176) and w_n160.is_contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    out = torch.empty((N, Hp, Wp, 64), dtype=torch.bfloat16, device=x.device)
+    _tok = _pb("stem", 2.0 * N * Ho * Wo * 64 * 147, x.numel() * x.element_size() + out.numel() * 2)
+    rc = lib.mega_stem_pool_bf16(_ptr(x), int(u8), _ptr(w_n160), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
+                                 float(mean[0]), float(mean[1]), float(mean[2]), int(to_bgr), _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_stem_pool_bf16")
+    return out
+
+
 def pack_stem_weight_bf16(w_oihw):
     """conv1.weight [64,3,7,7] -> bf16 [64,176]: column k = ((c*7+r)*8 + s for the 7 taps s of kernel row (c, r); the
     8th column of every group and columns 168..175 are zero (the kernel reads 8 consecutive patch pixels per group)."""

@@ -52,6 +52,10 @@ def stem(x_nchw, w_tap64, scale, bias, out_dtype, w_n160=None):
     return F.relu(y).permute(0, 2, 3, 1).contiguous().to(out_dtype)
 
 
+def stem_pool(x, w_n160, scale, bias, mean=None, to_bgr=True):
+    raise AssertionError("the CPU twins run float32: the bf16 stem + pool kernel has no twin")
+
+
 def maxpool3x3s2(x):
     return F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous().to(x.dtype)
 

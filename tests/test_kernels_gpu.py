@@ -845,6 +845,33 @@ def test_stem_u8_bit_equal_to_preprocess_plus_stem(dev, shape, to_bgr):
     assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("shape", [(2, 600, 1000), (2, 75, 131), (1, 9, 7), (3, 64, 66), (1, 17, 130), (2, 31, 33)])
+def test_stem_pool_bit_equal(dev, shape):
+    """ops.stem_pool (stem conv + BN + ReLU + 3x3/2 max-pool in one kernel; the stem's 64-channel map stays in LDS) ==
+    ops.maxpool3x3s2(ops.stem[_u8](...)) bit for bit, from the uint8 frames and from the preprocessed f32 image, including
+    odd sizes (windows hanging over the map's right / bottom edge), maps smaller than one tile and the padding row /
+    column at the top / left (backbone/resnet.py:355-366)."""
+    ops = _ops()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * 3 + W)
+    u8 = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8).to(dev)
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.05
+    sc = (torch.rand((64,), generator=g) + 0.5).to(dev)
+    bi = (torch.randn((64,), generator=g) * 0.1).to(dev)
+    mean = (102.9801, 115.9465, 122.7717)
+    w160 = ops.pack_stem_weight_bf16(w).to(dev)
+    wt = w.permute(1, 2, 3, 0).reshape(147, 64).contiguous().to(dev)
+    for to_bgr in (True, False):
+        ref = ops.maxpool3x3s2(ops.stem_u8(u8, w160, sc, bi, mean, to_bgr))
+        got = ops.stem_pool(u8, w160, sc, bi, mean, to_bgr)
+        assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    img = ops.preprocess_frames(u8, mean, True)
+    ref = ops.maxpool3x3s2(ops.stem(img, wt, sc, bi, torch.bfloat16, w_n160=w160))
+    got = ops.stem_pool(img, w160, sc, bi)
+    assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    assert float(got.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("shape", [(2, 150, 250), (3, 37, 53), (1, 8, 16), (5, 64, 48), (40, 9, 17)])
 def test_fused_bottleneck64_bit_equal_to_unfused(dev, shape):
     """ops.bottleneck64 (bneck64.hip: layer1's identity bottleneck 256 -> 64 -> 64 (3x3) -> 256 + residual in one persistent

@@ -16,7 +16,7 @@ def name(n):
 
 def main(path):
     rows = [(int(a), int(b), n) for a, b, q, s, n in csv.reader(open(path))]
-    pre = [i for i, r in enumerate(rows) if 'preprocess' in r[2] or 'stem_mfma' in r[2]]    # first kernel of a frame stage
+    pre = [i for i, r in enumerate(rows) if 'preprocess' in r[2] or 'stem_mfma' in r[2] or 'stem_pool' in r[2]]    # first kernel of a frame stage
     seg = rows[pre[-1]:]
     roi = [i for i, r in enumerate(seg) if 'roi_align' in r[2]][-1]
     # the frame stage ends with the first FC (one igemm launch after ROIAlign, + its split-K finalize)
