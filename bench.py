@@ -65,7 +65,7 @@ ALGO_GFLOP_PER_FRAME = 729.0   # minimal algorithmic work per stea
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=60)     # three step-batches of 20 key frames
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--arch", default="R-101")
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
@@ -110,20 +110,19 @@ def key_frames_per_block(steps, world):
 
 def default_steps_per_batch(steps, world):
     """Key frames per engine step-batch when --steps-per-batch is not given: the largest divisor of the block's key
-    frames (steps x world) that is <= 20 x world -- one GPU: 20 key frames = a 40-frame frame stage (M = 95760 rows per
+    frames (steps x world) that is <= 20 x world.  One GPU: 20 key frames = a 40-frame frame stage (M = 95760 rows per
     layer-3 launch = 1.95 rounds of 192-row tiles on the 256 CUs), the aggregation's small kernels amortised over 20 key
-    frames; N GPUs: 20 N, every rank's slice of the frame stage the same 40 frames as on one GPU.
-    EXCEPT when that would make the block ONE batch (the driver's --steps 20): a block is bracketed by synchronisations,
-    so a single batch runs frame stage -> aggregation back to back with nothing overlapped; two batches of 10 x world
-    let the second frame stage (20 frames = 0.97 rounds of 192-row tiles) run beside the first aggregation.  Measured on
-    one box, round 4 (the aggregation replays a hipGraph, so halving the batch no longer doubles host work): [10, 10]
-    890.5 FPS, [20] 877.0, [5, 5, 5, 5] 713.2; round 3 (eager aggregation) had [20] ahead, 767 : 753."""
+    frames.  N GPUs: 20 N whenever --steps is a multiple of 20 -- every rank's slice of the frame stage is then the same
+    40 frames as on one GPU.
+    The driver's --steps 20 block is therefore ONE batch: frame stage, then aggregation, nothing overlapped inside the
+    synchronised block.  Cutting it into two batches of 10 (the second frame stage beside the first aggregation) was
+    re-measured in round 4 with the aggregation replayed from a hipGraph: +1.5 % on one box (890.5 : 877.0), -1.4 % and
+    -2.4 % on two others (858.7 : 871.1, 867.5 : 887.9; profiles/r04_step_batch_structure.txt) -- how much of the first
+    aggregation gets CUs beside igemm8 blocks that own a CU's whole register file is up to the hardware scheduler, and two
+    aggregations of 10 cost 7.2 ms of GPU time against 5.3 for one of 20.  [20] stays."""
     world = max(world, 1)
     kf = key_frames_per_block(steps, world)
-    d = max(d for d in range(1, kf + 1) if kf % d == 0 and d <= 20 * world)
-    if d == kf and d % (2 * world) == 0 and d // 2 >= 10 * world:
-        d //= 2
-    return d
+    return max(d for d in range(1, kf + 1) if kf % d == 0 and d <= 20 * world)
 
 
 def free_port():

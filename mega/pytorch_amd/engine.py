@@ -17,6 +17,7 @@ sync) runs concurrently with the aggregation steps of batch b (many small kernel
 frame-stage tails leave idle).  The host only ever waits for work that was enqueued a full batch earlier
 (proposal counts of batch b, detection counts of batch b-1).
 """
+import os
 from collections import deque
 
 import numpy as np
@@ -587,6 +588,7 @@ class ClipEngine(object):
         sF = sB = cur = None
         if use_streams:
             if self._streams is None:
+                # (a high-priority aggregation stream was measured in round 4: no effect on any block structure)
                 self._streams = (torch.cuda.Stream(device=clip.device), torch.cuda.Stream(device=clip.device))
             sF, sB = self._streams
             cur = torch.cuda.current_stream(clip.device)

@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .relation import (RelationWeights, cat_rows, cat_rows_many, relation_attend, relation_attend_batched,
+from .relation import (RelationWeights, cat_rows, cat_rows_many, position_logits_for, relation_attend, relation_attend_batched,
                        relation_attention_forward, relation_project_batched, op_dtype, project_v)
 from .structures import BoxList, cat_boxlist, to_image_list
 from .synth import _cell_anchors
@@ -663,6 +663,89 @@ class MEGAFeatureExtractor(_Packed):
             z = [relation_attend(w, xc[t], qs[t], ks[t], vts[t]) for t in range(len(xs))]
         return (z, res[4]) if also_cat else z
 
+    # aggregate_batch, MEGA_EARLY_POS=1 (opt-in; same bits): the position logits of EVERY stage are computed at its start, on
+    # a side stream, instead of inside each stage in stream order.  Measured round 4: -0.3 % with one step-batch per block,
+    # -4 % with two (the VALU-bound position kernel beside the chain's GEMMs / attention slows those by as much as it hides,
+    # and the forked hipGraph branch adds cross-queue dependencies): off by default.
+    early_pos = os.environ.get("MEGA_EARLY_POS", "0") == "1"
+
+    def _early_position_logits(self, pk, frames, own, rois_cur01):
+        """The position logits of all stages of a step-batch, ahead of time.  They depend on boxes only -- the queries'
+        boxes and, per stage, the key set's [local window ; memory snapshot] boxes, all known when the batch starts -- while
+        the serial chain of a stage is projections -> attention -> FC.  The position kernel is VALU-bound (64 sin / cos per
+        pair; 1.1 of the aggregation's 5.3 ms per 20 key frames), the chain's other kernels are matrix-core- or
+        memory-bound: launched on a side stream at the start of the batch (forked from / joined to the current stream with
+        events, so a hipGraph capture records them as a parallel branch) they run beside update_lm, the projections and
+        the global attention instead of between them.
+        -> dict(tape=[boxes tape of memory pool i, as _push_memory_batch lays it out], pos=[per stage: list over own],
+                ev=[per stage: event to wait for before the attention], keep=...)."""
+        S = len(frames)
+        dev = frames[0]["x"].device
+        rois_ref, new_rois, tgroups, tidx = [], [], [], []
+        for i in range(self.stage):
+            n_push = self.base_num if i == 0 else self.advanced_num
+            rr = [f["rois"] if i == 0 else f["rois_dis"] for f in frames]
+            rois_ref.append(rr)
+            new_rois.append([r[:min(n_push, r.shape[0])] for r in rr])
+            if self.memory_enable:
+                have_old = len(self.mem_queue_list[i]["rois"]) > 0
+                tidx.append(len(tgroups))
+                tgroups.append(((([self.mem[i]["rois"]] if have_old else []) + new_rois[i]), 0))
+            else:
+                tidx.append(None)
+        tapes = ops.multi_cat(tgroups) if tgroups else []
+        tape = [None if j is None else tapes[j] for j in tidx]
+        rgroups, nk = [], []
+        for i in range(self.stage):
+            snaps = {}
+            if tape[i] is not None:       # the snapshot frame t reads: the live entries before its own push (:914-917)
+                q = self.mem_queue_list[i]["rois"]
+                cap, old = q.maxlen, [r.shape[0] for r in q]
+                off = [0]
+                for n in old + [r.shape[0] for r in new_rois[i]]:
+                    off.append(off[-1] + n)
+                for t in own:
+                    hi = len(old) + t
+                    if hi > 0:
+                        snaps[t] = tape[i][off[max(0, hi - cap)]:off[hi]]
+            pieces, n_i = [], {}
+            for t in own:
+                pieces.append(rois_ref[i][t])
+                n_i[t] = rois_ref[i][t].shape[0]
+                if t in snaps:
+                    pieces.append(snaps[t])
+                    n_i[t] += snaps[t].shape[0]
+            rgroups.append((pieces, 0))
+            nk.append(n_i)
+        r_flat = ops.multi_cat(rgroups)
+        side = None
+        if dev.type == "cuda" and not ops.profiling():
+            side = getattr(self, "_pos_stream", None)
+            if side is None or side.device != dev:
+                side = self._pos_stream = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+        pos, evs = [], []
+        for i in range(self.stage):
+            w = pk["local"][i]
+            if not w.with_pos:
+                pos.append(None)
+                evs.append(None)
+                continue
+            last = i == self.stage - 1
+            rq = [frames[t]["rois_key"] if last else rois_cur01[t] for t in own]
+            rk, o = [], 0
+            for t in own:
+                rk.append(r_flat[i][o:o + nk[i][t]])
+                o += nk[i][t]
+            with ops.launch_on(side):          # (buffers allocated under the current stream, kernels on the side stream)
+                pos.append(position_logits_for(w, rq, rk))
+            ev = None
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(side)
+            evs.append(ev)
+        return {"tape": tape, "pos": pos, "ev": evs, "nk": nk, "keep": (tapes, r_flat)}
+
     def _zero_cols(self, like, n):
         """[rows of like, n] zeros (n < 32), cut from one cached block: the pad columns between V^T blocks"""
         z = getattr(self, "_zpad", None)
@@ -758,6 +841,9 @@ class MEGAFeatureExtractor(_Packed):
             for t in own:
                 rois_cur01[t] = rc_all[o:o + nkey[t] + ndis[t]]
                 o += nkey[t] + ndis[t]
+        early = None
+        if self.early_pos and self.batched_attention and own:
+            early = self._early_position_logits(pk, frames, own, rois_cur01)
         for i in range(self.stage):
             last = i == self.stage - 1
             w = pk["local"][i]
@@ -785,7 +871,8 @@ class MEGAFeatureExtractor(_Packed):
                 else:
                     new_k = [ks[t][:n_ent[t]] for t in range(S)]
                     new_vt = [vts[t][:, :n_ent[t]] for t in range(S)]
-                snaps = self._push_memory_batch(i, [rois_ref[t][:n_ent[t]] for t in range(S)], new_k, new_vt)
+                snaps = self._push_memory_batch(i, [rois_ref[t][:n_ent[t]] for t in range(S)], new_k, new_vt,
+                                                tr=None if early is None else early["tape"][i])
             jobs = []
             if own:
                 # key sets [local window ; memory snapshot] of all own frames, assembled by three concatenations
@@ -802,18 +889,29 @@ class MEGAFeatureExtractor(_Packed):
                         vp.append(self._zero_cols(vts[t], ldv[t] - Nk[t]))
                 # (row blocks: one copy launch; the V^T column blocks are only 2-byte aligned -- 75 keys = 150 bytes --
                 # and stay with torch.cat's element-wise kernel)
-                k_flat, r_flat = ops.multi_cat([(kp, 0), (rp, 0)])
+                if early is None:
+                    k_flat, r_flat = ops.multi_cat([(kp, 0), (rp, 0)])
+                else:                    # (the boxes of the key sets were laid out, and used, before the stages)
+                    k_flat, r_flat = ops.multi_cat([(kp, 0)])[0], None
+                    assert all(early["nk"][i][t] == Nk[t] for t in own)
                 vt_flat = torch.cat(vp, dim=1)
                 ok = oc = 0
                 for t in own:
                     rc = frames[t]["rois_key"] if last else rois_cur01[t]
                     jobs.append({"x": feats_cur[t], "q": qs[t], "k_all": k_flat[ok:ok + Nk[t]],
                                  "vt_all": vt_flat[:, oc:oc + ldv[t]], "Nk": Nk[t], "rois_q": rc,
-                                 "rois_k": r_flat[ok:ok + Nk[t]]})
+                                 "rois_k": None if r_flat is None else r_flat[ok:ok + Nk[t]]})
                     ok += Nk[t]
                     oc += ldv[t]
             if self.batched_attention:
-                outs = dict(zip(own, relation_attend_batched(w, jobs)))
+                pos_i = None
+                if early is not None and early["pos"][i] is not None:
+                    pos_i = early["pos"][i]
+                    if early["ev"][i] is not None:          # join: the side stream's launch of this stage's logits
+                        torch.cuda.current_stream().wait_event(early["ev"][i])
+                outs = dict(zip(own, relation_attend_batched(w, jobs, pos=pos_i)))
+                if early is not None:
+                    early["pos"][i] = None                  # (frees the stage's logits as before: after its attention)
             else:
                 outs = dict(zip(own, [relation_attend_batched(w, [j])[0] for j in jobs]))
             if last:
@@ -836,19 +934,22 @@ class MEGAFeatureExtractor(_Packed):
                     xs[t] = z[j]
         return [xs.get(t) for t in range(S)]
 
-    def _push_memory_batch(self, i, new_rois, new_k, new_vt):
+    def _push_memory_batch(self, i, new_rois, new_k, new_vt, tr=None):
         """The pushes of S consecutive key frames into memory[i] (update_memory + _remember_kv, in frame order) as one
         tape: [live entries ; the S new entries] laid out by three concatenations.  Returns {t: snapshot} where
         snapshot = dict(rois, k, vt) views of the pool frame t READS (the live entries before its own push, :914-917;
         absent while the pool is empty).  The deques / self.mem[i] are left as S single pushes would leave them
-        (their tensors are views of the tape)."""
+        (their tensors are views of the tape).  tr: the boxes tape if it was laid out earlier."""
         q = self.mem_queue_list[i]
         cap = q["rois"].maxlen
         old = [r.shape[0] for r in q["rois"]]
         E0, S = len(old), len(new_rois)
         have_old = E0 > 0
-        tr, tk = ops.multi_cat([(([self.mem[i]["rois"]] if have_old else []) + list(new_rois), 0),
-                                (([self.mem[i]["k"]] if have_old else []) + list(new_k), 0)])
+        if tr is None:
+            tr, tk = ops.multi_cat([(([self.mem[i]["rois"]] if have_old else []) + list(new_rois), 0),
+                                    (([self.mem[i]["k"]] if have_old else []) + list(new_k), 0)])
+        else:      # the boxes tape already exists (_early_position_logits laid it out from the same pieces)
+            tk = ops.multi_cat([(([self.mem[i]["k"]] if have_old else []) + list(new_k), 0)])[0]
         tv = torch.cat(([self.mem[i]["vt"]] if have_old else []) + list(new_vt), dim=1)
         off = [0]
         for n in old + [r.shape[0] for r in new_rois]:

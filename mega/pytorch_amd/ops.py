@@ -4,7 +4,9 @@ torch is used here only for device memory and the current HIP stream; every comp
 hand-written gfx950 kernel in libmega_hip.so.  All wrappers raise if the library is missing, a
 tensor is not on a HIP device, or a kernel call returns non-zero -- there is no CPU fallback.
 """
+import contextlib
 import ctypes
+import threading
 import math
 
 import torch
@@ -22,8 +24,30 @@ def _dt(t):
         raise TypeError("unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
 
 
+_LAUNCH = threading.local()
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    s = getattr(_LAUNCH, "s", None)
+    return torch.cuda.current_stream().cuda_stream if s is None else s.cuda_stream
+
+
+@contextlib.contextmanager
+def launch_on(stream):
+    """Inside the block this module's kernels are launched on `stream` (a torch.cuda.Stream; None = no change) while
+    tensors are still ALLOCATED under torch's current stream: the way to run an op beside the current stream's work without
+    handing the caching allocator blocks that belong to another stream (the caller orders the two streams with events
+    and keeps the op's inputs alive until the streams have joined)."""
+    prev = getattr(_LAUNCH, "s", None)
+    _LAUNCH.s = stream if stream is not None else prev
+    try:
+        yield
+    finally:
+        _LAUNCH.s = prev
+
+
+def profiling():
+    return _PROF is not None
 
 
 def _gpu(*ts):

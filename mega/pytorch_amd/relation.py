@@ -233,12 +233,13 @@ def relation_attend(w, x, q, k, vt, rois_q=None, rois_k=None, mem_kv=None, resid
     return ops.relation_attention(q, k, vv, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
 
 
-def relation_attend_batched(w, jobs, residual=True):
+def relation_attend_batched(w, jobs, residual=True, pos=None):
     """relation_attend for several problems of the SAME weights (the key frames of a step-batch at one stage) with the
     position logits and the attention core each as ONE launch: jobs = list of dict(x, q, k, vt, rois_q, rois_k, mem_kv),
     or, with the key sets already assembled by the caller, dict(x, q, k_all [Nk,1024], vt_all [1024,>=ceil32(Nk)]
     (unit column stride, any row stride), Nk, rois_q, rois_k).  Same bits per problem as relation_attend.
-    The outputs are consecutive row blocks of one buffer (cat_rows() of them in order is free)."""
+    The outputs are consecutive row blocks of one buffer (cat_rows() of them in order is free).
+    pos: the problems' position logits if the caller already has them (position_logits_for)."""
     if not jobs:
         return []
     items, rq, rk = [], [], []
@@ -262,8 +263,16 @@ def relation_attend_batched(w, jobs, residual=True):
         rq.append(j.get("rois_q"))
         rk.append(j.get("rois_k"))
     if w.with_pos:
-        fast = w.wq.dtype != torch.float32
-        pos = ops.position_logits_batched(rq, rk, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
+        if pos is None:      # (else: computed ahead of time by position_logits_for, same call, same bits)
+            pos = position_logits_for(w, rq, rk)
         for it, p in zip(items, pos):
             it["pos"] = p
     return ops.relation_attention_batched(items)
+
+
+def position_logits_for(w, rois_qs, rois_ks):
+    """The position logits relation_attend_batched(w, jobs) computes for jobs with these query / key boxes (one launch per
+    20 problems in bf16 mode).  They depend on boxes only, so a caller that knows the key sets' boxes of a stage before its
+    features can compute them early, beside other work (MEGAFeatureExtractor.aggregate_batch does, on a side stream)."""
+    fast = w.wq.dtype != torch.float32
+    return ops.position_logits_batched(rois_qs, rois_ks, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)

@@ -39,11 +39,10 @@ def test_self_launch_reports_the_live_world_size():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["dry_run"] is True and line["steps"] == 20 and line["scaling"] == "weak"
     c = line["config"]
-    # a step = 2 key frames; a block = 40.  ONE step-batch of 40 key frames would leave nothing to overlap inside the
-    # synchronised block, so the default cuts it into two of 20 key frames = 40 frames, 20 per rank (the one-GPU [10, 10])
-    assert c["key_frames_per_step"] == 2 and c["key_frames_per_block"] == 40 and c["steps_per_batch"] == 20
-    assert c["batch_sizes_in_a_block"] == [20, 20]
-    assert c["frames_per_batch"] == 40 and c["frames_per_rank_per_batch"] == 20 and c["backend"] == "gloo"
+    # a step = 2 key frames; a block = 40; the default step-batch = 40 key frames = 80 frames, 40 per rank
+    assert c["key_frames_per_step"] == 2 and c["key_frames_per_block"] == 40 and c["steps_per_batch"] == 40
+    assert c["batch_sizes_in_a_block"] == [40]
+    assert c["frames_per_batch"] == 80 and c["frames_per_rank_per_batch"] == 40 and c["backend"] == "gloo"
 
 
 @pytest.mark.timeout(900)

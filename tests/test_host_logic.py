@@ -471,7 +471,7 @@ def test_bench_default_steps_per_batch():
     # is 20 key frames per rank whenever --steps is a multiple of 20 (a rank's frame-stage launch keeps its 40 frames)
     assert [kf(20, w) for w in (1, 2, 4, 8)] == [20, 40, 80, 160]
     assert [f(20, w) for w in (1, 2, 4, 8)] == [20, 40, 80, 160]
-    assert [f(100, w) for w in (1, 2, 8)] == [20, 40, 160]
+    assert [f(100, w) for w in (1, 2, 8)] == [20, 40, 160] and [f(60, w) for w in (1, 8)] == [20, 160]
     assert [f(48, w) for w in (1, 2, 4, 8)] == [16, 32, 64, 128]      # 48 = 3 x 16: 16 key frames per rank
     assert f(7, 1) == 7 and f(7, 2) == 14
     for steps in (5, 20, 48):
@@ -651,6 +651,9 @@ def test_static_batch_aggregation_equals_eager(monkeypatch):
         m._reset(200)
         models.append(m)
     a, b = models
+    # b also takes the opt-in early form of the position logits (all stages' logits from boxes tapes laid out before the
+    # stages, MEGAFeatureExtractor._early_position_logits): same values, same state
+    b.roi_heads.box.feature_extractor.early_pos = True
     kn, bn = a.key_num, a.base_num
     recs = [record(kn) for _ in range(60)]
     globs = [[record(bn)] for _ in range(60)]

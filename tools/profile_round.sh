@@ -34,9 +34,9 @@ timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-rooflin
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --aggregation batched-eager > $out/bench_n1_eager_aggregation.json 2> $out/bench_n1_eager_aggregation.err
 MEGA_FUSE_BOTTLENECK=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_unfused_layer1.json 2> $out/bench_n1_unfused_layer1.err
 MEGA_STEM_POOL=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_stem_pool_two_kernels.json 2> $out/bench_n1_stem_pool_two_kernels.err
-timeout 300 python bench.py --steps 20 --warmup 5 --steps-per-batch 20 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_one_batch_per_block.json 2> $out/bench_n1_one_batch_per_block.err
+timeout 300 python bench.py --steps 20 --warmup 5 --steps-per-batch 10 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_two_batches_per_block.json 2> $out/bench_n1_two_batches_per_block.err
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_driver_cli_again.json 2> $out/bench_n1_driver_cli_again.err
-for f in $out/bench_n1*.err; do echo "$(basename $f .err): $(grep -h "timed region:" $f | cut -c1-150)"; done | tee $out/ab_legs.txt
+for f in $out/bench_n1*.err; do echo "$(basename $f .err): $(grep -h "\] timed region:" $f | head -1 | cut -c1-150)"; done | tee $out/ab_legs.txt
 # kernel timeline of the steady state (per-kernel busy time of one step-batch: tools/trace_summary.py)
 bash tools/gpu/trace.sh $tag/trace > /dev/null 2>&1; python tools/trace_summary.py $out/trace/tail.csv > $out/trace_summary.txt 2>&1; head -3 $out/trace_summary.txt
 bash tools/gpu/trace_cli.sh $tag/trace_cli > /dev/null 2>&1; cp $out/trace_cli/cli_summary.txt $out/cli_block_timeline.txt; head -6 $out/cli_block_timeline.txt
