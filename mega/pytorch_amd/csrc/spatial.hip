@@ -509,7 +509,7 @@ __host__ __device__ constexpr int stem_group_off(int g) {   // LDS element offse
 // value = (float)byte - mean[c], the same f32 subtraction, then the same f32 -> bf16 conversion -- identical bits, a quarter
 // of the input bytes, no f32 image in HBM and no preprocess launch.
 template <bool U8>
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const void* __restrict__ in_, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(256, 4) void stem_mfma_kernel(const void* __restrict__ in_, const bf16_t* __restrict__ w,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                         int N, int H, int W, int Ho, int Wo, float m0, float m1, float m2,
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const void* __restrict__
   //  column past the 69 real ones, and 0 x whatever-LDS-held is NaN when that happens to be a NaN pattern)
   constexpr int NPL = (3 * SM_PH * SM_PS + 255) / 256, NWL = (64 * (SM_K / 8) + 255) / 256;
   float pv[NPL];
-  uint4 wv[NWL];
+  u32x4_t wv[NWL];      // (ext vector, not HIP's uint4 class: an array of those is placed in scratch memory)
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int e = tid + 256 * i;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const void* __restrict__
   for (int i = 0; i < NWL; ++i) {
     const int e = tid + 256 * i;
     const int row = e / (SM_K / 8), v = e - row * (SM_K / 8);
-    if (e < 64 * (SM_K / 8)) wv[i] = *reinterpret_cast<const uint4*>(w + row * SM_K + v * 8);
+    if (e < 64 * (SM_K / 8)) wv[i] = *reinterpret_cast<const u32x4_t*>(w + row * SM_K + v * 8);
   }
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const void* __restrict__
   for (int i = 0; i < NWL; ++i) {
     const int e = tid + 256 * i;
     const int row = e / (SM_K / 8), v = e - row * (SM_K / 8);
-    if (e < 64 * (SM_K / 8)) *reinterpret_cast<uint4*>(&wl[row * SM_WS + v * 8]) = wv[i];
+    if (e < 64 * (SM_K / 8)) *reinterpret_cast<u32x4_t*>(&wl[row * SM_WS + v * 8]) = wv[i];
   }
   __syncthreads();
 
@@ -649,7 +649,7 @@ __host__ __device__ constexpr int sp_group_off(int g) {
 }
 
 template <bool U8>
-__global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__ in_, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void stem_pool_kernel(const void* __restrict__ in_, const bf16_t* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
                                                         bf16_t* __restrict__ out, int N, int H, int W, int Ho, int Wo, int Hp,
                                                         int Wp, float m0, float m1, float m2, int to_bgr) {
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__
   const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
   constexpr int NPL = (3 * SP_PH * SP_PS + 255) / 256, NWL = (64 * (SM_K / 8) + 255) / 256;
   float pv[NPL];
-  uint4 wv[NWL];
+  u32x4_t wv[NWL];      // (ext vector, not HIP's uint4 class: an array of those is placed in scratch memory)
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int e = tid + 256 * i;
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__
   for (int i = 0; i < NWL; ++i) {
     const int e = tid + 256 * i;
     const int row = e / (SM_K / 8), v = e - row * (SM_K / 8);
-    if (e < 64 * (SM_K / 8)) wv[i] = *reinterpret_cast<const uint4*>(w + row * SM_K + v * 8);
+    if (e < 64 * (SM_K / 8)) wv[i] = *reinterpret_cast<const u32x4_t*>(w + row * SM_K + v * 8);
   }
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__
   for (int i = 0; i < NWL; ++i) {
     const int e = tid + 256 * i;
     const int row = e / (SM_K / 8), v = e - row * (SM_K / 8);
-    if (e < 64 * (SM_K / 8)) *reinterpret_cast<uint4*>(&wl[row * SM_WS + v * 8]) = wv[i];
+    if (e < 64 * (SM_K / 8)) *reinterpret_cast<u32x4_t*>(&wl[row * SM_WS + v * 8]) = wv[i];
   }
   __syncthreads();
 
