@@ -582,7 +582,8 @@ def main():
         conv = lambda f: f.startswith("igemm")      # noqa: E731
         hbm_entry("igemm8 streaming class (1x1 layers with K <= 512: layer3 conv3, res5 conv3, layer2 / layer3 projections)",
                   lambda f, d_: f.startswith("igemm8s_"))
-        hbm_entry("stem 7x7/2 conv + BN + ReLU", lambda f, d_: f == "stem")
+        hbm_entry("stem: 7x7/2 conv + BN + ReLU + 3x3/2 max-pool in one kernel (uint8 frames in, pooled map out)"
+                  if os.environ.get("MEGA_STEM_POOL", "1") != "0" else "stem 7x7/2 conv + BN + ReLU", lambda f, d_: f == "stem")
         hbm_entry("max-pool 3x3/2", lambda f, d_: f == "maxpool")
         hbm_entry("layer1 convs (Cin or Cout = 64)", lambda f, d_: conv(f) and shape_of(d_) is not None
                   and (shape_of(d_)[2] in (64, 576) or shape_of(d_)[1] == 64))
