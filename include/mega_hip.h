@@ -292,6 +292,12 @@ typedef struct {
   int ldq, ldk, ldv, ldp, ldr, ldo, Nq, Nk;
   int io_f32;      /* != 0 with dtype bf16: resid and out are f32 rows (the head's f32 activation stream, cfg.HEAD_STREAM:
                     * x + attention is never rounded to bf16 between the stages of roi_box_feature_extractors.py:806-829) */
+  int nk1;         /* keys 0 .. nk1-1 come from (k, vt), keys nk1 .. Nk-1 from (k2, vt2): the [local window ; memory] key set of a
+                    * MEGA stage (roi_box_feature_extractors.py:676,:687-688,:812-814 concatenate it per key frame) read in
+                    * place.  0 or Nk: one segment, k2 / vt2 ignored.  Same keys in the same order: same bits. */
+  const void* k2;  /* [Nk - nk1][ldk] */
+  const void* vt2; /* [groups*64][ldv2]; its columns may start at any element (2-byte) address */
+  int ldv2;
   int reserved;
 } mega_attn_desc;
 int mega_relation_attention_batched(const void* descs /* mega_attn_desc[n], host memory */, int n, int groups,

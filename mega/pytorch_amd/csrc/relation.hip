@@ -342,21 +342,24 @@ template <> struct Mma32<float> {
 //  compiled to two conversions + shift + or)
 
 struct AttnParams {
-  const void* Q; int ldq;     // [Nq][ldq], head h in columns h*64 .. h*64+63  (u already folded in)
-  const void* K; int ldk;     // [Nk][ldk]
-  const void* Vt; int ldv;    // [G*64][ldv]  row h*64+dv, column = key (V already projected by Wv)
-  const float* pos; int ldp;  // [G][Nq][ldp] additive logits or null
+  const void* Q;              // [Nq][ldq], head h in columns h*64 .. h*64+63  (u already folded in)
+  const void* K;              // [N1][ldk]   keys 0 .. N1-1
+  const void* Vt;             // [G*64][ldv]  row h*64+dv, column = key (V already projected by Wv), keys 0 .. N1-1
+  const void* K2;             // [Nk-N1][ldk]  keys N1 .. Nk-1 (second segment; unused when N1 == Nk)
+  const void* Vt2;            // [G*64][ldv2]  keys N1 .. Nk-1; its columns may start at any 2-byte (bf16) / 4-byte (f32) address
+  const float* pos;           // [G][Nq][ldp] additive logits or null
   const bf16_t* pos_t;        // or: bf16 logits in tile order [G][ceil(Nk/32)][Nq][32] (see pos_logits_mfma_kernel)
-  const void* resid; int ldr; // [Nq][ldr] residual (feats_cur) or null
+  const void* resid;          // [Nq][ldr] residual (feats_cur) or null
   const float* bias_v;        // [G*64] or null
-  void* out; int ldo;         // [Nq][ldo]
-  int Nq, Nk, G;
+  void* out;                  // [Nq][ldo]
+  float* part_o;              // [nsplit][Nq][G*64] un-normalised partial outputs (nsplit > 1)
+  float* part_ml;             // [nsplit][2][G][Nq]   running max / sum of each partial
+  int ldq, ldk, ldv, ldv2, ldp, ldr, ldo;
+  int Nq, Nk, N1, G;
   float scale;
   int nsplit, tiles_per_split;
   int vmask_always;           // experiments: mask the V^T tail in every tile (the pre-round-3 form) instead of the last one
   int io_f32;                 // resid / out are f32 rows whatever T is (the head's f32 activation stream in bf16 mode)
-  float* part_o;              // [nsplit][Nq][G*64] un-normalised partial outputs (nsplit > 1)
-  float* part_ml;             // [nsplit][2][G][Nq]   running max / sum of each partial
 };
 
 template <typename T, bool POS_TILED>
@@ -375,10 +378,18 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
   const int head = blockIdx.y;
   const int qw0 = blockIdx.x * 128 + wave * 32;  // first query row of this wave
   const T* __restrict__ Qp = (const T*)p.Q;
+  // Keys 0 .. N1-1 live in (K, Vt), keys N1 .. Nk-1 in (K2, Vt2): the [local window ; memory snapshot] key set of a MEGA
+  // stage is read where its two parts already are (the projections' output, the memory tape) instead of being copied into
+  // one buffer per key frame.  N1 == Nk: one segment.  Nothing about the arithmetic changes: same keys, same order.
+  const int N1 = p.N1;
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.K), 0, (int)((unsigned)p.Nk * (unsigned)p.ldk * (unsigned)sizeof(T)), 0x00020000);
+      const_cast<void*>(p.K), 0, (int)((unsigned)N1 * (unsigned)p.ldk * (unsigned)sizeof(T)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.Vt), 0, (int)((unsigned)(p.G * 64) * (unsigned)p.ldv * (unsigned)sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_k2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.K2), 0, (int)((unsigned)(p.Nk - N1) * (unsigned)p.ldk * (unsigned)sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.Vt2), 0, (int)((unsigned)(p.G * 64) * (unsigned)p.ldv2 * (unsigned)sizeof(T)), 0x00020000);
 
   // ---- Q fragments (B operand of S^T = K Q^T): row q = qw0 + l31, vector v at bytes v*32 + h2*16
   const int q_ld = min(qw0 + l31, p.Nq - 1);
@@ -391,22 +402,58 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
 
   // ---- cooperative tile loads (global -> registers), two register sets = two tiles in flight
   auto load_tiles = [&](int k0, uint4 (&kreg)[NLD], uint4 (&vreg)[NLD]) {
+    // which segment(s) the 32 keys of this tile come from (k0 is wave-uniform: scalar branches)
+    const bool in1 = k0 + 32 <= N1, in2 = k0 >= N1;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
-      // branch-free buffer loads: lanes past Nk use offset 0xFFFFFFFF, which the range check turns into zeros
+      // branch-free buffer loads: lanes past the end use offset 0xFFFFFFFF, which the range check turns into zeros
       {  // K tile: 32 keys x 64 d
         const int row = idx / KV_PER_ROW, vec = idx - row * KV_PER_ROW;
         const int key = k0 + row;
-        const unsigned off = ((unsigned)key * (unsigned)p.ldk + (unsigned)(head * 64 + vec * VE)) * (unsigned)sizeof(T);
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_k, key < p.Nk ? off : 0xFFFFFFFFu, 0, 0);
+        const unsigned col = (unsigned)(head * 64 + vec * VE);
+        const unsigned off1 = ((unsigned)key * (unsigned)p.ldk + col) * (unsigned)sizeof(T);
+        const unsigned off2 = ((unsigned)(key - N1) * (unsigned)p.ldk + col) * (unsigned)sizeof(T);
+        u32x4_t v;
+        if (in1) {
+          v = __builtin_amdgcn_raw_buffer_load_b128(rs_k, key < N1 ? off1 : 0xFFFFFFFFu, 0, 0);
+        } else if (in2) {
+          v = __builtin_amdgcn_raw_buffer_load_b128(rs_k2, key < p.Nk ? off2 : 0xFFFFFFFFu, 0, 0);
+        } else {          // the tile with the seam: a row is in exactly one segment, the other load returns zeros
+          const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rs_k, key < N1 ? off1 : 0xFFFFFFFFu, 0, 0);
+          const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rs_k2, key >= N1 && key < p.Nk ? off2 : 0xFFFFFFFFu, 0, 0);
+          v = a | b;
+        }
         kreg[i] = make_uint4(v.x, v.y, v.z, v.w);
       }
       {  // V^T tile: 64 dv x 32 keys
         const int row = idx / VV_PER_ROW, vec = idx - row * VV_PER_ROW;
         const int key = k0 + vec * VE;
-        const unsigned off = ((unsigned)(head * 64 + row) * (unsigned)p.ldv + (unsigned)key) * (unsigned)sizeof(T);
-        const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(rs_v, key < p.Nk ? off : 0xFFFFFFFFu, 0, 0);
+        const unsigned off1 = ((unsigned)(head * 64 + row) * (unsigned)p.ldv + (unsigned)key) * (unsigned)sizeof(T);
+        const unsigned off2 = ((unsigned)(head * 64 + row) * (unsigned)p.ldv2 + (unsigned)(key - N1)) * (unsigned)sizeof(T);
+        u32x4_t r;
+        if (in1) {
+          r = __builtin_amdgcn_raw_buffer_load_b128(rs_v, key < N1 ? off1 : 0xFFFFFFFFu, 0, 0);
+        } else if (in2) {       // (16-byte loads at element alignment: gfx950 serves them, tools/probes/unaligned_load.hip)
+          r = __builtin_amdgcn_raw_buffer_load_b128(rs_v2, key < p.Nk ? off2 : 0xFFFFFFFFu, 0, 0);
+        } else {
+          // the tile with the seam: whole vectors from either side as above; the one vector per row that straddles it is
+          // assembled element by element
+          const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rs_v, key + VE <= N1 ? off1 : 0xFFFFFFFFu, 0, 0);
+          const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rs_v2, key >= N1 && key < p.Nk ? off2 : 0xFFFFFFFFu, 0, 0);
+          r = a | b;
+          if (key < N1 && key + VE > N1) {
+            T e[VE];
+#pragma unroll
+            for (int t = 0; t < VE; ++t) {
+              const int kk = key + t;
+              const T* src = kk < N1 ? (const T*)p.Vt + (size_t)(head * 64 + row) * p.ldv + kk
+                                     : (const T*)p.Vt2 + (size_t)(head * 64 + row) * p.ldv2 + (kk - N1);
+              e[t] = kk < p.Nk ? *src : (T)0;
+            }
+            r = *reinterpret_cast<const u32x4_t*>(e);
+          }
+        }
         uint4 v = make_uint4(r.x, r.y, r.z, r.w);
         if (p.vmask_always || k0 + 32 > p.Nk) {   // only a tile that reaches past Nk has tail keys (wave-uniform branch):
           T* e = reinterpret_cast<T*>(&v);         // zero them (pad columns of Vt are not guaranteed finite)
@@ -667,8 +714,8 @@ struct AttnBatch {
 };
 static_assert(sizeof(AttnBatch) <= 4096, "AttnBatch travels as the kernel argument");
 
-// MINB = blocks per CU the register allocation aims at: 2 (174 VGPRs) or 3 (168 VGPRs; the tiled-position variant then
-// spills 6 dwords) -- an A/B pair, selected by MEGA_ATTN_OCC3 until one of them is measured to win.
+// MINB = blocks per CU the register allocation aims at: 2 or 3 (<= 168 VGPRs: three waves per SIMD; default since the
+// second key segment, see mega_relation_attention_batched; MEGA_ATTN_OCC3=0 selects the 2-block bound).
 template <typename T, bool POS_TILED, int MINB>
 __global__ __launch_bounds__(256, MINB) void attn_batched_kernel(AttnBatch b) {
   const int z = blockIdx.z;
@@ -788,12 +835,17 @@ extern "C" size_t mega_relation_attention_workspace_bytes(int Nq, int Nk, int gr
 static int attn_fill(AttnParams& p, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
                      const float* pos, int ldp, const void* pos_tiled, const void* resid, int ldr, const float* bias_v,
                      void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype, void* ws, size_t ws_bytes,
-                     int io_f32 = 0) {
+                     int io_f32 = 0, int nk1 = 0, const void* k2 = nullptr, const void* vt2 = nullptr, int ldv2 = 0) {
   if (!q || !k || !vt || !out || Nq <= 0 || Nk <= 0 || groups <= 0) return MEGA_ERR_ARG;
+  // second key segment: keys nk1 .. Nk-1 from (k2, vt2); nk1 == 0 or nk1 == Nk: one segment
+  if (nk1 < 0 || nk1 > Nk) return MEGA_ERR_ARG;
+  if (nk1 == 0 || nk1 == Nk) { nk1 = Nk; k2 = k; vt2 = vt; ldv2 = ldv; }
+  else if (!k2 || !vt2 || ldv2 < Nk - nk1) return MEGA_ERR_ARG;
+  p.N1 = nk1; p.K2 = k2; p.Vt2 = vt2; p.ldv2 = ldv2;
   p.io_f32 = (io_f32 != 0 && dtype != MEGA_F32) ? 1 : 0;   // (f32 mode: T is float already)
   const int ve = dtype == MEGA_BF16 ? 8 : 4;
   if (ldq % ve || ldk % ve || ldv % ve || (pos && (ldp % 32 || ldp < Nk))) return MEGA_ERR_ARG;
-  if (ldv < ((Nk + ve - 1) / ve) * ve) return MEGA_ERR_ARG;
+  if (ldv < (nk1 == Nk ? ((Nk + ve - 1) / ve) * ve : nk1)) return MEGA_ERR_ARG;
   if (pos_tiled && (pos || dtype != MEGA_BF16 || (reinterpret_cast<size_t>(pos_tiled) & 15))) return MEGA_ERR_ARG;
   p.pos_t = (const bf16_t*)pos_tiled;
   p.Q = q; p.ldq = ldq; p.K = k; p.ldk = ldk; p.Vt = vt; p.ldv = ldv; p.pos = pos; p.ldp = ldp;
@@ -846,7 +898,8 @@ struct MegaAttnDescC {
   const void* q; const void* k; const void* vt; const float* pos; const void* pos_tiled; const void* resid;
   const float* bias_v; void* out; void* ws; size_t ws_bytes;
   int ldq, ldk, ldv, ldp, ldr, ldo, Nq, Nk;
-  int io_f32, reserved;
+  int io_f32, nk1;
+  const void* k2; const void* vt2; int ldv2, reserved;
 };
 
 extern "C" int mega_relation_attention_batched(const void* descs, int n, int groups, float scale, int dtype,
@@ -864,7 +917,8 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
     if ((d[i].pos_tiled != nullptr) != tiled) return MEGA_ERR_ARG;
     const int rc = attn_fill(b.p[i], d[i].q, d[i].ldq, d[i].k, d[i].ldk, d[i].vt, d[i].ldv, d[i].pos, d[i].ldp,
                              d[i].pos_tiled, d[i].resid, d[i].ldr, d[i].bias_v, d[i].out, d[i].ldo, d[i].Nq, d[i].Nk,
-                             groups, scale, dtype, d[i].ws, d[i].ws_bytes, d[i].io_f32);
+                             groups, scale, dtype, d[i].ws, d[i].ws_bytes, d[i].io_f32, d[i].nk1, d[i].k2, d[i].vt2,
+                             d[i].ldv2);
     if (rc != MEGA_OK) return rc;
     if (nz + b.p[i].nsplit > ATTN_MAXZ) return MEGA_ERR_ARG;
     for (int s2 = 0; s2 < b.p[i].nsplit; ++s2) { b.zprob[nz] = (unsigned char)i; b.zsplit[nz] = (unsigned char)s2; ++nz; }
@@ -876,7 +930,9 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
   b.nz = nz;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(max_q, 128), groups, nz);
-  static const bool occ3 = getenv("MEGA_ATTN_OCC3") != nullptr && getenv("MEGA_ATTN_OCC3")[0] == '1';
+  // (three blocks per CU: with the second key segment the tiled-position variant needs 170 VGPRs under a 2-block bound -- two
+  //  over the 168 that still fit three waves per SIMD -- and exactly 168, without spills, under a 3-block bound)
+  static const bool occ3 = !(getenv("MEGA_ATTN_OCC3") != nullptr && getenv("MEGA_ATTN_OCC3")[0] == '0');
   if (dtype == MEGA_BF16 && tiled && occ3) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, true, 3>), grid, dim3(256), 0, st, b);
   else if (dtype == MEGA_BF16 && tiled) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, true, 2>), grid, dim3(256), 0, st, b);
   else if (dtype == MEGA_BF16 && occ3) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, false, 3>), grid, dim3(256), 0, st, b);

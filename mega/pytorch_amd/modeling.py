@@ -663,6 +663,9 @@ class MEGAFeatureExtractor(_Packed):
             z = [relation_attend(w, xc[t], qs[t], ks[t], vts[t]) for t in range(len(xs))]
         return (z, res[4]) if also_cat else z
 
+    # aggregate_batch: the attention kernel reads a stage's key set [local window ; memory snapshot] as two segments where
+    # they lie (MEGA_ATTN_SEGMENTS=0: copied into one K / V^T buffer per key frame first -- the A/B switch; same bits)
+    attn_segments = os.environ.get("MEGA_ATTN_SEGMENTS", "1") != "0"
     # aggregate_batch, MEGA_EARLY_POS=1 (opt-in; same bits): the position logits of EVERY stage are computed at its start, on
     # a side stream, instead of inside each stage in stream order.  Measured round 4: -0.3 % with one step-batch per block,
     # -4 % with two (the VALU-bound position kernel beside the chain's GEMMs / attention slows those by as much as it hides,
@@ -875,8 +878,9 @@ class MEGAFeatureExtractor(_Packed):
                                                 tr=None if early is None else early["tape"][i])
             jobs = []
             if own:
-                # key sets [local window ; memory snapshot] of all own frames, assembled by three concatenations
+                # key sets [local window ; memory snapshot] of all own frames
                 kp, vp, rp, Nk, ldv = [], [], [], {}, {}
+                segments = self.attn_segments and self.batched_attention and all(t in snaps for t in own)
                 for t in own:
                     m = snaps.get(t)
                     kp.append(ks[t]); vp.append(vts[t]); rp.append(rois_ref[t])
@@ -887,22 +891,36 @@ class MEGAFeatureExtractor(_Packed):
                     ldv[t] = (Nk[t] + 31) // 32 * 32
                     if ldv[t] > Nk[t]:
                         vp.append(self._zero_cols(vts[t], ldv[t] - Nk[t]))
-                # (row blocks: one copy launch; the V^T column blocks are only 2-byte aligned -- 75 keys = 150 bytes --
-                # and stay with torch.cat's element-wise kernel)
+                r_flat = None
                 if early is None:
-                    k_flat, r_flat = ops.multi_cat([(kp, 0), (rp, 0)])
+                    r_flat = ops.multi_cat([(rp, 0)])[0]
                 else:                    # (the boxes of the key sets were laid out, and used, before the stages)
-                    k_flat, r_flat = ops.multi_cat([(kp, 0)])[0], None
                     assert all(early["nk"][i][t] == Nk[t] for t in own)
-                vt_flat = torch.cat(vp, dim=1)
-                ok = oc = 0
-                for t in own:
-                    rc = frames[t]["rois_key"] if last else rois_cur01[t]
-                    jobs.append({"x": feats_cur[t], "q": qs[t], "k_all": k_flat[ok:ok + Nk[t]],
-                                 "vt_all": vt_flat[:, oc:oc + ldv[t]], "Nk": Nk[t], "rois_q": rc,
-                                 "rois_k": None if r_flat is None else r_flat[ok:ok + Nk[t]]})
-                    ok += Nk[t]
-                    oc += ldv[t]
+                if segments:
+                    # the attention kernel reads both parts where they lie -- the projections' output (ks / vts) and the
+                    # memory tape (the snapshot's row / column range) -- as two key segments: no K / V^T copies at all
+                    # (they were 0.3 ms per 20 key frames: 155 MB each way at stage 0)
+                    ok = 0
+                    for t in own:
+                        rc = frames[t]["rois_key"] if last else rois_cur01[t]
+                        m = snaps[t]
+                        jobs.append({"x": feats_cur[t], "q": qs[t], "k": ks[t], "vt": vts[t], "N1": ks[t].shape[0],
+                                     "k2": m["k"], "vt2": m["vt"], "Nk": Nk[t], "rois_q": rc,
+                                     "rois_k": None if r_flat is None else r_flat[ok:ok + Nk[t]]})
+                        ok += Nk[t]
+                else:
+                    # assembled by concatenation (row blocks: one copy launch; the V^T column blocks are only 2-byte
+                    # aligned -- 75 keys = 150 bytes -- and stay with torch.cat's element-wise kernel)
+                    k_flat = ops.multi_cat([(kp, 0)])[0]
+                    vt_flat = torch.cat(vp, dim=1)
+                    ok = oc = 0
+                    for t in own:
+                        rc = frames[t]["rois_key"] if last else rois_cur01[t]
+                        jobs.append({"x": feats_cur[t], "q": qs[t], "k_all": k_flat[ok:ok + Nk[t]],
+                                     "vt_all": vt_flat[:, oc:oc + ldv[t]], "Nk": Nk[t], "rois_q": rc,
+                                     "rois_k": None if r_flat is None else r_flat[ok:ok + Nk[t]]})
+                        ok += Nk[t]
+                        oc += ldv[t]
             if self.batched_attention:
                 pos_i = None
                 if early is not None and early["pos"][i] is not None:

@@ -536,7 +536,8 @@ def _even_chunks(n, cap):
 class _AttnDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("q", "k", "vt", "pos", "pos_tiled", "resid", "bias_v", "out", "ws")] + \
                [("ws_bytes", ctypes.c_size_t)] + \
-               [(n, ctypes.c_int) for n in ("ldq", "ldk", "ldv", "ldp", "ldr", "ldo", "Nq", "Nk", "io_f32", "reserved")]
+               [(n, ctypes.c_int) for n in ("ldq", "ldk", "ldv", "ldp", "ldr", "ldo", "Nq", "Nk", "io_f32", "nk1")] + \
+               [("k2", ctypes.c_void_p), ("vt2", ctypes.c_void_p), ("ldv2", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
 class _PosDesc(ctypes.Structure):
@@ -598,9 +599,15 @@ def relation_attention_batched(items, groups=16):
             assert t_ is None or (t_.dtype in (dt, sdt) and t_.stride(1) == 1 and t_.data_ptr() % 16 == 0 and
                                   (t_.stride(0) * t_.element_size()) % 16 == 0)
         assert q.dtype == k.dtype == vt.dtype == dt
-        # vt: [G*64, >= ceil32(Nk)] with unit column stride; a column block of a wider matrix is fine (16-B aligned)
-        assert vt.stride(1) == 1 and vt.shape[1] >= (it["Nk"] + 31) // 32 * 32 and vt.data_ptr() % 16 == 0 and \
-            (vt.stride(0) * vt.element_size()) % 16 == 0
+        # vt: [G*64, >= ceil32(Nk)] with unit column stride; a column block of a wider matrix is fine (16-B aligned).
+        # With a second key segment (k2 / vt2 / N1) the blocks are read in place at element alignment: no such constraint.
+        if it.get("k2") is None:
+            assert vt.stride(1) == 1 and vt.shape[1] >= (it["Nk"] + 31) // 32 * 32 and vt.data_ptr() % 16 == 0 and \
+                (vt.stride(0) * vt.element_size()) % 16 == 0
+            assert k.shape[0] >= it["Nk"]
+        else:
+            _gpu(it["k2"], it["vt2"])
+            assert it["k2"].data_ptr() % 16 == 0 and (vt.stride(0) * vt.element_size()) % 16 == 0
         assert (pos is None) == (items[0].get("pos") is None) and (pos is None or pos.dtype == items[0]["pos"].dtype)
         outs.append(out_all[o:o + q.shape[0]])
         o += q.shape[0]
@@ -617,6 +624,13 @@ def relation_attention_batched(items, groups=16):
             Nq, Nk = q.shape[0], it["Nk"]
             d.q, d.k, d.vt, d.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), outs[o + i].data_ptr()
             d.ldq, d.ldk, d.ldv, d.ldo, d.Nq, d.Nk = q.stride(0), k.stride(0), vt.stride(0), groups * 64, Nq, Nk
+            k2, vt2 = it.get("k2"), it.get("vt2")
+            if k2 is not None:          # second key segment (keys N1 .. Nk-1), read where it lies
+                N1 = it["N1"]
+                assert 0 < N1 < Nk and k.shape[0] >= N1 and k2.shape[0] == Nk - N1 and vt2.shape[1] >= Nk - N1
+                assert k2.dtype == k.dtype and vt2.dtype == vt.dtype and k2.stride(0) == k.stride(0)
+                assert k2.stride(1) == 1 and vt2.stride(1) == 1 and vt.shape[1] >= N1
+                d.nk1, d.k2, d.vt2, d.ldv2 = N1, k2.data_ptr(), vt2.data_ptr(), vt2.stride(0)
             d.resid, d.ldr = _ptr(resid), 0 if resid is None else resid.stride(0)
             d.io_f32 = io_f32
             d.bias_v = _ptr(it.get("bias_v"))

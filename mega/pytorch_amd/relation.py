@@ -237,14 +237,20 @@ def relation_attend_batched(w, jobs, residual=True, pos=None):
     """relation_attend for several problems of the SAME weights (the key frames of a step-batch at one stage) with the
     position logits and the attention core each as ONE launch: jobs = list of dict(x, q, k, vt, rois_q, rois_k, mem_kv),
     or, with the key sets already assembled by the caller, dict(x, q, k_all [Nk,1024], vt_all [1024,>=ceil32(Nk)]
-    (unit column stride, any row stride), Nk, rois_q, rois_k).  Same bits per problem as relation_attend.
+    (unit column stride, any row stride), Nk, rois_q, rois_k), or in two segments that are read where they lie:
+    dict(x, q, k [N1,1024], vt [1024,>=N1], k2 [Nk-N1,1024], vt2 [1024,>=Nk-N1], N1, Nk, rois_q, rois_k).
+    Same bits per problem as relation_attend.
     The outputs are consecutive row blocks of one buffer (cat_rows() of them in order is free).
     pos: the problems' position logits if the caller already has them (position_logits_for)."""
     if not jobs:
         return []
     items, rq, rk = [], [], []
     for j in jobs:
-        if "k_all" in j:
+        seg = None
+        if "k2" in j:          # two key segments read in place: (k, vt) keys 0 .. N1-1, (k2, vt2) keys N1 .. Nk-1
+            k, vv, Nk = j["k"], j["vt"], j["Nk"]
+            seg = {"k2": j["k2"], "vt2": j["vt2"], "N1": j["N1"]}
+        elif "k_all" in j:
             k, vv, Nk = j["k_all"], j["vt_all"], j["Nk"]
         else:
             k, vt = j["k"], j["vt"]
@@ -260,6 +266,8 @@ def relation_attend_batched(w, jobs, residual=True, pos=None):
                 vparts.append(vt.new_zeros((vt.shape[0], ldv - Nk)))
             vv = torch.cat(vparts, dim=1) if len(vparts) > 1 else vt.contiguous()
         items.append({"q": j["q"], "k": k, "vt": vv, "Nk": Nk, "resid": j["x"] if residual else None, "bias_v": w.bv})
+        if seg is not None:
+            items[-1].update(seg)
         rq.append(j.get("rois_q"))
         rk.append(j.get("rois_k"))
     if w.with_pos:

@@ -170,8 +170,16 @@ def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, t
 
 
 def relation_attention_batched(items, groups=16):
-    return [relation_attention(it["q"], it["k"], it["vt"], it["Nk"], pos=it.get("pos"), resid=it.get("resid"),
-                               bias_v=it.get("bias_v"), groups=groups) for it in items]
+    outs = []
+    for it in items:
+        k, vt = it["k"], it["vt"]
+        if it.get("k2") is not None:        # second key segment: keys N1 .. Nk-1 (the kernel reads both in place)
+            N1 = it["N1"]
+            k = torch.cat([k[:N1], it["k2"]], dim=0)
+            vt = torch.cat([vt[:, :N1], it["vt2"][:, :it["Nk"] - N1]], dim=1)
+        outs.append(relation_attention(it["q"], k, vt, it["Nk"], pos=it.get("pos"), resid=it.get("resid"),
+                                       bias_v=it.get("bias_v"), groups=groups))
+    return outs
 
 
 import contextlib

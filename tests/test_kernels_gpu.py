@@ -776,6 +776,57 @@ def test_relation_attention_f32_stream(dev, shape):
     assert torch.equal(both[0], out) and torch.equal(both[1], out)
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
+@pytest.mark.parametrize("shape", [(300, 1875, 1875), (675, 1875, 1800), (130, 75, 150), (64, 37, 5), (200, 96, 64),
+                                   (90, 1, 40), (33, 250, 1)])
+def test_attention_two_key_segments_bit_equal(dev, dtype, shape):
+    """mega_attn_desc.nk1 / k2 / vt2: keys 0 .. N1-1 read from (k, vt), keys N1 .. Nk-1 from (k2, vt2) -- column / row blocks
+    of wider buffers at ELEMENT alignment (what MEGAFeatureExtractor.aggregate_batch hands over: the projections' output
+    and the memory tape) -- against the same keys copied into one K / V^T buffer: the same bits, for seams inside a tile,
+    inside a 16-byte vector, at tile boundaries, for one-key segments, with and without the tile-ordered position logits."""
+    ops = _ops()
+    dt = getattr(torch, dtype)
+    Nq, N1, N2 = shape
+    Nk = N1 + N2
+    g = torch.Generator().manual_seed(N1 * 3 + N2)
+    q = (torch.randn((Nq, 1024), generator=g) * 0.3).to(dt).to(dev)
+    kfull = (torch.randn((Nk, 1024), generator=g) * 0.3).to(dt)
+    vfull = (torch.randn((1024, Nk), generator=g) + 0.5).to(dt)
+    resid = (torch.randn((Nq, 1024), generator=g)).to(dt).to(dev)
+    bv = (torch.randn((1024,), generator=g) * 0.1).to(dev)
+    ld = (Nk + 31) // 32 * 32
+    vt = torch.zeros((1024, ld), dtype=dt)
+    vt[:, :Nk] = vfull
+    rq = torch.rand((Nq, 4), generator=g) * 100
+    rq[:, 2:] += rq[:, :2] + 5
+    rk = torch.rand((Nk, 4), generator=g) * 100
+    rk[:, 2:] += rk[:, :2] + 5
+    wg = torch.randn((64, 16), generator=g) * 0.3
+    bg = torch.randn((16,), generator=g) * 0.1 + 0.3
+    dim_mat = torch.full((8,), 1000.0).pow(torch.arange(8) / 8.0)
+    fast = dt == torch.bfloat16
+    pos = ops.position_logits(rq.to(dev), rk.to(dev), wg.to(dev), bg.to(dev), dim_mat.to(dev), precise=not fast, tiled=fast)
+    # the two segments inside wider buffers at odd element offsets (3 and 5 columns in, rows after 2 other rows)
+    a_cols, b_cols = 3, 5
+    big1 = torch.full((1024, (a_cols + N1 + 9 + 7) // 8 * 8), 7.0, dtype=dt)     # (first segment: 16-byte row pitch, any column)
+    big1[:, a_cols:a_cols + N1] = vfull[:, :N1]
+    big2 = torch.full((1024, b_cols + N2 + 11), -3.0, dtype=dt)
+    big2[:, b_cols:b_cols + N2] = vfull[:, N1:]
+    kb1 = torch.zeros((2 + N1 + 1, 1024), dtype=dt)
+    kb1[2:2 + N1] = kfull[:N1]
+    kb2 = torch.zeros((1 + N2 + 3, 1024), dtype=dt)
+    kb2[1:1 + N2] = kfull[N1:]
+    big1, big2, kb1, kb2 = big1.to(dev), big2.to(dev), kb1.to(dev), kb2.to(dev)
+    for p_ in (None, pos):
+        one = ops.relation_attention_batched([{"q": q, "k": kfull.to(dev), "vt": vt.to(dev), "Nk": Nk, "resid": resid,
+                                               "bias_v": bv, "pos": p_}])[0]
+        two = ops.relation_attention_batched([{"q": q, "k": kb1[2:2 + N1], "vt": big1[:, a_cols:a_cols + N1], "N1": N1,
+                                               "k2": kb2[1:1 + N2], "vt2": big2[:, b_cols:b_cols + N2], "Nk": Nk,
+                                               "resid": resid, "bias_v": bv, "pos": p_}])[0]
+        assert torch.equal(one, two), (dtype, shape, p_ is not None, (one.float() - two.float()).abs().max().item())
+    assert torch.isfinite(one.float()).all()
+
+
 def test_attention_row_sum_uses_the_rounded_p(dev):
     """bf16 mode: softmax weights are rounded to bf16 for the PV MFMA and the row sum is taken over the ROUNDED values,
     so the output is an exact weighted mean of the values: with every value row equal to a constant c the output is c to
