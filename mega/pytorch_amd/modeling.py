@@ -854,10 +854,17 @@ class MEGAFeatureExtractor(_Packed):
             rois_ref = [f["rois"] if i == 0 else f["rois_dis"] for f in frames]
             n_ent = [min(n_push, r.shape[0]) for r in rois_ref]           # rows of each frame's memory entry
             qs, ks, vts = {}, {}, {}
+            # will every own frame read a memory snapshot (then the attention takes its key set as two segments)?  Frame t's
+            # snapshot is the pool before its own push: empty only for the first frame of a video's first batch
+            seg_ok = (self.attn_segments and self.batched_attention and self.memory_enable and bool(own)
+                      and (len(self.mem_queue_list[i]["rois"]) > 0 or 0 not in own))
             if own:
-                q_, k_, v_ = relation_project_batched(w, [feats_cur[t] for t in own], [feats_ref[t] for t in own])
+                # (segments: every frame's key rows are followed by zero rows up to a multiple of 32, so its V^T block starts
+                #  at a 32-aligned column of the GEMM's output -- the first segment's loads stay 16-byte aligned)
+                q_, k_, v_ = relation_project_batched(w, [feats_cur[t] for t in own], [feats_ref[t] for t in own],
+                                                      pad_refs=seg_ok)
                 for j, t in enumerate(own):
-                    qs[t], ks[t], vts[t] = q_[j], k_[j], v_[j]
+                    qs[t], ks[t], vts[t] = q_[j], k_[j], v_[j][:, :k_[j].shape[0]]
             snaps = {}
             if self.memory_enable:
                 if shard is not None:
@@ -880,7 +887,8 @@ class MEGAFeatureExtractor(_Packed):
             if own:
                 # key sets [local window ; memory snapshot] of all own frames
                 kp, vp, rp, Nk, ldv = [], [], [], {}, {}
-                segments = self.attn_segments and self.batched_attention and all(t in snaps for t in own)
+                segments = seg_ok and all(t in snaps for t in own)
+                assert segments == seg_ok
                 for t in own:
                     m = snaps.get(t)
                     kp.append(ks[t]); vp.append(vts[t]); rp.append(rois_ref[t])
