@@ -362,7 +362,7 @@ struct AttnParams {
   int io_f32;                 // resid / out are f32 rows whatever T is (the head's f32 activation stream in bf16 mode)
 };
 
-template <typename T, bool POS_TILED>
+template <typename T, bool POS_TILED, bool SEG>
 __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) {
   using C = AttnCfg<T>;
   constexpr int VE = 16 / (int)sizeof(T);
@@ -381,7 +381,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
   // Keys 0 .. N1-1 live in (K, Vt), keys N1 .. Nk-1 in (K2, Vt2): the [local window ; memory snapshot] key set of a MEGA
   // stage is read where its two parts already are (the projections' output, the memory tape) instead of being copied into
   // one buffer per key frame.  N1 == Nk: one segment.  Nothing about the arithmetic changes: same keys, same order.
-  const int N1 = p.N1;
+  const int N1 = SEG ? p.N1 : p.Nk;      // (SEG = false: the one-segment build, no seam code in the tile loop)
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.K), 0, (int)((unsigned)N1 * (unsigned)p.ldk * (unsigned)sizeof(T)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(
@@ -403,7 +403,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
   // ---- cooperative tile loads (global -> registers), two register sets = two tiles in flight
   auto load_tiles = [&](int k0, uint4 (&kreg)[NLD], uint4 (&vreg)[NLD]) {
     // which segment(s) the 32 keys of this tile come from (k0 is wave-uniform: scalar branches)
-    const bool in1 = k0 + 32 <= N1, in2 = k0 >= N1;
+    const bool in1 = !SEG || k0 + 32 <= N1, in2 = SEG && k0 >= N1;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
@@ -417,6 +417,8 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
         u32x4_t v;
         if (in1) {
           v = __builtin_amdgcn_raw_buffer_load_b128(rs_k, key < N1 ? off1 : 0xFFFFFFFFu, 0, 0);
+        } else if (!SEG) {
+          v = u32x4_t{0, 0, 0, 0};
         } else if (in2) {
           v = __builtin_amdgcn_raw_buffer_load_b128(rs_k2, key < p.Nk ? off2 : 0xFFFFFFFFu, 0, 0);
         } else {          // the tile with the seam: a row is in exactly one segment, the other load returns zeros
@@ -434,6 +436,8 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
         u32x4_t r;
         if (in1) {
           r = __builtin_amdgcn_raw_buffer_load_b128(rs_v, key < N1 ? off1 : 0xFFFFFFFFu, 0, 0);
+        } else if (!SEG) {
+          r = u32x4_t{0, 0, 0, 0};
         } else if (in2) {       // (16-byte loads at element alignment: gfx950 serves them, tools/probes/unaligned_load.hip)
           r = __builtin_amdgcn_raw_buffer_load_b128(rs_v2, key < p.Nk ? off2 : 0xFFFFFFFFu, 0, 0);
         } else {
@@ -698,7 +702,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
 
 template <typename T, bool POS_TILED>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
-  attn_body<T, POS_TILED>(p, (int)blockIdx.z);
+  attn_body<T, POS_TILED, false>(p, (int)blockIdx.z);
 }
 
 // Several independent attention problems (the key frames of one engine step-batch at the same stage) in ONE launch:
@@ -716,12 +720,12 @@ static_assert(sizeof(AttnBatch) <= 4096, "AttnBatch travels as the kernel argume
 
 // MINB = blocks per CU the register allocation aims at: 2 or 3 (<= 168 VGPRs: three waves per SIMD; default since the
 // second key segment, see mega_relation_attention_batched; MEGA_ATTN_OCC3=0 selects the 2-block bound).
-template <typename T, bool POS_TILED, int MINB>
+template <typename T, bool POS_TILED, int MINB, bool SEG>
 __global__ __launch_bounds__(256, MINB) void attn_batched_kernel(AttnBatch b) {
   const int z = blockIdx.z;
   const AttnParams& p = b.p[b.zprob[z]];
   if ((int)blockIdx.x * 128 >= p.Nq) return;          // (block-uniform: the grid is sized for the largest problem)
-  attn_body<T, POS_TILED>(p, (int)b.zsplit[z]);
+  attn_body<T, POS_TILED, SEG>(p, (int)b.zsplit[z]);
 }
 
 // out[q][c] = resid + bias + (sum_s e^{m_s - M} O_s[q][c]) / (sum_s e^{m_s - M} l_s),  M = max_s m_s  (head = c / 64)
@@ -910,7 +914,7 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
   const MegaAttnDescC* d = (const MegaAttnDescC*)descs;
   AttnBatch b;                 // by-value kernel argument (~2.5 KB)
   b.n = n;
-  int nz = 0, max_q = 0, any_split = 0;
+  int nz = 0, max_q = 0, any_split = 0, any_seg = 0;
   size_t max_total = 0;
   const bool tiled = d[0].pos_tiled != nullptr;
   for (int i = 0; i < n; ++i) {
@@ -924,6 +928,7 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
     for (int s2 = 0; s2 < b.p[i].nsplit; ++s2) { b.zprob[nz] = (unsigned char)i; b.zsplit[nz] = (unsigned char)s2; ++nz; }
     max_q = d[i].Nq > max_q ? d[i].Nq : max_q;
     any_split |= b.p[i].nsplit > 1;
+    any_seg |= b.p[i].N1 != b.p[i].Nk;
     const size_t total = (size_t)d[i].Nq * groups * 64;
     max_total = total > max_total ? total : max_total;
   }
@@ -932,12 +937,25 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
   dim3 grid(cdiv(max_q, 128), groups, nz);
   // (three blocks per CU: with the second key segment the tiled-position variant needs 170 VGPRs under a 2-block bound -- two
   //  over the 168 that still fit three waves per SIMD -- and exactly 168, without spills, under a 3-block bound)
-  static const bool occ3 = !(getenv("MEGA_ATTN_OCC3") != nullptr && getenv("MEGA_ATTN_OCC3")[0] == '0');
-  if (dtype == MEGA_BF16 && tiled && occ3) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, true, 3>), grid, dim3(256), 0, st, b);
-  else if (dtype == MEGA_BF16 && tiled) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, true, 2>), grid, dim3(256), 0, st, b);
-  else if (dtype == MEGA_BF16 && occ3) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, false, 3>), grid, dim3(256), 0, st, b);
-  else if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_batched_kernel<bf16_t, false, 2>), grid, dim3(256), 0, st, b);
-  else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_batched_kernel<float, false, 2>), grid, dim3(256), 0, st, b);
+  // Builds: SEG = some problem of the launch has a second key segment (the seam code costs the one-segment launches 5 %:
+  // they keep their own build); MINB = blocks per CU the register allocation aims at -- the two-segment tiled-position
+  // variant needs 170 VGPRs under a 2-block bound, two over the 168 that still fit three waves per SIMD, and exactly 168,
+  // without spills, under a 3-block bound (886 against 1020 us at stage 0); every other variant fits 166 under the 2-block
+  // bound and is 4 % faster that way.  MEGA_ATTN_OCC3 = 0 / 1 forces the bound for all variants (A/B).
+  static const int occ_env = getenv("MEGA_ATTN_OCC3") == nullptr ? -1 : (getenv("MEGA_ATTN_OCC3")[0] == '1' ? 1 : 0);
+  const bool occ3 = occ_env >= 0 ? occ_env == 1 : (any_seg && tiled);
+#define MEGA_ATTN_LAUNCH(T, TILED)                                                                                   \
+  do {                                                                                                               \
+    if (any_seg && occ3) hipLaunchKernelGGL((attn_batched_kernel<T, TILED, 3, true>), grid, dim3(256), 0, st, b);    \
+    else if (any_seg) hipLaunchKernelGGL((attn_batched_kernel<T, TILED, 2, true>), grid, dim3(256), 0, st, b);       \
+    else if (occ3) hipLaunchKernelGGL((attn_batched_kernel<T, TILED, 3, false>), grid, dim3(256), 0, st, b);         \
+    else hipLaunchKernelGGL((attn_batched_kernel<T, TILED, 2, false>), grid, dim3(256), 0, st, b);                   \
+  } while (0)
+  if (dtype == MEGA_BF16 && tiled) MEGA_ATTN_LAUNCH(bf16_t, true);
+  else if (dtype == MEGA_BF16) MEGA_ATTN_LAUNCH(bf16_t, false);
+  else if (dtype == MEGA_F32 && any_seg) hipLaunchKernelGGL((attn_batched_kernel<float, false, 2, true>), grid, dim3(256), 0, st, b);
+  else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_batched_kernel<float, false, 2, false>), grid, dim3(256), 0, st, b);
+#undef MEGA_ATTN_LAUNCH      // (f32: 192 / 211 VGPRs, two blocks per CU either way; a 3-block bound would spill)
   else return MEGA_ERR_ARG;
   if (any_split) {
     const int blocks = (int)((max_total + 255) / 256 > 4096 ? 4096 : (max_total + 255) / 256);
