@@ -9,8 +9,10 @@
 //
 // A segment is a [rows][row_bytes] byte block with independent source / destination row strides, so both row
 // concatenation (dim 0) and column concatenation (dim 1: the key-contiguous V^T blocks, whose 150-byte rows are only
-// 2-byte aligned) are the same thing.  The copy width (16 / 8 / 4 / 2 bytes per thread) is the largest that divides
-// every segment's addresses, strides and row length; pure data movement, bit-exact by construction.
+// 2-byte aligned) are the same thing.  Since the end of round 4 all segments of a call go out in ONE launch of
+// copy_any_kernel (16-byte units at whatever alignment a segment has); the per-width form before it (MEGA_COPY_ANY=0: one
+// launch per copy width 16 / 8 / 4 / 2 bytes, the largest that divides a segment's addresses, strides and row length) is
+// kept for A/B.  Pure data movement, bit-exact by construction.
 #include "common.h"
 
 namespace {
@@ -22,6 +24,7 @@ struct CopySeg {
   unsigned char* dst;
   long long src_stride, dst_stride;   // bytes
   int rows, units_per_row;            // units of W bytes
+  int row_bytes, reserved;            // (copy_any_kernel: units of 16 bytes, the last one of a row may be shorter)
 };
 struct CopyBatch {
   int n;
@@ -43,6 +46,35 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(CopyBatch b) {
     const unsigned r = u / (unsigned)s.units_per_row, c = u - r * (unsigned)s.units_per_row;
     *reinterpret_cast<V*>(s.dst + (long long)r * s.dst_stride + (size_t)c * sizeof(V)) =
         *reinterpret_cast<const V*>(s.src + (long long)r * s.src_stride + (size_t)c * sizeof(V));
+  }
+}
+
+// The same for ANY element-aligned geometry in one launch: a row is cut into 16-byte units from its first byte, whatever
+// the addresses -- gfx950 serves 16-byte global loads AND stores at 2-byte-aligned addresses correctly, at ~90 % of the
+// aligned rate (tools/probes/unaligned_load.hip) -- and the last unit of a row carries its remaining bytes in 2-byte (and at
+// most one 1-byte) pieces.  Round 4: before this, every copy width that occurred in a call was its own launch, and the
+// 150-byte V^T column blocks of the memory tapes (75 keys) went through torch.cat's element-wise kernel.
+__global__ __launch_bounds__(256) void copy_any_kernel(CopyBatch b) {
+  const unsigned total = b.ubase[b.n];
+  for (unsigned unit = blockIdx.x * 256u + threadIdx.x; unit < total; unit += gridDim.x * 256u) {
+    int lo = 0, hi = b.n;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (b.ubase[mid] <= unit) lo = mid; else hi = mid;
+    }
+    const CopySeg& s = b.s[lo];
+    const unsigned u = unit - b.ubase[lo];
+    const unsigned r = u / (unsigned)s.units_per_row, c = u - r * (unsigned)s.units_per_row;
+    const unsigned char* sp = s.src + (long long)r * s.src_stride + (size_t)c * 16;
+    unsigned char* dp = s.dst + (long long)r * s.dst_stride + (size_t)c * 16;
+    const int nb = s.row_bytes - (int)c * 16;
+    if (nb >= 16) {
+      *reinterpret_cast<u32x4_t*>(dp) = *reinterpret_cast<const u32x4_t*>(sp);
+    } else {
+      int i = 0;
+      for (; i + 2 <= nb; i += 2) *reinterpret_cast<unsigned short*>(dp + i) = *reinterpret_cast<const unsigned short*>(sp + i);
+      if (i < nb) dp[i] = sp[i];
+    }
   }
 }
 
@@ -208,10 +240,46 @@ extern "C" int mega_copy_segments(const void* segs, int n, void* stream) {
   for (int i = 0; i < n; ++i) {
     const MegaCopySegC& g = d[i];
     if (g.rows < 0 || g.row_bytes < 0 || (g.rows > 0 && g.row_bytes > 0 && (!g.src || !g.dst))) return MEGA_ERR_ARG;
-    if (g.rows > 0 && g.row_bytes > 0 && seg_align(g) < 2) return MEGA_ERR_ARG;   // (bf16 / f32 / i32 data: >= 2 bytes)
+    if (g.rows > 0 && g.row_bytes > 0 && seg_align(g) < 2 && getenv("MEGA_COPY_ANY") != nullptr && getenv("MEGA_COPY_ANY")[0] == '0')
+      return MEGA_ERR_ARG;   // (the per-width form: bf16 / f32 / i32 data, >= 2 bytes)
   }
-  // one launch per copy width that occurs (a 2-byte-aligned V^T column block must not drag the 16-byte-aligned row
-  // blocks of the same call down to 2 bytes per thread), in groups of COPY_MAXSEG segments
+  static const bool any_form = !(getenv("MEGA_COPY_ANY") != nullptr && getenv("MEGA_COPY_ANY")[0] == '0');
+  if (any_form) {
+    // all segments in one launch (groups of COPY_MAXSEG), 16-byte units at whatever alignment the segment has
+    CopyBatch b;
+    b.n = 0;
+    unsigned long long units = 0;
+    auto flush = [&]() {
+      if (b.n == 0) return;
+      b.ubase[b.n] = (unsigned)units;
+      unsigned long long nb = (units + 1023) / 1024;        // ~4 units per thread
+      if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(copy_any_kernel, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, st, b);
+      b.n = 0;
+      units = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      const MegaCopySegC& g = d[i];
+      if (g.rows == 0 || g.row_bytes == 0) continue;
+      if (g.row_bytes >= (1ll << 31)) return MEGA_ERR_ARG;
+      const unsigned long long upr = (unsigned long long)(g.row_bytes + 15) / 16;
+      const unsigned long long u = (unsigned long long)g.rows * upr;
+      if (u >= 0xFFFFFFFFull) return MEGA_ERR_ARG;
+      if (b.n == COPY_MAXSEG || units + u >= 0xFFFFFFFFull) flush();
+      CopySeg& sg = b.s[b.n];
+      sg.src = (const unsigned char*)g.src; sg.dst = (unsigned char*)g.dst;
+      sg.src_stride = g.src_stride; sg.dst_stride = g.dst_stride;
+      sg.rows = g.rows; sg.units_per_row = (int)upr; sg.row_bytes = (int)g.row_bytes; sg.reserved = 0;
+      b.ubase[b.n] = (unsigned)units;
+      units += u;
+      ++b.n;
+    }
+    flush();
+    return mega_check_launch();
+  }
+  // (MEGA_COPY_ANY=0, the form before round 4's end) one launch per copy width that occurs (a 2-byte-aligned V^T column
+  // block must not drag the 16-byte-aligned row blocks of the same call down to 2 bytes per thread), in groups of
+  // COPY_MAXSEG segments
   for (unsigned long long align = 16; align >= 2; align >>= 1) {
     CopyBatch b;
     b.n = 0;

@@ -917,10 +917,9 @@ class MEGAFeatureExtractor(_Packed):
                                      "rois_k": None if r_flat is None else r_flat[ok:ok + Nk[t]]})
                         ok += Nk[t]
                 else:
-                    # assembled by concatenation (row blocks: one copy launch; the V^T column blocks are only 2-byte
-                    # aligned -- 75 keys = 150 bytes -- and stay with torch.cat's element-wise kernel)
+                    # assembled by concatenation
                     k_flat = ops.multi_cat([(kp, 0)])[0]
-                    vt_flat = torch.cat(vp, dim=1)
+                    vt_flat = ops.multi_cat([(vp, 1)])[0]
                     ok = oc = 0
                     for t in own:
                         rc = frames[t]["rois_key"] if last else rois_cur01[t]
@@ -971,12 +970,14 @@ class MEGAFeatureExtractor(_Packed):
         old = [r.shape[0] for r in q["rois"]]
         E0, S = len(old), len(new_rois)
         have_old = E0 > 0
+        # (one launch for all three tapes: the copy kernel takes any alignment, so the 150-byte V^T column blocks ride along)
+        groups = [(([self.mem[i]["k"]] if have_old else []) + list(new_k), 0),
+                  (([self.mem[i]["vt"]] if have_old else []) + list(new_vt), 1)]
         if tr is None:
-            tr, tk = ops.multi_cat([(([self.mem[i]["rois"]] if have_old else []) + list(new_rois), 0),
-                                    (([self.mem[i]["k"]] if have_old else []) + list(new_k), 0)])
+            groups.append(((([self.mem[i]["rois"]] if have_old else []) + list(new_rois)), 0))
+            tk, tv, tr = ops.multi_cat(groups)
         else:      # the boxes tape already exists (_early_position_logits laid it out from the same pieces)
-            tk = ops.multi_cat([(([self.mem[i]["k"]] if have_old else []) + list(new_k), 0)])[0]
-        tv = torch.cat(([self.mem[i]["vt"]] if have_old else []) + list(new_vt), dim=1)
+            tk, tv = ops.multi_cat(groups)
         off = [0]
         for n in old + [r.shape[0] for r in new_rois]:
             off.append(off[-1] + n)

@@ -694,6 +694,22 @@ def test_multi_cat_equals_torch_cat(dev):
     ref[:, 10:85] = vt[:64, 100:175]
     ref[:, 85:86] = vt[:64, 7:8]
     assert torch.equal(dst, ref)
+    # round 4 (copy_any_kernel): any geometry in one launch -- odd byte counts, byte tensors, rows shorter than one unit,
+    # 2-byte-aligned sources AND destinations, nothing written outside the destination blocks
+    u8 = torch.randint(0, 256, (37, 1001), generator=g, dtype=torch.uint8).to(dev)
+    d8 = torch.full((37, 1200), 7, dtype=torch.uint8, device=dev)
+    d16 = torch.full((1024, 500), -1.0, dtype=torch.bfloat16, device=dev)
+    d32 = torch.full((50, 9), -2.0, device=dev)
+    ops.copy_blocks([(d8[:, 3:1004], u8), (d16[:, 1:76], vt[:, 75:150]), (d16[:, 77:80], vt[:, 1001:1004]),
+                     (d16[:, 301:490], vt[:, 2001:2190]), (d32[:, 2:3], boxes[100:150, 1:2]), (d32[:, 4:8], boxes[200:250])])
+    r8, r16, r32 = torch.full_like(d8, 7), torch.full_like(d16, -1.0), torch.full_like(d32, -2.0)
+    r8[:, 3:1004] = u8
+    r16[:, 1:76] = vt[:, 75:150]
+    r16[:, 77:80] = vt[:, 1001:1004]
+    r16[:, 301:490] = vt[:, 2001:2190]
+    r32[:, 2:3] = boxes[100:150, 1:2]
+    r32[:, 4:8] = boxes[200:250]
+    assert torch.equal(d8, r8) and torch.equal(d16.view(torch.int16), r16.view(torch.int16)) and torch.equal(d32, r32)
 
 
 @pytest.mark.parametrize("shape", [(2, 150, 250), (5, 70, 90), (3, 151, 249), (40, 33, 47)])

@@ -27,6 +27,11 @@ __global__ void bw(const unsigned short* __restrict__ src, u32x4_t* __restrict__
   if (acc.x == 0x12345678u) out[0] = acc;
 }
 
+__global__ void probe_store(const u32x4_t* __restrict__ src, unsigned short* __restrict__ dst, int shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(dst) + (size_t)i * 16 + shift * 2) = src[i];
+}
+
 int main() {
   const int N = 1 << 16;                 // vectors
   std::vector<unsigned short> h((size_t)N * 8 + 64);
@@ -42,6 +47,20 @@ int main() {
     size_t bad_b = 0, bad_g = 0;
     for (size_t i = 0; i < (size_t)N * 8; ++i) { bad_b += rb[i] != h[i + shift]; bad_g += rg[i] != h[i + shift]; }
     printf("shift %d elements (%2d bytes): buffer_load_b128 wrong %zu, global_load_b128 wrong %zu of %d\n", shift, shift * 2, bad_b, bad_g, N * 8);
+  }
+  {  // 16-byte stores at 2-byte-aligned addresses
+    unsigned short* dd; hipMalloc(&dd, (size_t)N * 16 + 64);
+    std::vector<unsigned short> back((size_t)N * 8 + 32);
+    for (int shift = 0; shift < 8; ++shift) {
+      hipMemset(dd, 0xEE, (size_t)N * 16 + 64);
+      hipLaunchKernelGGL(probe_store, dim3(N / 256), dim3(256), 0, 0, (const u32x4_t*)d, dd, shift);
+      hipMemcpy(back.data(), dd, (size_t)N * 16 + 64, hipMemcpyDeviceToHost);
+      size_t bad = 0;
+      for (size_t i = 0; i < (size_t)N * 8; ++i) bad += back[i + shift] != h[i];
+      for (int i = 0; i < shift; ++i) bad += back[i] != 0xEEEE;
+      bad += back[(size_t)N * 8 + shift] != 0xEEEE;
+      printf("store shift %d elements: wrong %zu\n", shift, bad);
+    }
   }
   // bandwidth: 256 MB
   const size_t NV = (size_t)16 << 20;
