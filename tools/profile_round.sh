@@ -34,7 +34,7 @@ timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-rooflin
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --aggregation batched-eager > $out/bench_n1_eager_aggregation.json 2> $out/bench_n1_eager_aggregation.err
 MEGA_FUSE_BOTTLENECK=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_unfused_layer1.json 2> $out/bench_n1_unfused_layer1.err
 MEGA_ATTN_SEGMENTS=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_copied_key_sets.json 2> $out/bench_n1_copied_key_sets.err
-MEGA_L3_SPLIT=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_layer3_whole_batch.json 2> $out/bench_n1_layer3_whole_batch.err
+MEGA_L3_SPLIT=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_layer3_in_two_halves.json 2> $out/bench_n1_layer3_in_two_halves.err
 MEGA_STEM_POOL=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_stem_pool_two_kernels.json 2> $out/bench_n1_stem_pool_two_kernels.err
 timeout 300 python bench.py --steps 20 --warmup 5 --steps-per-batch 10 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_two_batches_per_block.json 2> $out/bench_n1_two_batches_per_block.err
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_driver_cli_again.json 2> $out/bench_n1_driver_cli_again.err
