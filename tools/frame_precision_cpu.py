@@ -7,6 +7,8 @@ arithmetic on bf16-rounded operands, outputs rounded to the dtype the HIP kernel
   bb16+rpn32     bf16 backbone, RPN head (3x3 conv + logits / deltas) in f32 on the bf16 C4 map
   bb32+rpn16     f32 backbone, C4 rounded to bf16 once, RPN head in bf16
   bb16+t32       bf16 backbone and bf16 RPN conv operands, but the conv's OUTPUT t kept f32 into the 1x1 logits (f32 weights)
+  res11 / res15  everything bf16 EXCEPT the backbone's residual stream, carried with 11 / 15 mantissa bits (bf16 has 7): the
+                 conv inputs are its bf16 rounding, the residual add reads / writes the wide value (a 4-bit / 8-bit remainder plane)
 -> agreement of the 300 kept anchor indices with f32 (as sets, and of the first 75 = the reference-role rows).
 
   MEGA_STEM_POOL=0 python tools/frame_precision_cpu.py [--frames 0,5,11] [--threads 16]
@@ -76,6 +78,32 @@ def main():
                            rpn.nms_thresh, rpn.min_size, W, H, rpn.strict_gt, want_index=True)
         return r[3][0, :int(r[2][0])].tolist(), out
 
+    def round_bits(v, bits):
+        """f32 -> nearest value with `bits` mantissa bits (round to nearest even on the dropped bits)"""
+        i = v.contiguous().view(torch.int32)
+        drop = 23 - bits
+        r = ((i >> drop) & 1) + ((1 << (drop - 1)) - 1)
+        return (((i + r) >> drop) << drop).view(torch.float32)
+
+    def backbone_wide(img, bits):
+        """the bf16 backbone with the RESIDUAL stream carried at `bits` mantissa bits (bf16 = 7): conv inputs are the bf16
+        rounding of the stream, the residual add reads and writes the wide value (a bf16 plane + a remainder plane)"""
+        body = m16.backbone.body
+        y = body.stem.run(img.float().contiguous(), torch.bfloat16).float()     # (the stem's output is bf16 either way)
+        for name in body.stages:
+            for blk in getattr(body, name):
+                pk = blk._packed(torch.bfloat16, y.device)
+                x16 = y.to(torch.bfloat16)
+                ident = y
+                if blk.downsample is not None:
+                    ident = round_bits(ops.conv2d_nhwc(x16, pk["wd"], pk["sd"], pk["bd"], stride=blk.down_stride,
+                                                       out_dtype=torch.float32), bits)
+                t = ops.conv2d_nhwc(x16, pk["w1"], pk["s1"], pk["b1"], stride=blk.stride, relu=True)
+                t = ops.conv2d_nhwc(t, pk["w2"], pk["s2"], pk["b2"], pad=blk.dilation, dil=blk.dilation, relu=True)
+                o = ops.conv2d_nhwc(t, pk["w3"], pk["s3"], pk["b3"], out_dtype=torch.float32)
+                y = round_bits(torch.relu(o + ident), bits)
+        return y                                                               # NHWC f32 (wide)
+
     res = {}
     for f in [int(x) for x in a.frames.split(",")]:
         t0 = time.time()
@@ -90,8 +118,13 @@ def main():
                     "bb16+rpn32": select(m32, n16.float())[0],
                     "bb32+rpn16": select(m16, n32.to(torch.bfloat16))[0],
                     "bb16+t32": select(m16, n16, t32=True)[0]}
+            for bits in (11, 15):
+                nw = backbone_wide(img, bits)
+                rows["res%d" % bits] = select(m16, nw.to(torch.bfloat16))[0]
+                if bits == 15:
+                    relw = ((nw - n32).abs().mean() / n32.abs().mean()).item()
         rel = ((n16.float() - n32).abs().mean() / n32.abs().mean()).item()
-        line = "frame %2d (%.0fs): C4 bf16 mean |err| / mean |x| = %.2e;" % (f, time.time() - t0, rel)
+        line = "frame %2d (%.0fs): C4 mean |err| / mean |x|: bf16 %.2e, 15-bit residual stream %.2e;" % (f, time.time() - t0, rel, relw)
         for k, v in rows.items():
             agree = len(set(v) & set(ref)) / max(len(ref), 1)
             a75 = len(set(v[:75]) & set(ref[:75])) / 75.0
