@@ -274,6 +274,29 @@ int mega_bottleneck64_ds_fwd(const void* x, const void* w1, const float* s1, con
  * stage FCs of the aggregation head (roi_box_feature_extractors.py:826-827) when the activation stream is f32. */
 int mega_split_f32_to_bf16x3(const float* src, void* dst_bf16, int rows, int K, void* stream);
 
+/* ---- split-precision activation PLANES (round 5): the parity mode of the frame stage at bf16 matrix-core rates, and the
+ * wide residual stream of the bf16 mode.  The reference computes these layers in fp32 (mega_core/config/defaults.py:541;
+ * backbone/resnet.py:324-344 `out += identity`, rpn/rpn.py:99-106, roi_box_feature_extractors.py:894,:907).  An f32
+ * activation x [M][C] lives in HBM as bf16 [M][2C] = [hi | lo], hi = bf16(x), lo = bf16(x - hi): x = hi + lo to ~2^-17. */
+
+/* dst [rows][2K] bf16 = [hi | lo] of src [rows][K] f32 (K % 8 == 0, both 16-byte aligned). */
+int mega_split_f32_to_planes(const float* src, void* dst_bf16, int rows, int K, void* stream);
+
+/* conv + FrozenBN (+ split residual) + activation on plane tensors, bf16 matrix cores, f32 accumulation (igemm8 SP kernels):
+ *   in       bf16 [N][H][W][ldi]; the contraction runs over Cin channels per tap, SOURCE channel k < kwrap ? k : k - kwrap
+ *            (kwrap = 0: no wrap).  Split precision: ldi = 2C, Cin = 3C, kwrap = 2C reads [hi | lo | hi]; with weights
+ *            packed [Wh | Wh | Wl] per tap ([Cout][R][S][3C]) the contraction is x_hi.Wh + x_lo.Wh + x_hi.Wl = x.W to ~2^-16.
+ *            bf16 compute on a wide residual stream: ldi = 2C, Cin = C, kwrap = 0, plain weights (only hi is read).
+ *   residual split planes [M][ldr] (ldr >= 2 Cout; 0 = 2 Cout) or NULL: hi + lo is added in f32 before the activation
+ *   out_mode 0: bf16 [M][ldo];  1: split planes [M][ldo] (ldo >= 2 Cout);  2: f32 [M][ldo]     (ldo 0 = the natural width)
+ *   relu     0 none, 1 ReLU, 2 LeakyReLU(0.1)
+ * Cin % 64 == 0, kwrap % 64 == 0, Cout % 8 == 0, every tensor below 2 GiB (MEGA_ERR_ARG otherwise).  ws / ws_bytes: the
+ * split-K workspace of mega_conv2d_nhwc_workspace_bytes(M, Cout, R S Cin) (long-K layers: f32 output without residual). */
+int mega_conv2d_nhwc_sp(const void* in, int ldi, int kwrap, const void* w, const float* scale, const float* bias,
+                        const void* residual, int ldr, void* out, int ldo, int out_mode, int N, int H, int W, int Cin,
+                        int Cout, int R, int S, int stride, int pad, int dil, int relu, void* ws, size_t ws_bytes,
+                        void* stream);
+
 /* mega_copy_segments with an f32 -> bf16 conversion on the way (source blocks f32, destination blocks bf16; row_bytes =
  * SOURCE bytes per row, a multiple of 32; 16-byte aligned on both sides): a concatenation of f32 row blocks delivered as the
  * rounded copy the bf16 projections read (roi_box_feature_extractors.py:812-814 pools with an f32 activation stream). */

@@ -82,6 +82,13 @@ def _mega_cfg(r50):
         # to bf16 and the stage FCs / predictor run in exact-f32 MFMA (logits within ~1e-4 of the f32 path);
         # "bfloat16": every hand-off rounds (the round-3 behaviour, ~2 % faster, logit error median 1.7e-3)
         "HEAD_STREAM": "float32",
+        # float32 mode only: "exact" = exact-f32 MFMA convolutions (157 TF/s roof); "bf16x3" = split-precision frame stage:
+        # activations as [hi | lo] bf16 planes, every conv / fc0 as ONE bf16 matrix-core GEMM over K x 3
+        # ([hi | lo | hi] . [Wh | Wh | Wl], f32 accumulation: x.W to ~2^-16) -- the parity mode at matrix-core rates
+        "F32_CONV": "exact",
+        # bfloat16 mode only: "bfloat16" = the residual trunk is a bf16 tensor (rounded at each of the 36 `out += identity`,
+        # resnet.py:324-344); "planes" = the trunk is carried as [hi | lo] planes and added in f32 (modeling.conv_mode "wide")
+        "RESIDUAL_STREAM": "bfloat16",
         "INPUT": {"MIN_SIZE_TEST": 600, "MAX_SIZE_TEST": 1000,
                   "PIXEL_MEAN": [102.9801, 115.9465, 122.7717], "PIXEL_STD": [1.0, 1.0, 1.0], "TO_BGR255": True},
         "MODEL": {

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void copy_cast_segments_kernel(CopyBatch b) {
 // f32 row [K] -> bf16 row [3K] = [hi | lo | hi], hi = bf16(v), lo = bf16(v - hi): with the weight rows laid out
 // [Wh | Wh | Wl] a plain bf16 GEMM over 3K computes hi.Wh + lo.Wh + hi.Wl = v.W to ~2^-16 (f32 accumulation of exact
 // bf16 products; only the lo.Wl term, 2^-18, is dropped) at the bf16 MFMA rate.  8 elements per thread.
+template <int PLANES>
 __global__ __launch_bounds__(256) void split3_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows,
                                                               int K8) {
   const size_t total = (size_t)rows * K8;
@@ -131,10 +132,10 @@ __global__ __launch_bounds__(256) void split3_f32_bf16_kernel(const float* __res
       hi[d] = h;
       lo[d] = pack_bf16x2(v[2 * d] - __uint_as_float(h << 16), v[2 * d + 1] - __uint_as_float(h & 0xffff0000u));
     }
-    u32x4_t* row = reinterpret_cast<u32x4_t*>(dst + r * (size_t)(K8 * 24));
+    u32x4_t* row = reinterpret_cast<u32x4_t*>(dst + r * (size_t)(K8 * 8 * PLANES));
     row[c] = hi;
     row[K8 + c] = lo;
-    row[2 * K8 + c] = hi;
+    if (PLANES == 3) row[2 * K8 + c] = hi;
   }
 }
 
@@ -151,7 +152,21 @@ extern "C" int mega_split_f32_to_bf16x3(const float* src, void* dst, int rows, i
   const size_t total = (size_t)rows * (K / 8);
   size_t nb = (total + 255) / 256;
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(split3_f32_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K / 8);
+  hipLaunchKernelGGL(split3_f32_bf16_kernel<3>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K / 8);
+  return mega_check_launch();
+}
+
+// dst[r][0:K] = hi, dst[r][K:2K] = lo of src[r][0:K]: the split-precision PLANES form of an f32 activation (hi = bf16(x),
+// lo = bf16(x - hi)) that mega_conv2d_nhwc_sp reads as its input / residual and writes as its output.
+extern "C" int mega_split_f32_to_planes(const float* src, void* dst, int rows, int K, void* stream) {
+  mega_clear_error();
+  if (rows == 0) return MEGA_OK;
+  if (!src || !dst || rows < 0 || K <= 0 || K % 8 || (reinterpret_cast<size_t>(src) & 15) || (reinterpret_cast<size_t>(dst) & 15))
+    return MEGA_ERR_ARG;
+  const size_t total = (size_t)rows * (K / 8);
+  size_t nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(split3_f32_bf16_kernel<2>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K / 8);
   return mega_check_launch();
 }
 

@@ -538,7 +538,7 @@ extern "C" int mega_conv2d_nhwc_ws(const void* in, const void* w, const float* s
   if (!in || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
       dil <= 0 || pad < 0)
     return MEGA_ERR_ARG;
-  ConvParams p;
+  ConvParams p = {};
   p.in = in; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.out = out;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad; p.dil = dil;
@@ -590,4 +590,62 @@ extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scal
                                 int in_dtype, int out_dtype, void* stream) {
   return mega_conv2d_nhwc_ws(in, w, scale, bias, residual, out, N, H, W, Cin, Cout, R, S, stride, pad, dil, relu, ldo,
                              ldr, in_dtype, out_dtype, nullptr, 0, stream);
+}
+
+// Split-precision activation planes (igemm_params.h, igemm8.hip SP kernels).  An f32 activation x [N,H,W,C] lives in HBM as
+// bf16 [N,H,W,2C] = [hi | lo] (mega_split_f32_to_planes; ~2^-17 relative).  This entry point runs conv + FrozenBN (+ split
+// residual) + activation on such tensors with the bf16 matrix cores:
+//   in       bf16 [N,H,W,ldi]; the contraction runs over Cin channels per tap whose SOURCE channel is k < kwrap ? k : k - kwrap
+//            (kwrap = 0: no wrap).  Split precision ("bf16 x 3"): ldi = 2C, Cin = 3C, kwrap = 2C, w = [Wh | Wh | Wl] per tap
+//            ([Cout,R,S,3C], ops.split_weight_bf16x3): x_hi.Wh + x_lo.Wh + x_hi.Wl = x.W to ~2^-16, f32 accumulation.
+//            bf16 compute on a wide residual stream: ldi = 2C, Cin = C, kwrap = 0, plain bf16 weights (the hi plane is read).
+//   residual split planes [M][ldr] (ldr >= 2 Cout) or null: hi + lo is added in f32 before the activation
+//   out_mode 0: bf16 [M][ldo];  1: split planes [M][ldo] (ldo >= 2 Cout);  2: f32 [M][ldo]
+// Cin % 64 == 0, Cout % 8 == 0, every tensor below 2 GiB.  ws: split-K workspace as for mega_conv2d_nhwc_ws (f32 output, no
+// residual).  Replaces, in the split-precision parity mode, the same reference layers as mega_conv2d_nhwc
+// (backbone/resnet.py:324-344, rpn/rpn.py:99-106, roi_box_feature_extractors.py:894,:907).
+extern "C" int mega_conv2d_nhwc_sp(const void* in, int ldi, int kwrap, const void* w, const float* scale, const float* bias,
+                                   const void* residual, int ldr, void* out, int ldo, int out_mode, int N, int H, int W,
+                                   int Cin, int Cout, int R, int S, int stride, int pad, int dil, int relu, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  mega_clear_error();
+  if (!in || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
+      dil <= 0 || pad < 0 || out_mode < 0 || out_mode > 2 || ldi <= 0 || kwrap < 0 || Cin % 64 != 0)
+    return MEGA_ERR_ARG;
+  ConvParams p = {};
+  p.in = in; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.out = out;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S;
+  p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+  if (p.Ho <= 0 || p.Wo <= 0) return MEGA_ERR_ARG;
+  p.M = N * p.Ho * p.Wo;
+  p.K = R * S * Cin;
+  p.sp = 1; p.ldi = ldi; p.kwrap = kwrap; p.split_out = out_mode == 1;
+  p.ldo = ldo > 0 ? ldo : (out_mode == 1 ? 2 * Cout : Cout);
+  p.ldr = ldr > 0 ? ldr : 2 * Cout;
+  p.relu = relu;
+  p.ksplit = 1;
+  p.partial = nullptr;
+  if (ws) {
+    const int z = choose_ksplit(p.K);
+    if (z > 1) {
+      if (ws_bytes < (size_t)z * p.M * Cout * sizeof(float) || out_mode != 2 || residual) return MEGA_ERR_ARG;
+      p.ksplit = z;
+      p.partial = (float*)ws;
+    }
+  }
+  {
+    const size_t ib = (size_t)N * H * W * ldi * 2, wb = (size_t)Cout * p.K * 2;
+    if (ib >= 0x7FF00000ull || wb >= 0x7FF00000ull) return MEGA_ERR_ARG;  // 32-bit buffer offsets
+    p.in_bytes = (unsigned)ib;
+    p.w_bytes = (unsigned)wb;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // one block per CU: the row count that wastes the fewest CU-rounds (the rule of choose_tile)
+  const long t256 = (long)cdiv(p.M, 256) * cdiv(Cout, 256) * p.ksplit, t192 = (long)cdiv(p.M, 192) * cdiv(Cout, 256) * p.ksplit;
+  const long c256 = cdiv((int)t256, 256) * 256L * 8, c192 = cdiv((int)t192, 256) * 192L * 9;
+  int rc = mega_igemm8_launch(p, c192 < c256 ? 192 : 256, out_mode == 2, st);
+  if (rc == MEGA_OK && p.ksplit > 1) rc = launch_finalize<bf16_t, float>(p, st);
+  return rc;
 }

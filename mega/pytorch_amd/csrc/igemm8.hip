@@ -59,6 +59,7 @@ struct KPos {
 // two classes sit under different roofs (MFMA vs HBM / CU fetch rate); as ONE symbol their rocprofv3 average blends
 // 1290 TF/s (RPN conv) with 480 TF/s (layer3 conv3) and says nothing about either.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 // ABL == 5: whole-tile timeline of EVERY block (waves 0 and 4, one per MFMA group): 16 u64 slots per wave in p.partial
 // (tools/gpu/timeline8.py): s_memtime (shader cycles) at 0 entry, 1 K loop starts, 2 K loop done, 3 + 2s slab s staged,
@@ -79,7 +80,13 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     }                                                                                                                   \
   } while (0)
 
-template <typename OT, int MF1, int CLS = 0, int ABL = 0>
+// SP != 0: split-precision activation planes (igemm_params.h: ldi, kwrap, split_out, split residual) -- its own symbols, the
+// plain kernels' code does not change.
+__device__ __forceinline__ int fast_div(int n, unsigned mg, unsigned sh) {   // n / d for 0 <= n < 2^31 (launch8 computes mg, sh)
+  return (int)((__umulhi((unsigned)n, mg) + (unsigned)n) >> sh);
+}
+
+template <typename OT, int MF1, int CLS = 0, int ABL = 0, int SP = 0>
 __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   constexpr int BM = 128 + 64 * MF1;
   constexpr int BN = 256;
@@ -113,9 +120,13 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   //      chunk pch), u = 0, 1; the logical chunk it reads from memory is pch ^ swizzle(row)  (64 u does not change it)
   const int prow = tid >> 3, pch = tid & 7;
   const unsigned lcb = (unsigned)((pch ^ ((prow >> 1) & 7)) * 16);
+  const int ldi = SP ? p.ldi : p.Cin;          // pixel stride of the input in elements
+  const int kwrap = SP && p.kwrap > 0 ? p.kwrap : 0x7fffffff;
   int a_hi0[4], a_wi0[4];
   unsigned a_off[4];
   {
+    // (m -> (image, ho, wo) by magic-number multiplication: the eight integer divisions this replaces were ~1 k cycles
+    //  of every tile's prologue -- ~35 VALU instructions each, before the first DMA could be issued)
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -123,13 +134,13 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
       const int m = m0 + (r >> 1) * 128 + prow + 64 * (r & 1);
       const bool ok = m < p.M;
       const int mm = ok ? m : 0;
-      const int nimg = mm / HoWo;
+      const int nimg = fast_div(mm, p.mg_howo, p.sh_howo);
       const int rem = mm - nimg * HoWo;
-      const int ho = rem / p.Wo;
+      const int ho = fast_div(rem, p.mg_wo, p.sh_wo);
       const int wo = rem - ho * p.Wo;
       a_hi0[r] = ok ? ho * p.stride - p.pad : -(1 << 20);      // a row past M never passes the range test below
       a_wi0[r] = wo * p.stride - p.pad;
-      a_off[r] = ((unsigned)(nimg * p.H * p.W) + (unsigned)(a_hi0[r] * p.W + a_wi0[r])) * (unsigned)(p.Cin * 2) + lcb;
+      a_off[r] = ((unsigned)(nimg * p.H * p.W) + (unsigned)(a_hi0[r] * p.W + a_wi0[r])) * (unsigned)(ldi * 2) + lcb;
     }
   }
   unsigned b_off[4];
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     s.kr = (kk / p.Cin) / p.S;
     s.dh = s.kr * p.dil;
     s.dw = s.ks * p.dil;
-    s.uni = (unsigned)(((s.dh * p.W + s.dw) * p.Cin + s.kc) * 2);
+    s.uni = (unsigned)(((s.dh * p.W + s.dw) * ldi + (s.kc >= kwrap ? s.kc - kwrap : s.kc)) * 2);
   };
   auto kpos_next = [&](KPos& s) {
     s.kc += 64;
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
       s.dw += p.dil;
       if (++s.ks == p.S) { s.ks = 0; s.dw = 0; ++s.kr; s.dh += p.dil; }
     }
-    s.uni = (unsigned)(((s.dh * p.W + s.dw) * p.Cin + s.kc) * 2);
+    s.uni = (unsigned)(((s.dh * p.W + s.dw) * ldi + (s.kc >= kwrap ? s.kc - kwrap : s.kc)) * 2);
   };
   KPos pa0, pa1;                       // K position of the next A0 / A1 half-tile to be issued
   kpos_init(pa0);
@@ -250,10 +261,14 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     __builtin_amdgcn_s_barrier();     \
     asm volatile("" ::: "memory");   \
   } while (0)
+// The WEIGHT fragment is the MFMA's first operand: the 32 x 32 result is then indexed [n][m] -- a lane owns ONE output row
+// m = lane & 31 and, for each r >> 2, FOUR CONSECUTIVE channels n = 8 (r >> 2) + 4 (lane >> 5) + (r & 3) -- so the epilogue
+// stages a fragment with 4 ds_write_b128 instead of 16 ds_write_b32 (its staging was LDS store-issue bound: 1.4 k cycles
+// per slab).  Same products, same K order per output element: the same bits as the (activation, weight) operand order.
 #define MEGA_MMA(acc_, a_, b_)                                                                                          \
   do {                                                                                                                  \
     if (ABL != 3)                                                                                                       \
-      acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a_), __builtin_bit_cast(bf16x8_t, b_), \
+      acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b_), __builtin_bit_cast(bf16x8_t, a_), \
                                                      acc_, 0, 0, 0);                                                    \
     else                                                                                                                \
       asm volatile("" ::"v"(a_), "v"(b_));                                                                              \
@@ -372,10 +387,12 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   MEGA_BAR();
   MEGA_TS(2);
 
-  // ---- epilogue: accumulators (lane owns column lane & 31, rows (r&3) + 8 (r>>2) + 4 (lane>>5) of a 32 x 32
-  //      fragment) are scaled / biased and staged through LDS as f32, one 64-row slab per (A half, M fragment) --
-  //      the two wave rows' 32-row fragments, all 256 columns -- then written as whole 16-byte vectors along n with
-  //      residual add and activation: same scheme as igemm.hip.
+  // ---- epilogue.  Accumulator fragment [n][m] (see MEGA_MMA): lane owns output row m = lane & 31 of its fragment and
+  //      channels 8 g + 4 (lane >> 5) + (0..3), g = 0..3.  The RAW accumulators are staged through LDS as f32, one 64-row
+  //      slab per (A half, M fragment) -- the two wave rows' 32-row fragments, all 256 columns: 8 ds_write_b128 per lane --
+  //      and read back as 16-byte vectors along n; FrozenBN scale / bias (one fma per element: the same v_fma the staging
+  //      used to apply), residual add and activation happen at the read-out, where a thread's column vector is fixed
+  //      (its 8 / 4 scale and bias values live in registers).  Same scheme as igemm.hip, same bits.
   constexpr int CST = BN + 4;
   static_assert(64 * CST * 4 <= LDS8, "staging slab must fit");
   float* cs = reinterpret_cast<float*>(smem);
@@ -385,14 +402,17 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   constexpr int VPR = BN / OVE;
   const float neg_slope = p.relu == 1 ? 0.f : (p.relu == 2 ? 0.1f : 1.f);
   auto act = [&](float x) { return x > 0.f ? x : x * neg_slope; };
-  const bool vec_ok = (p.ldo % OVE == 0) && (!res || (sizeof(OT) == 2 && p.ldr % OVE == 0));
-  float sc[2], bi[2];
+  const bool vec_ok = (p.ldo % OVE == 0) && (!res || (SP ? p.ldr % 8 == 0 : (sizeof(OT) == 2 && p.ldr % OVE == 0)));
+  auto stage = [&](float* csb, int i, int f) {
+    float* dst = csb + (wr * 32 + l31) * CST + wc * 32 + 4 * (lane >> 5);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + j * 128 + wc * 32 + l31;
-    sc[j] = (p.ksplit == 1 && p.scale && n < p.Cout) ? p.scale[n] : 1.f;
-    bi[j] = (p.ksplit == 1 && p.bias && n < p.Cout) ? p.bias[n] : 0.f;
-  }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t q = {acc[i][f][j][4 * g], acc[i][f][j][4 * g + 1], acc[i][f][j][4 * g + 2], acc[i][f][j][4 * g + 3]};
+        *reinterpret_cast<f32x4_t*>(dst + j * 128 + 8 * g) = q;
+      }
+  };
   // The slab loop's barriers are raw s_barrier + lgkmcnt(0) (LDS traffic only), NOT __syncthreads(): a __syncthreads()
   // is also a vmcnt(0) fence, which made every slab wait for its own global stores to be acknowledged and for every
   // residual load in flight -- four exposed HBM round trips per 256-row tile (round 2), two with the residual rows
@@ -401,39 +421,42 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   // written (the K loop's fragment registers are dead here; all four at once would need 64 registers and spill).  The
   // 1x1 "conv3 + residual" layers are HBM-bound: the epilogue is most of their time.
   constexpr int NIT = 64 * VPR / NT8;                  // 16-byte output vectors per thread per slab (4 bf16 / 8 f32)
-  const bool res_vec = res != nullptr && vec_ok && sizeof(OT) == 2 && p.ksplit == 1;
-  uint4 rres2[2][NIT];
-  auto load_res = [&](int i, int f, uint4 (&dst)[NIT]) {
-    const int wrows = i == 1 ? WROWS1 : 64;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int e = tid + it * NT8;
-      const int row = e / VPR, cv = e - row * VPR;
-      const int m = m0 + i * 128 + (row >> 5) * wrows + f * 32 + (row & 31), n = n0 + cv * OVE;
-      dst[it] = make_uint4(0, 0, 0, 0);
-      if (m < p.M && n + OVE <= p.Cout) dst[it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
-    }
-  };
   // ---- fast path (every bf16 / f32 layer whose Cout is a multiple of 256 and whose output is below 2 GiB: all of the
   //      frame stage): buffer loads / stores with the hardware range check instead of per-vector bounds branches.  With
   //      branches in the read-out loop hipcc merges the wait counts at every join into vmcnt(0) -- each 16-byte store
   //      then waited for the previous one to be acknowledged, four serialized round trips per slab.  Straight-line code
   //      keeps the counts exact: the stores of a slab go out back to back and drain behind the next slab's staging.
-  const bool fast = vec_ok && p.ksplit == 1 && n0 + BN <= p.Cout && (res == nullptr || sizeof(OT) == 2) &&
-                    ((size_t)(p.M - 1) * p.ldo + p.Cout) * sizeof(OT) < 0x7FF00000ull &&
-                    (res == nullptr || ((size_t)(p.M - 1) * p.ldr + p.Cout) * 2 < 0x7FF00000ull);
+  //      SP kernels: any Cout % 8 == 0 (threads whose column vector lies past Cout carry an out-of-range offset), split
+  //      residual / output planes; they have no other epilogue (launch8 refuses what does not qualify), except the raw
+  //      partial sums of a split-K launch.
+  const int oplanes = SP && p.split_out ? 2 : 1;       // planes of Cout columns behind each other in an output row
+  const bool fast = vec_ok && p.ksplit == 1 && (SP ? p.Cout % OVE == 0 : n0 + BN <= p.Cout) && (res == nullptr || sizeof(OT) == 2 || SP) &&
+                    ((size_t)(p.M - 1) * p.ldo + (size_t)oplanes * p.Cout) * sizeof(OT) < 0x7FF00000ull &&
+                    (res == nullptr || ((size_t)(p.M - 1) * p.ldr + (size_t)(SP ? 2 : 1) * p.Cout) * 2 < 0x7FF00000ull);
   if (fast) {
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        p.out, 0, (int)(((size_t)(p.M - 1) * p.ldo + p.Cout) * sizeof(OT)), 0x00020000);
+        p.out, 0, (int)(((size_t)(p.M - 1) * p.ldo + (size_t)oplanes * p.Cout) * sizeof(OT)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.res ? p.res : p.out), 0, res ? (int)(((size_t)(p.M - 1) * p.ldr + p.Cout) * 2) : 0, 0x00020000);
+        const_cast<void*>(p.res ? p.res : p.out), 0, res ? (int)(((size_t)(p.M - 1) * p.ldr + (size_t)(SP ? 2 : 1) * p.Cout) * 2) : 0, 0x00020000);
     constexpr int RSTEP = NT8 / VPR;                   // slab rows between a thread's consecutive vectors
     const int row0 = tid / VPR, ncol = n0 + (tid % VPR) * OVE;
+    const unsigned cmask = SP && ncol >= p.Cout ? OOB : 0u;      // (SP) this thread's columns do not exist: loads give 0, stores are dropped
     // (row0 < RSTEP and RSTEP divides 32: the slab row row0 + it * RSTEP splits into a per-thread part and a
     // compile-time part -- one add per vector instead of the shift / mask / multiply chain)
     auto slab_m = [&](int i, int f, int it) {
       return (m0 + row0) + (i * 128 + ((it * RSTEP) >> 5) * (i == 1 ? WROWS1 : 64) + f * 32 + ((it * RSTEP) & 31));
     };
+    float scv[OVE], biv[OVE];
+    {
+      const bool colok = !SP || ncol < p.Cout;
+#pragma unroll
+      for (int t = 0; t < OVE; t += 4) {
+        const f32x4_t s4 = p.scale && colok ? *reinterpret_cast<const f32x4_t*>(p.scale + ncol + t) : f32x4_t{1.f, 1.f, 1.f, 1.f};
+        const f32x4_t b4 = p.bias && colok ? *reinterpret_cast<const f32x4_t*>(p.bias + ncol + t) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { scv[t + u] = s4[u]; biv[t + u] = b4[u]; }
+      }
+    }
     // RL = 1: ReLU applied to the ROUNDED value -- for bf16 one v_pk_max_i16 per pair on the packed bits (sign bit set
     // -> 0), for f32 one v_max: round(relu(x)) == relu(round(x)) bit for bit except that a negative input gives +0
     // instead of the generic form's -0 (x * 0).  The generic x > 0 ? x : x * slope costs cmp + cndmask + mul per element:
@@ -444,31 +467,47 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     // address register per store.)
     int slab1 = 64 * CST;
     asm volatile("" : "+v"(slab1));
-    auto run = [&](auto HR, auto RL) {
+    auto run = [&](auto HR, auto RL, auto SO) {
       constexpr bool HAS_RES = decltype(HR)::value;
       constexpr bool RELU = decltype(RL)::value;
+      constexpr bool SPLIT_OUT = decltype(SO)::value;
+      // plain kernels: rr[f][it] = the bf16 residual vectors of slab (i, f), two slabs rolling.
+      // SP kernels: rr[plane][it] = the hi / lo vectors of ONE slab (the next slab's are requested right after this
+      // slab's stores); an f32-output thread's vector is 4 elements: hi in words 0-1, lo in words 2-3 of rr[0][it].
       u32x4_t rr[2][NIT];
       auto ldres = [&](int i, int f, u32x4_t (&dst)[NIT]) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
           dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, (unsigned)(slab_m(i, f, it) * p.ldr + ncol) * 2u, 0, 0);
       };
+      auto ldres_sp = [&](int i, int f) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const unsigned off = ((unsigned)(slab_m(i, f, it) * p.ldr + ncol) * 2u) | cmask;
+          if constexpr (sizeof(OT) == 2) {
+            rr[0][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
+            rr[1][it] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off + (unsigned)p.Cout * 2u, 0, 0);
+          } else {
+            const u32x2_t h = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0);
+            const u32x2_t l = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off + (unsigned)p.Cout * 2u, 0, 0);
+            rr[0][it] = u32x4_t{h[0], h[1], l[0], l[1]};
+          }
+        }
+      };
       if (HAS_RES) {
-        ldres(0, 0, rr[0]);
-        ldres(0, 1, rr[1]);
+        if constexpr (SP) {
+          ldres_sp(0, 0);
+        } else {
+          ldres(0, 0, rr[0]);
+          ldres(0, 1, rr[1]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int f = 0; f < (i == 1 ? MF1 : 2); ++f) {
           float* csb = ((2 * i + f) & 1) ? cs + slab1 : cs;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int nl = j * 128 + wc * 32 + l31;
-            const int rb = wr * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) csb[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][f][j][r] * sc[j] + bi[j];
-          }
+          stage(csb, i, f);
           MEGA_WAIT_LDS();
           MEGA_BAR();
           MEGA_TS(3 + 2 * (2 * i + f));
@@ -479,9 +518,10 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #pragma unroll
             for (int t = 0; t < OVE; t += 4) {
               const float4 q4 = *reinterpret_cast<const float4*>(csb + row * CST + (tid % VPR) * OVE + t);
-              v[t] = q4.x; v[t + 1] = q4.y; v[t + 2] = q4.z; v[t + 3] = q4.w;
+              v[t] = fmaf(q4.x, scv[t], biv[t]); v[t + 1] = fmaf(q4.y, scv[t + 1], biv[t + 1]);
+              v[t + 2] = fmaf(q4.z, scv[t + 2], biv[t + 2]); v[t + 3] = fmaf(q4.w, scv[t + 3], biv[t + 3]);
             }
-            if (HAS_RES) {
+            if constexpr (HAS_RES && !SP) {
               u32x4_t r4 = rr[f][it];
               asm volatile("" : "+v"(r4));             // unpack HERE: hoisted, the 64 unpacked floats of two slabs spill
 #pragma unroll
@@ -490,32 +530,82 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
                 v[2 * d + 1] += __uint_as_float(r4[d] & 0xffff0000u);
               }
             }
-            u32x4_t o;                                 // packed explicitly (no type-punned stores into o)
-            if constexpr (sizeof(OT) == 2) {
+            if constexpr (HAS_RES && SP) {             // residual value = hi + lo (exact in f32), then one add
+              u32x4_t h4 = rr[0][it];
+              asm volatile("" : "+v"(h4));
+              if constexpr (sizeof(OT) == 2) {
+                u32x4_t l4 = rr[1][it];
+                asm volatile("" : "+v"(l4));
 #pragma unroll
-              for (int d = 0; d < 4; ++d) {
-                if constexpr (RELU) {
-                  const s16x2_t z = {0, 0};
-                  o[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pack_bf16x2(v[2 * d], v[2 * d + 1])), z));
-                } else {
-                  o[d] = pack_bf16x2(act(v[2 * d]), act(v[2 * d + 1]));
+                for (int d = 0; d < 4; ++d) {
+                  v[2 * d] += __uint_as_float(h4[d] << 16) + __uint_as_float(l4[d] << 16);
+                  v[2 * d + 1] += __uint_as_float(h4[d] & 0xffff0000u) + __uint_as_float(l4[d] & 0xffff0000u);
+                }
+              } else {
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                  v[2 * d] += __uint_as_float(h4[d] << 16) + __uint_as_float(h4[2 + d] << 16);
+                  v[2 * d + 1] += __uint_as_float(h4[d] & 0xffff0000u) + __uint_as_float(h4[2 + d] & 0xffff0000u);
                 }
               }
-            } else {
-#pragma unroll
-              for (int t = 0; t < 4; ++t) o[t] = __float_as_uint(RELU ? fmaxf(v[t], 0.f) : act(v[t]));
             }
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (unsigned)(slab_m(i, f, it) * p.ldo + ncol) * (unsigned)sizeof(OT), 0, 0);
+            const unsigned ooff = ((unsigned)(slab_m(i, f, it) * p.ldo + ncol) * (unsigned)sizeof(OT)) | cmask;
+            u32x4_t o;                                 // packed explicitly (no type-punned stores into o)
+            if constexpr (SPLIT_OUT) {                 // hi = bf16(x), lo = bf16(x - hi) of x = act(v), both planes
+              u32x4_t ol;
+#pragma unroll
+              for (int d = 0; d < 4; ++d) {
+                const float x0 = RELU ? fmaxf(v[2 * d], 0.f) : act(v[2 * d]), x1 = RELU ? fmaxf(v[2 * d + 1], 0.f) : act(v[2 * d + 1]);
+                const unsigned h = pack_bf16x2(x0, x1);
+                o[d] = h;
+                ol[d] = pack_bf16x2(x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u));
+              }
+              __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ooff, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(ol, rs_out, ooff + (unsigned)p.Cout * 2u, 0, 0);
+            } else {
+              if constexpr (sizeof(OT) == 2) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                  if constexpr (RELU) {
+                    const s16x2_t z = {0, 0};
+                    o[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pack_bf16x2(v[2 * d], v[2 * d + 1])), z));
+                  } else {
+                    o[d] = pack_bf16x2(act(v[2 * d]), act(v[2 * d + 1]));
+                  }
+                }
+              } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = __float_as_uint(RELU ? fmaxf(v[t], 0.f) : act(v[t]));
+              }
+              __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ooff, 0, 0);
+            }
           }
-          if (HAS_RES && i == 0 && f < MF1) ldres(1, f, rr[f]);   // slab s + 2 into the registers slab s just freed
+          if constexpr (SP) {
+            // the NEXT slab's residual rows, into the registers this slab's read-out just released
+            if (HAS_RES && !(i == 1 && f == MF1 - 1)) ldres_sp(f + 1 < (i == 1 ? MF1 : 2) ? i : i + 1, f + 1 < (i == 1 ? MF1 : 2) ? f + 1 : 0);
+          } else {
+            if (HAS_RES && i == 0 && f < MF1) ldres(1, f, rr[f]);   // slab s + 2 into the registers slab s just freed
+          }
           MEGA_TS(4 + 2 * (2 * i + f));
         }
       }
     };
-    if (res) {
-      if (p.relu == 1) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
-    } else {
-      if (p.relu == 1) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
+    const bool so = SP && sizeof(OT) == 2 && p.split_out;
+    if constexpr (SP && sizeof(OT) == 2) {
+      if (so) {
+        if (res) {
+          if (p.relu == 1) run(std::true_type{}, std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}, std::true_type{});
+        } else {
+          if (p.relu == 1) run(std::false_type{}, std::true_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}, std::true_type{});
+        }
+      }
+    }
+    if (!so) {
+      if (res) {
+        if (p.relu == 1) run(std::true_type{}, std::true_type{}, std::false_type{}); else run(std::true_type{}, std::false_type{}, std::false_type{});
+      } else {
+        if (p.relu == 1) run(std::false_type{}, std::true_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}, std::false_type{});
+      }
     }
     if (ABL == 5) {
       MEGA_WAIT_VM(0);
@@ -531,6 +621,27 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     }
     return;
   }
+  // ---- general path: partial sums of a split-K launch, Cout not a multiple of 256, unaligned rows, outputs >= 2 GiB
+  //      (SP kernels get here for split-K partial sums only)
+  if (SP && p.ksplit == 1) return;                     // (launch8 refuses such launches: nothing to do here)
+  const bool res_vec = res != nullptr && vec_ok && sizeof(OT) == 2 && p.ksplit == 1;
+  uint4 rres2[2][NIT];
+  auto load_res = [&](int i, int f, uint4 (&dst)[NIT]) {
+    const int wrows = i == 1 ? WROWS1 : 64;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * NT8;
+      const int row = e / VPR, cv = e - row * VPR;
+      const int m = m0 + i * 128 + (row >> 5) * wrows + f * 32 + (row & 31), n = n0 + cv * OVE;
+      dst[it] = make_uint4(0, 0, 0, 0);
+      if (m < p.M && n + OVE <= p.Cout) dst[it] = *reinterpret_cast<const uint4*>(res + (size_t)m * p.ldr + n);
+    }
+  };
+  auto scb = [&](int n, float x) {                       // FrozenBN scale / bias of column n (split-K: finalize applies them)
+    const float sc = (p.ksplit == 1 && p.scale && n < p.Cout) ? p.scale[n] : 1.f;
+    const float bi = (p.ksplit == 1 && p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+    return fmaf(x, sc, bi);
+  };
   if (res_vec) {
     load_res(0, 0, rres2[0]);
     load_res(0, 1, rres2[1]);
@@ -542,13 +653,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
       const int wrows = i == 1 ? WROWS1 : 64;          // rows per wave row inside this A half
       uint4 (&rres)[NIT] = rres2[f];
       if (i + f > 0) { MEGA_WAIT_LDS(); MEGA_BAR(); }  // the previous slab has been read out
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int nl = j * 128 + wc * 32 + l31;
-        const int rb = wr * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * CST + nl] = acc[i][f][j][r] * sc[j] + bi[j];
-      }
+      stage(cs, i, f);
       MEGA_WAIT_LDS();
       MEGA_BAR();
       if (p.ksplit > 1) {                              // raw partial sums; splitk_finalize_kernel (igemm.hip) finishes
@@ -567,6 +672,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
         }
         continue;
       }
+      if constexpr (!SP) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int e = tid + it * NT8;
@@ -577,7 +683,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #pragma unroll
         for (int t = 0; t < OVE; t += 4) {
           const float4 q4 = *reinterpret_cast<const float4*>(cs + row * CST + cv * OVE + t);
-          v[t] = q4.x; v[t + 1] = q4.y; v[t + 2] = q4.z; v[t + 3] = q4.w;
+          v[t] = scb(n + t, q4.x); v[t + 1] = scb(n + t + 1, q4.y); v[t + 2] = scb(n + t + 2, q4.z); v[t + 3] = scb(n + t + 3, q4.w);
         }
         if (vec_ok && n + OVE <= p.Cout) {
           if (res_vec) {
@@ -601,6 +707,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
         }
       }
       if (res_vec && i == 0 && f < MF1) load_res(1, f, rres);   // slab s + 2 into the registers slab s just freed
+      }
     }
   }
 #undef MEGA_LDS_RD
@@ -612,13 +719,23 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #undef MEGA_STAMP
 }
 
-template <typename OT, int MF1, int CLS = 0, int ABL = 0>
-int launch8(const ConvParams& p, hipStream_t st) {
+// n / d == (umulhi(n, mg) + n) >> sh for every 0 <= n < 2^31 (round-up method: sh = ceil(log2 d), mg = floor(2^32 (2^sh - d) / d) + 1)
+inline void magic_div(int d, unsigned& mg, unsigned& sh) {
+  sh = 0;
+  while ((1ull << sh) < (unsigned long long)d) ++sh;
+  mg = (unsigned)((((1ull << sh) - (unsigned long long)d) << 32) / (unsigned long long)d + 1ull);
+}
+
+template <typename OT, int MF1, int CLS = 0, int ABL = 0, int SP = 0>
+int launch8(const ConvParams& p0, hipStream_t st) {
   constexpr int BM = 128 + 64 * MF1;
+  ConvParams p = p0;
+  magic_div(p.Ho * p.Wo, p.mg_howo, p.sh_howo);
+  magic_div(p.Wo, p.mg_wo, p.sh_wo);
   const int ntm = cdiv(p.M, BM), ntn = cdiv(p.Cout, 256);
   // set on every launch (a per-process flag would miss the second device of a multi-GPU process)
-  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1, CLS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_ALLOC);
-  hipLaunchKernelGGL((igemm8_kernel<OT, MF1, CLS, ABL>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8_ALLOC, st, p);
+  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1, CLS, ABL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_ALLOC);
+  hipLaunchKernelGGL((igemm8_kernel<OT, MF1, CLS, ABL, SP>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8_ALLOC, st, p);
   return mega_check_launch();
 }
 
@@ -690,6 +807,22 @@ int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st)
   }
 #endif
   const bool stream = mega_igemm8_streaming(p.R * p.S, p.K) && p.ksplit == 1;
+  if (p.sp) {
+    // split-precision planes: the SP kernels have the buffer-addressed epilogue only (+ raw split-K partial sums)
+    const size_t oplanes = p.split_out ? 2 : 1, osz = out_f32 ? 4 : 2;
+    const bool ok = p.ldi >= (p.kwrap > 0 ? p.kwrap : p.Cin) && p.ldi % 64 == 0 && (p.kwrap == 0 || (p.kwrap % 64 == 0 && p.kwrap < p.Cin && p.Cin - p.kwrap <= p.kwrap)) &&
+                    p.Cout % 8 == 0 && !(p.split_out && out_f32) && p.ldo % (out_f32 ? 4 : 8) == 0 && p.ldo >= (int)oplanes * p.Cout &&
+                    (!p.res || (p.ldr % 8 == 0 && p.ldr >= 2 * p.Cout)) &&
+                    ((size_t)(p.M - 1) * p.ldo + oplanes * p.Cout) * osz < 0x7FF00000ull &&
+                    (!p.res || ((size_t)(p.M - 1) * p.ldr + 2 * (size_t)p.Cout) * 2 < 0x7FF00000ull) &&
+                    (p.ksplit == 1 || (!p.split_out && !p.res));
+    if (!ok) return MEGA_ERR_ARG;
+    if (bm == 256 && stream) return out_f32 ? launch8<float, 2, 1, 0, 1>(p, st) : launch8<bf16_t, 2, 1, 0, 1>(p, st);
+    if (bm == 192 && stream) return out_f32 ? launch8<float, 1, 1, 0, 1>(p, st) : launch8<bf16_t, 1, 1, 0, 1>(p, st);
+    if (bm == 256) return out_f32 ? launch8<float, 2, 0, 0, 1>(p, st) : launch8<bf16_t, 2, 0, 0, 1>(p, st);
+    if (bm == 192) return out_f32 ? launch8<float, 1, 0, 0, 1>(p, st) : launch8<bf16_t, 1, 0, 0, 1>(p, st);
+    return MEGA_ERR_ARG;
+  }
   if (bm == 256 && stream) return out_f32 ? launch8<float, 2, 1>(p, st) : launch8<bf16_t, 2, 1>(p, st);
   if (bm == 192 && stream) return out_f32 ? launch8<float, 1, 1>(p, st) : launch8<bf16_t, 1, 1>(p, st);
   if (bm == 256) return out_f32 ? launch8<float, 2>(p, st) : launch8<bf16_t, 2>(p, st);

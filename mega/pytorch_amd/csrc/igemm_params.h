@@ -17,6 +17,16 @@ struct ConvParams {
   unsigned in_bytes, w_bytes;
   int ksplit;        // > 1: blockIdx.z owns a contiguous range of K-tiles and writes raw f32 partial sums
   float* partial;    // [ksplit][M][Cout] f32 when ksplit > 1
+  // ---- igemm8 only.  Split-precision ("hi | lo planes") activations, sp != 0 (igemm8.hip, SP kernels): an f32 activation
+  //      x [M][C] is stored as bf16 [M][2C] = [hi | lo], hi = bf16(x), lo = bf16(x - hi)  (x = hi + lo to ~2^-17).
+  int sp;            // 1: the fields below apply (mega_conv2d_nhwc_sp); 0: plain tensors (every other entry point)
+  int ldi;           // pixel stride of `in` in elements (2C for a split input; Cin when the input is a plain tensor)
+  int kwrap;         // contraction channel at which the SOURCE channel index wraps to 0 (0: never).  Cin = 3C, kwrap = 2C
+                     // reads the planes as [hi | lo | hi]: against weights packed [Wh | Wh | Wl] per tap the K = 3C
+                     // contraction is x_hi.Wh + x_lo.Wh + x_hi.Wl = x.W to ~2^-16 on the bf16 matrix cores
+  int split_out;     // 1: out is split planes [M][ldo] with hi at column n and lo at column Cout + n (bf16 output only)
+                     // (a residual given to an SP launch is ALWAYS split planes: res[m][n] + res[m][Cout + n])
+  unsigned mg_howo, sh_howo, mg_wo, sh_wo;   // magic multipliers / shifts for m / (Ho Wo) and rem / Wo (set by the launcher)
 };
 
 // igemm8.hip: bf16 operands, 8 waves, 256 (BM8 rows) x 256 tile; returns MEGA_OK / MEGA_ERR_*.  out_f32: 0 bf16, 1 f32.

@@ -46,8 +46,27 @@ def stream_dtype(cfg):
     return _DTYPES[str(getattr(cfg, "HEAD_STREAM", "float32"))]
 
 
+def conv_mode(cfg):
+    """How the frame stage's convolutions / first FC run:
+      "f32"   cfg.DTYPE float32: exact-f32 MFMA (the parity mode, 157 TF/s roof)
+      "x3"    cfg.DTYPE float32 + cfg.F32_CONV "bf16x3": split-precision -- activations live as [hi | lo] bf16 planes
+              (ops.Planes), every conv contracts [hi | lo | hi] against [Wh | Wh | Wl] on the bf16 matrix cores with f32
+              accumulation (x.W to ~2^-16); the stem, the narrow RPN outputs and ROIAlign stay exact f32.  The parity mode
+              at matrix-core rates.
+      "bf16"  cfg.DTYPE bfloat16 (what bench.py times)
+      "wide"  cfg.DTYPE bfloat16 + cfg.RESIDUAL_STREAM "planes": bf16 convolutions, but the residual trunk of layer1-3 /
+              res5 (resnet.py:324-344 `out += identity`, 33 + 3 times in R-101-C4) is carried as planes: a conv reads the
+              hi plane (= the bf16 tensor it always read), conv3 adds hi + lo in f32 and writes both planes, so the trunk is
+              never rounded to 8 bits."""
+    if compute_dtype(cfg) == torch.float32:
+        return "x3" if str(getattr(cfg, "F32_CONV", "exact")) == "bf16x3" else "f32"
+    return "wide" if str(getattr(cfg, "RESIDUAL_STREAM", "bfloat16")) == "planes" else "bf16"
+
+
 def _nhwc(x):
     """logical NCHW / channels-last memory -> contiguous NHWC view (no copy when the contract holds)."""
+    if isinstance(x, ops.Planes):
+        return x
     y = x.permute(0, 2, 3, 1)
     return y if y.is_contiguous() else y.contiguous()
 
@@ -101,6 +120,11 @@ def _pack_conv(conv, dtype):
     return conv.weight.detach().permute(0, 2, 3, 1).contiguous().to(dtype)
 
 
+def _pack_conv_x3(conv, dtype=None):
+    """OIHW parameter -> split-precision operand [Cout,R,S,3C] = [Wh | Wh | Wl] per tap (ops.conv2d_sp(x3=True))."""
+    return ops.split_conv_weight_x3(conv.weight.detach().float().permute(0, 2, 3, 1).contiguous())
+
+
 class _Packed(nn.Module):
     """Modules that cache kernel-ready operands; invalidated on load_state_dict / dtype change."""
 
@@ -151,15 +175,36 @@ class Bottleneck(_Packed):
 
     def _pack(self, dtype, device):
         pk = {}
+        pack = _pack_conv_x3 if dtype == "x3" else _pack_conv
         for i in (1, 2, 3):
             s, b = getattr(self, "bn%d" % i).folded()
-            pk["w%d" % i] = _pack_conv(getattr(self, "conv%d" % i), dtype).to(device)
+            pk["w%d" % i] = pack(getattr(self, "conv%d" % i), dtype).to(device)
             pk["s%d" % i], pk["b%d" % i] = s.to(device), b.to(device)
         if self.downsample is not None:
             s, b = self.downsample[1].folded()
-            pk["wd"] = _pack_conv(self.downsample[0], dtype).to(device)
+            pk["wd"] = pack(self.downsample[0], dtype).to(device)
             pk["sd"], pk["bd"] = s.to(device), b.to(device)
         return pk
+
+    sp_mode = None     # "x3" / "wide" (conv_mode): set on every block by the module that owns the stage
+
+    def run_sp(self, x, out_mode="planes"):
+        """The block on split-precision planes (conv_mode "x3" / "wide").  x: ops.Planes, or -- wide mode, the stem's
+        output -- a plain bf16 tensor.  -> Planes, or out_mode "f32" / "bf16": a plain tensor (the last block of res5)."""
+        x3 = self.sp_mode == "x3"
+        pk = self._packed("x3" if x3 else torch.bfloat16, x.device)
+        identity = x
+        if self.downsample is not None:
+            identity = ops.conv2d_sp(x, pk["wd"], pk["sd"], pk["bd"], stride=self.down_stride, out_mode="planes", x3=x3)
+        elif not isinstance(x, ops.Planes):
+            raise ValueError("an identity block needs its input as planes")
+        if x3:
+            t = ops.conv2d_sp(x, pk["w1"], pk["s1"], pk["b1"], stride=self.stride, relu=True)
+            t = ops.conv2d_sp(t, pk["w2"], pk["s2"], pk["b2"], pad=self.dilation, dil=self.dilation, relu=True)
+        else:       # bf16 inside the block: conv1 reads the hi plane, conv2 is the plain launch
+            t = ops.conv2d_sp(x, pk["w1"], pk["s1"], pk["b1"], stride=self.stride, relu=True, out_mode="bf16", x3=False)
+            t = ops.conv2d_nhwc(t, pk["w2"], pk["s2"], pk["b2"], pad=self.dilation, dil=self.dilation, relu=True)
+        return ops.conv2d_sp(t, pk["w3"], pk["s3"], pk["b3"], residual=identity, relu=True, out_mode=out_mode, x3=x3)
 
     fuse = True        # layer1's identity blocks as ONE kernel (ops.bottleneck64); False / MEGA_FUSE_BOTTLENECK=0: three launches
 
@@ -178,6 +223,9 @@ class Bottleneck(_Packed):
 
     def run(self, x, out=None):
         """out: optional destination of the block's output (a contiguous [N,Ho,Wo,Cout] view, e.g. a batch slice)"""
+        if isinstance(x, ops.Planes) or self.sp_mode is not None:
+            assert out is None
+            return self.run_sp(x)
         pk = self._packed(x.dtype, x.device)
         if out is not None:
             assert not self._fusable(x) and not self._fusable_ds(x)
@@ -249,6 +297,7 @@ class ResNet(nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.dtype = compute_dtype(cfg)
+        self.mode = conv_mode(cfg)
         blocks = _STAGE_BLOCKS[cfg.MODEL.BACKBONE.CONV_BODY]
         self.stem = BaseStem(cfg.MODEL.RESNETS.STEM_OUT_CHANNELS)
         in_ch = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
@@ -259,19 +308,31 @@ class ResNet(nn.Module):
             self.add_module(name, _make_stage(in_ch, mid, out, n, first_stride=int(i > 0) + 1))
             self.stages.append(name)
             in_ch = out
+        if self.mode in ("x3", "wide"):
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    m.sp_mode = self.mode
 
     def forward(self, x, u8_norm=None):
         """x [N,3,H,W] f32 image batch -> [C4] (logical NCHW, channels-last memory, compute dtype).
-        u8_norm = (mean, to_bgr) with x the uint8 frames [N,H,W,3] (bf16 mode): preprocessing fused into the stem."""
+        u8_norm = (mean, to_bgr) with x the uint8 frames [N,H,W,3] (bf16 mode): preprocessing fused into the stem.
+        conv_mode "x3" / "wide": C4 as an f32 tensor (hi + lo of the planes run_nhwc returns)."""
+        y = self.run_nhwc(x, u8_norm)
+        return [_nchw_view(y.float() if isinstance(y, ops.Planes) else y)]
+
+    def run_nhwc(self, x, u8_norm=None):
+        """forward() without the NCHW view: -> C4 as a contiguous NHWC tensor, or as ops.Planes (conv_mode "x3" / "wide")"""
         if u8_norm is not None:
             assert self.dtype == torch.bfloat16 and x.dtype == torch.uint8
             y = self.stem.run_u8(x.contiguous(), u8_norm[0], u8_norm[1])
         else:
             y = self.stem.run(x.float().contiguous(), self.dtype)
+        if self.mode == "x3":
+            y = ops.split_planes(y)       # the stem (exact f32 direct conv + max-pool) hands over its f32 map as planes
         for name in self.stages:
             blocks = list(getattr(self, name))
             n = y.shape[0]
-            if name == "layer3" and _L3_SPLIT and y.is_cuda and y.dtype == torch.bfloat16 and n >= 32 and n % 2 == 0:
+            if name == "layer3" and _L3_SPLIT and not isinstance(y, ops.Planes) and y.is_cuda and y.dtype == torch.bfloat16 and n >= 32 and n % 2 == 0:
                 # layer3 in two halves of the batch, each through all its blocks: at 20 frames of 600x1000 the working set of a
                 # conv3 + residual layer (221 MB) stays in the 256 MB Infinity Cache -- 4.6 TB/s of algorithmic bytes against
                 # 3.5-3.8 at 40 frames (tools/gpu/l3_tiles.py); every conv is batch-invariant, so the bits do not change
@@ -290,7 +351,7 @@ class ResNet(nn.Module):
                 continue
             for blk in blocks:
                 y = blk.run(y)
-        return [_nchw_view(y)]
+        return y
 
 
 @BACKBONES.register("R-50-C4")
@@ -315,9 +376,15 @@ class ResNetHead(nn.Module):
         self.layer4 = _make_stage(1024, 512, 2048, 3, first_stride=1, dilation=dilation)
         self.out_channels = 2048
 
-    def run(self, x):
-        for blk in self.layer4:
-            x = blk.run(x)
+    def run(self, x, out_mode=None):
+        """out_mode (conv_mode "x3" / "wide": x is ops.Planes): what the LAST block writes -- "f32" / "bf16" (a plain map for
+        ROIAlign) or "planes" (a 1x1 reduce conv follows)"""
+        blocks = list(self.layer4)
+        for bi, blk in enumerate(blocks):
+            if isinstance(x, ops.Planes):
+                x = blk.run_sp(x, out_mode if bi + 1 == len(blocks) and out_mode else "planes")
+            else:
+                x = blk.run(x)
         return x
 
 
@@ -368,11 +435,23 @@ class RPNHead(_Packed):
     def _pack(self, dtype, device):
         w2 = torch.cat([self.cls_logits.weight.detach(), self.bbox_pred.weight.detach()], dim=0)
         b2 = torch.cat([self.cls_logits.bias.detach(), self.bbox_pred.bias.detach()], dim=0)
+        if dtype == "x3":      # split-precision 3x3 conv -> f32; the narrow 1x1 outputs stay exact f32
+            return {"w1": _pack_conv_x3(self.conv).to(device), "b1": self.conv.bias.detach().float().to(device).contiguous(),
+                    "w2": w2.permute(0, 2, 3, 1).contiguous().float().to(device), "b2": b2.float().to(device).contiguous()}
         return {"w1": _pack_conv(self.conv, dtype).to(device), "b1": self.conv.bias.detach().float().to(device).contiguous(),
                 "w2": w2.permute(0, 2, 3, 1).contiguous().to(dtype).to(device), "b2": b2.float().to(device).contiguous()}
 
+    sp_mode = None     # "x3" / "wide" when the backbone hands over C4 as ops.Planes (set by RPNWithRefModule)
+
     def run(self, feat_nhwc):
         """-> [B, H*W, 5A] f32 (channel a = objectness of anchor a, A + 4a + j = delta j)."""
+        if isinstance(feat_nhwc, ops.Planes):
+            x3 = self.sp_mode == "x3"
+            pk = self._packed("x3" if x3 else torch.bfloat16, feat_nhwc.device)
+            t = ops.conv2d_sp(feat_nhwc, pk["w1"], None, pk["b1"], pad=1, relu=True, out_mode="f32" if x3 else "bf16", x3=x3)
+            o = ops.conv2d_nhwc(t, pk["w2"], None, pk["b2"], out_dtype=torch.float32)
+            B, H, W, C = o.shape
+            return o.view(B, H * W, C)
         pk = self._packed(feat_nhwc.dtype, feat_nhwc.device)
         t = ops.conv2d_nhwc(feat_nhwc, pk["w1"], None, pk["b1"], pad=1, relu=True)
         o = ops.conv2d_nhwc(t, pk["w2"], None, pk["b2"], out_dtype=torch.float32)
@@ -404,6 +483,8 @@ class RPNWithRefModule(nn.Module):
         self.post_nms_top_n = {"key": c.POST_NMS_TOP_N_TEST, "ref": cfg.MODEL.VID.RPN.REF_POST_NMS_TOP_N}
         self.nms_thresh, self.min_size = c.NMS_THRESH, c.MIN_SIZE
         self.strict_gt = bool(getattr(cfg, "NMS_STRICT_GT", True))
+        if conv_mode(cfg) in ("x3", "wide"):
+            self.head.sp_mode = conv_mode(cfg)
         self.keep_index = False       # tests: frame records also carry the kept proposals' flat anchor indices
 
     def propose(self, feat_nhwc, im_w, im_h, version="key", want_index=False):
@@ -503,6 +584,11 @@ class MEGAFeatureExtractor(_Packed):
         self.out_channels = rep
         self.dtype = compute_dtype(cfg)
         self.stream = stream_dtype(cfg)
+        self.mode = conv_mode(cfg)
+        if self.mode in ("x3", "wide"):
+            for m_ in self.head.modules():
+                if isinstance(m_, Bottleneck):
+                    m_.sp_mode = self.mode
         self.mem = None
         self.global_cache = None
         self.cache_memory_kv = True      # keep the Wk / Wv projections of memory rows (False: re-project every step)
@@ -528,6 +614,10 @@ class MEGAFeatureExtractor(_Packed):
         if self.conv is not None:
             pk["rc_w"] = _pack_conv(self.conv, dtype).to(device)
             pk["rc_b"] = self.conv.bias.detach().float().to(device).contiguous()
+        if self.mode == "x3":      # split-precision fc0 (and reduce conv) operands
+            pk["fc0_x3"] = ops.split_conv_weight_x3(w0.float().contiguous().view(w0.shape[0], 1, 1, -1)).view(w0.shape[0], -1).to(device)
+            if self.conv is not None:
+                pk["rc_w_x3"] = _pack_conv_x3(self.conv).to(device)
         return pk
 
     # ---- per-frame stage (independent per frame; the multi-GPU sharding unit)
@@ -539,6 +629,13 @@ class MEGAFeatureExtractor(_Packed):
     def res5_features(self, feat_nhwc):
         """the proposal-independent half of box_features: res5 (+1x1 reduce) on the full C4 maps"""
         pk = self._packed(self.dtype, feat_nhwc.device)
+        if isinstance(feat_nhwc, ops.Planes):      # conv_mode "x3" / "wide": -> a plain f32 / bf16 map for ROIAlign
+            plain = "f32" if self.mode == "x3" else "bf16"
+            if self.conv is None:
+                return self.head.run(feat_nhwc, out_mode=plain)
+            x = self.head.run(feat_nhwc, out_mode="planes")
+            return ops.conv2d_sp(x, pk["rc_w_x3"] if self.mode == "x3" else pk["rc_w"], None, pk["rc_b"], relu=True,
+                                 out_mode=plain, x3=self.mode == "x3")
         x = self.head.run(feat_nhwc)
         if self.conv is not None:
             x = ops.conv2d_nhwc(x, pk["rc_w"], None, pk["rc_b"], relu=True)
@@ -547,6 +644,19 @@ class MEGAFeatureExtractor(_Packed):
     def pooled_fc(self, x5, rois5):
         """ROIAlign on the res5 maps -> fc0 + ReLU"""
         pk = self._packed(self.dtype, x5.device)
+        if self.mode == "x3":
+            # f32 ROIAlign (exact term order) -> planes -> split-precision fc0, in row chunks: a chunk's planes tensor
+            # ([rows, 2 x 49 C] bf16) stays below the kernels' 2 GiB operand limit.  Rows are independent (split-K depends
+            # on K alone), so the chunking does not change a row's bits.
+            K = rois5.shape[0]
+            per = max(1, min(K, (0x7FF00000 // (4 * self.pooled_c * self.resolution ** 2)) // 64 * 64))
+            out = torch.empty((K, self.feat_dim), dtype=torch.float32, device=x5.device)
+            for o in range(0, K, per):
+                pooled = ops.roi_align(x5, rois5[o:o + per].contiguous(), self.scale, (self.resolution, self.resolution),
+                                       self.sampling_ratio)
+                out[o:o + per] = ops.linear_sp(ops.split_planes(pooled.view(pooled.shape[0], -1)), pk["fc0_x3"], pk["fc_b"][0],
+                                               relu=True)
+            return out
         pooled = ops.roi_align(x5, rois5, self.scale, (self.resolution, self.resolution), self.sampling_ratio)
         return ops.linear(pooled.view(pooled.shape[0], -1), pk["fc_w"][0], pk["fc_b"][0], relu=True,
                           out_dtype=self.stream)
@@ -1199,8 +1309,11 @@ class GeneralizedRCNNMEGA(nn.Module):
     @torch.no_grad()
     def frame_stage_a0(self, imgs, u8_norm=None):
         """imgs: preprocessed f32 [B,3,H,W]; or, with u8_norm = (mean, to_bgr) in bf16 mode, the uint8 frames [B,H,W,3]"""
+        body = self.backbone.body
+        if hasattr(body, "run_nhwc"):      # (C4 stays NHWC -- or ops.Planes in conv_mode "x3" / "wide")
+            return body.run_nhwc(imgs, u8_norm)
         if u8_norm is not None:
-            return _nhwc(self.backbone.body(imgs, u8_norm=u8_norm)[0])
+            return _nhwc(body(imgs, u8_norm=u8_norm)[0])
         return _nhwc(self.backbone(imgs)[0])
 
     @torch.no_grad()

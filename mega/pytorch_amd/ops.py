@@ -803,6 +803,111 @@ def split_weight_bf16x3(w32):
     return torch.cat([wh, wh, wl], dim=1).contiguous()
 
 
+# ------------------------------------------------------------------------------------------------ split-precision planes
+class Planes(object):
+    """An f32 activation [..., C] held as bf16 [..., 2C] = [hi | lo] planes (hi = bf16(x), lo = bf16(x - hi); x = hi + lo to
+    ~2^-17): what the split-precision ("bf16 x 3") frame stage and the wide residual stream of the bf16 mode keep in HBM.
+    `t` is the contiguous bf16 tensor, `C` the logical channel count."""
+    __slots__ = ("t", "C")
+
+    def __init__(self, t, C):
+        assert t.dtype == torch.bfloat16 and t.shape[-1] == 2 * C and t.is_contiguous()
+        self.t, self.C = t, C
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape[:-1]) + (self.C,)
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def float(self):
+        """hi + lo as an f32 tensor (torch ops; tests and seams only)"""
+        return self.t[..., :self.C].float() + self.t[..., self.C:].float()
+
+    def hi(self):
+        return self.t[..., :self.C]
+
+
+def split_planes(x):
+    """f32 [..., C] (contiguous, C % 8 == 0) -> Planes (one launch)."""
+    _gpu(x)
+    lib = _lib.load()
+    C = x.shape[-1]
+    assert x.dtype == torch.float32 and x.is_contiguous() and C % 8 == 0
+    out = torch.empty(tuple(x.shape[:-1]) + (2 * C,), dtype=torch.bfloat16, device=x.device)
+    _tok = _pb("assemble", 0.0, x.numel() * 8.0)
+    rc = lib.mega_split_f32_to_planes(_ptr(x), _ptr(out), x.numel() // C, C, _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_split_f32_to_planes")
+    return Planes(out, C)
+
+
+def split_conv_weight_x3(w_ohwi):
+    """f32 conv weight [Cout,R,S,C] (OHWI) -> bf16 [Cout,R,S,3C] = [Wh | Wh | Wl] per tap: the operand of conv2d_sp(x3=True)
+    (host-side packing, once per model)."""
+    w32 = w_ohwi.float()
+    wh = w32.to(torch.bfloat16)
+    wl = (w32 - wh.float()).to(torch.bfloat16)
+    return torch.cat([wh, wh, wl], dim=-1).contiguous()
+
+
+def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_mode="planes", x3=True):
+    """conv + FrozenBN (+ residual) + activation on split-precision planes (mega_conv2d_nhwc_sp, igemm8 SP kernels).
+    x: Planes [N,H,W,C].  x3=True: w = split_conv_weight_x3(W) [Cout,R,S,3C]; the contraction reads the planes as
+    [hi | lo | hi] -- x.W to ~2^-16 with f32 accumulation.  x3=False: w plain bf16 [Cout,R,S,C], only the hi plane is read
+    (bf16 compute over a wide residual stream).  residual: Planes [N,Ho,Wo,Cout] (hi + lo added in f32).
+    out_mode: "planes" -> Planes, "f32" -> f32 tensor, "bf16" -> bf16 tensor  [N,Ho,Wo,Cout]."""
+    assert residual is None or isinstance(residual, Planes)
+    if not isinstance(x, Planes):      # a plain bf16 tensor as the input (pixel stride C): x3=False only
+        assert x.dtype == torch.bfloat16 and x.is_contiguous() and not x3
+        xt, ldi = x, x.shape[-1]
+    else:
+        xt, ldi = x.t, 2 * x.C
+    _gpu(xt, w, scale, bias, None if residual is None else residual.t)
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    Cout, R, S, Cw = w.shape
+    assert Cw == (3 * C if x3 else C) and w.dtype == torch.bfloat16 and w.is_contiguous() and C % 64 == 0 and Cout % 8 == 0
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    mode = {"bf16": 0, "planes": 1, "f32": 2}[out_mode]
+    if mode == 1:
+        out = torch.empty((N, Ho, Wo, 2 * Cout), dtype=torch.bfloat16, device=x.device)
+    else:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32 if mode == 2 else torch.bfloat16, device=x.device)
+    if residual is not None:
+        assert residual.shape == (N, Ho, Wo, Cout)
+    for v in (scale, bias):
+        assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
+    if max(xt.numel(), w.numel(), out.numel() * (2 if mode == 2 else 1)) * 2 >= 0x7FF00000:
+        raise ValueError("conv2d_sp: an operand of 2 GiB or more; the kernels use 32-bit buffer offsets: lower the "
+                         "frame-stage batch (ClipEngine steps_per_batch) or split the call over M")
+    K = R * S * Cw
+    M = N * Ho * Wo
+    _tok = None
+    if _PROF is not None:
+        _tok = _pb("igemm8_sp_" + ("x3" if x3 else "hi"), 2.0 * M * Cout * K,
+                   xt.numel() * (2.0 if x3 or xt is x else 1.0) + w.numel() * 2.0 + out.numel() * out.element_size()
+                   + (0 if residual is None else residual.t.numel() * 2.0), detail="%dx%dx%d (%dx%d)" % (M, Cout, K, R, S))
+    nb = lib.mega_conv2d_nhwc_workspace_bytes(M, Cout, K) if mode == 2 and residual is None else 0
+    ws = _ws(nb, x.device) if nb else None
+    rc = lib.mega_conv2d_nhwc_sp(_ptr(xt), ldi, 2 * C if x3 else 0, _ptr(w), _ptr(scale), _ptr(bias),
+                                 None if residual is None else _ptr(residual.t), 0, _ptr(out), 0, mode, N, H, W, Cw, Cout,
+                                 R, S, stride, pad, dil, int(relu), _ptr(ws), nb, _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_conv2d_nhwc_sp")
+    return Planes(out, Cout) if mode == 1 else out
+
+
+def linear_sp(x, w3, bias=None, relu=False):
+    """x: Planes [M,K]; w3 = split_conv_weight_x3 of [Nout,K] viewed [Nout,1,1,K] -> f32 [M,Nout] (x.W to ~2^-16)."""
+    M, K = x.shape
+    y = conv2d_sp(Planes(x.t.view(M, 1, 1, 2 * K), K), w3.view(w3.shape[0], 1, 1, 3 * K), None, bias, relu=relu, out_mode="f32")
+    return y.view(M, w3.shape[0])
+
+
 def linear_transposed(w, x, ld, residual=None):
     """Returns (x @ w^T)^T (+ residual) laid out [Nout, ld] with ld >= M and the pad columns zero:
     out[n][m] = sum_k w[n][k] * x[m][k].  The weight matrix plays the GEMM 'A rows' role, so the

@@ -1007,3 +1007,101 @@ def test_fused_bottleneck64_ds_bit_equal_to_unfused(dev, shape):
     torch.cuda.synchronize()
     nd = (got.view(torch.int16) != ref.view(torch.int16)).sum().item()
     assert nd == 0, "%d of %d elements differ (max |d| %.3g)" % (nd, got.numel(), (got.float() - ref.float()).abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ split-precision planes
+SP_CASES = [
+    # N, H, W, C, Cout, R, stride, pad, dil, relu, use_res, out_mode
+    (2, 38, 63, 256, 1024, 1, 1, 0, 1, True, True, "planes"),     # layer3 conv3 + residual (streaming class)
+    (2, 38, 63, 1024, 256, 1, 1, 0, 1, True, False, "planes"),    # layer3 conv1
+    (2, 38, 63, 256, 256, 3, 1, 1, 1, True, False, "planes"),     # layer3 conv2
+    (1, 75, 125, 256, 128, 1, 2, 0, 1, True, False, "planes"),    # stride-2 1x1, Cout < 256 (column mask)
+    (1, 40, 50, 64, 64, 3, 1, 1, 1, True, False, "planes"),       # layer1 conv2: one 64-channel plane per K-tile
+    (1, 19, 23, 512, 2048, 1, 1, 0, 1, True, True, "f32"),        # res5 conv3 + residual -> f32 (ROIAlign input)
+    (1, 19, 23, 512, 512, 3, 1, 2, 2, True, False, "planes"),     # dilated res5 conv2
+    (1, 38, 63, 1024, 1024, 3, 1, 1, 1, True, False, "f32"),      # RPN conv -> f32
+    (1, 17, 13, 128, 520, 1, 1, 0, 1, False, True, "planes"),     # Cout % 256 != 0, M tail, no ReLU
+]
+
+
+def _sp_inputs(case):
+    N, H, W, C, Cout, R, stride, pad, dil, relu, use_res, out_mode = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn((N, H, W, C), generator=g)
+    w = torch.randn((Cout, R, R, C), generator=g) / math.sqrt(C * R * R)
+    scale = torch.rand((Cout,), generator=g) + 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    res = torch.randn((N, Ho, Wo, Cout), generator=g) if use_res else None
+    return x, w, scale, bias, res
+
+
+@pytest.mark.parametrize("case", SP_CASES)
+def test_conv2d_sp_x3_vs_f64(dev, case):
+    """The split-precision conv (planes in, [Wh | Wh | Wl] weights, f32 accumulate) against the f64 convolution of the SAME
+    f32 tensors: error at f32 level (~2^-16 per product, averaging over K), 100x below the bf16 kernel's."""
+    ops = _ops()
+    N, H, W, C, Cout, R, stride, pad, dil, relu, use_res, out_mode = case
+    x, w, scale, bias, res = _sp_inputs(case)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), stride=stride, padding=pad, dilation=dil)
+    ref = ref * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1)
+    if use_res:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    if relu:
+        ref = ref.clamp(min=0)
+    ref = ref.permute(0, 2, 3, 1)
+    xp = ops.split_planes(x.to(dev).contiguous())
+    assert (xp.float().cpu() - x).abs().max() <= 2.0 ** -16 * x.abs().max()          # the planes hold x to ~2^-17
+    rp = ops.split_planes(res.to(dev).contiguous()) if use_res else None
+    y = ops.conv2d_sp(xp, ops.split_conv_weight_x3(w).to(dev), scale.to(dev), bias.to(dev), residual=rp, stride=stride,
+                      pad=pad, dil=dil, relu=relu, out_mode=out_mode, x3=True)
+    got = (y.float() if out_mode == "planes" else y).cpu().double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print("conv2d_sp x3 %s: max err / scale = %.3g" % (case, err))
+    assert got.shape == ref.shape and err < 3e-5, err
+
+
+@pytest.mark.parametrize("case", SP_CASES[:5] + SP_CASES[8:])
+def test_conv2d_sp_hi_plane_bit_equal_to_bf16_kernel(dev, case):
+    """x3=False (the bf16 mode over a wide residual stream): the hi plane is the bf16 kernel's input, so without a
+    residual the rounded output equals the plain bf16 launch bit for bit (out_mode "bf16"; the planes' hi is that value
+    too), and with a split residual the sum is taken against hi + lo in f32."""
+    ops = _ops()
+    N, H, W, C, Cout, R, stride, pad, dil, relu, use_res, out_mode = case
+    x, w, scale, bias, res = _sp_inputs(case)
+    xp = ops.split_planes(x.to(dev).contiguous())
+    wb = w.to(torch.bfloat16).to(dev)
+    sc, bi = scale.to(dev), bias.to(dev)
+    xh = xp.hi().contiguous()
+    plain = ops.conv2d_nhwc(xh, wb, sc, bi, stride=stride, pad=pad, dil=dil, relu=relu)
+    y16 = ops.conv2d_sp(xp, wb, sc, bi, stride=stride, pad=pad, dil=dil, relu=relu, out_mode="bf16", x3=False)
+    assert torch.equal(y16.view(torch.int16), plain.view(torch.int16))
+    yp = ops.conv2d_sp(xp, wb, sc, bi, stride=stride, pad=pad, dil=dil, relu=relu, out_mode="planes", x3=False)
+    assert torch.equal(yp.hi().contiguous().view(torch.int16), plain.view(torch.int16))
+    if use_res:
+        rp = ops.split_planes(res.to(dev).contiguous())
+        f32 = ops.conv2d_nhwc(xh, wb, sc, bi, stride=stride, pad=pad, dil=dil, relu=False, out_dtype=torch.float32)
+        want = f32 + rp.float()
+        if relu:
+            want = want.clamp(min=0)
+        got = ops.conv2d_sp(xp, wb, sc, bi, residual=rp, stride=stride, pad=pad, dil=dil, relu=relu, out_mode="planes",
+                            x3=False).float()
+        # (fma(acc, scale, bias) + residual in f32, then the planes hold it to 2^-17)
+        assert (got - want).abs().max().item() <= 2.0 ** -15 * want.abs().max().item()
+
+
+def test_linear_sp_split_k(dev):
+    """fc0's shape class (K >= 32768: three K ranges + finalize) through the SP kernels"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, K, Nout = 300, 49 * 1024, 1024
+    x = torch.randn((M, K), generator=g)
+    w = torch.randn((Nout, K), generator=g) / math.sqrt(K)
+    b = torch.randn((Nout,), generator=g) * 0.1
+    ref = (x.double() @ w.double().t() + b.double()).clamp(min=0)
+    y = ops.linear_sp(ops.split_planes(x.to(dev)), ops.split_conv_weight_x3(w.view(Nout, 1, 1, K)).to(dev).view(Nout, 3 * K),
+                      b.to(dev), relu=True).cpu().double()
+    err = (y - ref).abs().max().item() / ref.abs().max().item()
+    print("linear_sp split-K: max err / scale = %.3g" % err)
+    assert err < 3e-5
