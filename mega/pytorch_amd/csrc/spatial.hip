@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256, 4) void stem_mfma_kernel(const void* __restric
       for (int r = 0; r < 16; ++r) {
         const int px = (r & 3) + 8 * (r >> 2) + 4 * half;
         *reinterpret_cast<unsigned short*>(smem + ((2 * wave + i) * SM_TX + px) * SM_OUT_PS + ch * 2) =
-            f32_to_bf16(fmaxf(acc[i][j][r] * sc + bi, 0.f));
+            (bf16_t)(f32_to_bf16(fmaxf(acc[i][j][r] * sc + bi, 0.f)) & 0x7fffu);   // (& 0x7fff: fmaxf(-0, 0) may be -0; every ReLU of the path gives +0)
       }
     }
   }
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const void* __restric
           const int r = pix / SP_TX, c = pix - r * SP_TX;
           const int oy = oy0 + r, ox = ox0 + c;
           const bool ok = pix < SP_NPIX && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo;
-          *reinterpret_cast<unsigned short*>(smem + pix * OUT_PS + ch * 2) = ok ? f32_to_bf16(fmaxf(acc[b][j][q] * sc + bi, 0.f)) : (unsigned short)0;
+          *reinterpret_cast<unsigned short*>(smem + pix * OUT_PS + ch * 2) = ok ? (unsigned short)(f32_to_bf16(fmaxf(acc[b][j][q] * sc + bi, 0.f)) & 0x7fffu) : (unsigned short)0;   // +0, never -0: the pool below orders bit patterns
         }
       }
     }

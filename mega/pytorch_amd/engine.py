@@ -66,8 +66,9 @@ class KeyFrameShard(object):
     frame of the batch -- one all-gather each -- and at the end the padded detections.  Nothing of the per-key-frame step is
     replicated.  `wire` (optional dict) accumulates the bytes this rank contributes to each collective."""
 
-    def __init__(self, dist, group, rank, world, base=0, wire=None):
+    def __init__(self, dist, group, rank, world, base=0, wire=None, order=None):
         self.dist, self.group, self.rank, self.world, self.base, self.wire = dist, group, rank, world, base, wire
+        self.order = order                # optional list: the kinds of collectives in the order they were issued (tests)
 
     def owner(self, t):
         return (self.base + t) % self.world
@@ -75,6 +76,8 @@ class KeyFrameShard(object):
     def _count(self, key, t):
         if self.wire is not None:
             self.wire[key] = self.wire.get(key, 0) + t.numel() * t.element_size()
+        if self.order is not None:
+            self.order.append(key)
 
     def gather_rows(self, own, nrows, like):
         """own {t: [n_t, D] rows of my key frames}, nrows[t] for ALL key frames -> list of [n_t, D] for all of them.
@@ -184,9 +187,13 @@ class ClipEngine(object):
         self.owner_aligned = bool(self.batch_aggregation and static_aggregation is False and hasattr(model, "base_num")
                                   and getattr(fe, "cache_memory_kv", False))
         self.wire = {}                    # bytes this rank contributed to each kind of collective (tests, diagnostics)
+        self.wire_order = []              # and the kinds in issue order, with "aggregate" marking the start of a step-batch's
+                                          # aggregation (tests: a batch's frame records are gathered before it is aggregated)
         self.group_agg = dist_group       # the aggregation's collectives run on another stream than the frame stage's:
         if dist_group is not None and self.world > 1:      # their own communicator
-            self.group_agg = self.dist.new_group(list(range(self.world)))
+            # (the members are the ranks of dist_group itself -- a sub-group's global ranks are not 0 .. world-1 -- and
+            #  new_group() is a collective over the DEFAULT group: every process must construct its engine)
+            self.group_agg = self.dist.new_group(self.dist.get_process_group_ranks(dist_group))
         # ramp: every run() call is its own pipeline fill / drain (the first batch's frame stage and the last batch's
         # aggregation have nothing to overlap with).  With ramp=True a call's key frames are split into a SHORT first
         # and last batch (steps_per_batch // 4) around equal middle batches, so the un-overlapped head and tail shrink
@@ -318,7 +325,9 @@ class ClipEngine(object):
             if on_counts is not None:
                 on_counts(a["cnt"])
             return m.frame_stage_b(a, want)
-        key = (tuple(imgs.shape), tuple(int(w) for w in want), imgs.dtype)
+        # (u8 is part of the key: a uint8 clip on the fused-u8 stem path and a preprocessed f32 batch of the same size
+        #  report the same shape and dtype but own different static inputs and graphs -- ADVICE r04)
+        key = (tuple(imgs.shape), tuple(int(w) for w in want), imgs.dtype, bool(u8))
         ent = self._fgraphs.get(key)
         if ent is None:
             self._fgraphs[key] = {}
@@ -450,6 +459,7 @@ class ClipEngine(object):
 
     def _count_wire(self, key, t):
         self.wire[key] = self.wire.get(key, 0) + t.numel() * t.element_size()
+        self.wire_order.append(key)
 
     def records_async(self, clip, jobs, on_counts=None):
         """Enqueue the frame stage for jobs [(frame_id, want, role)]; no host sync.  -> handle for
@@ -709,6 +719,13 @@ class ClipEngine(object):
                 pending, o = [], 0
                 batched = (self.batch_aggregation and (self._static is None or not self.use_static)
                            and m.roi_heads.box.feature_extractor.cache_memory_kv)
+                if self.owner_aligned and not batched and (self.world > 1 or self.force_sharded):
+                    # owner-aligned dealing leaves non-owner ranks with base_num rows of a record: only the batched
+                    # aggregation (one owner per key frame) can consume that; the per-frame path steps every key frame on
+                    # every rank and would silently diverge (cache_memory_kv switched off after construction)
+                    raise RuntimeError("ClipEngine: frames were dealt owner-aligned but the batched aggregation is off "
+                                       "(cache_memory_kv / batch_aggregation changed after construction); build the engine "
+                                       "after setting them")
                 if batched and self._static is not None:
                     self._static.leave()          # the pools go back into the model's deques
                 if not batched and self._sbatch is not None:
@@ -723,7 +740,9 @@ class ClipEngine(object):
                     if self.world > 1 or self.force_sharded:
                         # (legacy dealing: batch position t -> rank t mod world, whole records are everywhere)
                         shard = KeyFrameShard(self.dist, self.group_agg, self.rank, self.world,
-                                              base=prepared[0][0] if self.owner_aligned else 0, wire=self.wire)
+                                              base=prepared[0][0] if self.owner_aligned else 0, wire=self.wire,
+                                              order=self.wire_order)
+                        self.wire_order.append("aggregate")
                     steps = [st for _, st in prepared]
                     sb = self._sbatch
                     if (self.graph_aggregation and self.use_static and shard is None and clip.is_cuda and prepared[0][0] > 0

@@ -127,8 +127,12 @@ def _igemm_family(lib, M, Cout, K, dtype, shape=None):
     kind, t = t // 1000000, t % 1000000
     if kind == 6:
         return "conv64_bf16_3x3"
-    return "igemm%s_%s_%dx%d" % ({8: "8", 7: "8s"}.get(kind, ""), "bf16" if dtype == torch.bfloat16 else "f32", t // 1000,
-                                 t % 1000)
+    # one family = one rocprofv3 symbol: igemm8_kernel<OT, ...> is instantiated per OUTPUT type, so a bf16 launch that writes
+    # f32 (fc0's split-K partial sums, the RPN head's f32 logits) is a different symbol from the bf16-output launches of the
+    # same tile ("_f32out")
+    f32out = shape is not None and dtype == torch.bfloat16 and (shape[-1] == torch.float32 or (kind in (7, 8) and lib.mega_conv2d_nhwc_workspace_bytes(M, Cout, K) > 0))
+    return "igemm%s_%s_%dx%d%s" % ({8: "8", 7: "8s"}.get(kind, ""), "bf16" if dtype == torch.bfloat16 else "f32", t // 1000,
+                                   t % 1000, "_f32out" if f32out else "")
 
 
 def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,

@@ -30,7 +30,7 @@ def _install_cpu_ops():
         setattr(ops, name, getattr(cpu_ops, name))
 
 
-def _build():
+def _build(T=T):
     """R-50 MEGA with a 7-frame window / memory and a 3-frame global pool: 14 key frames wrap every deque."""
     from mega.pytorch_amd import config, modeling, synth
     cfg = config.get_cfg("R-50")
@@ -44,37 +44,41 @@ def _build():
     return cfg, model, frames
 
 
-def _worker(rank, world, port, outdir, spb):
+def _worker(rank, world, port, outdir, spb, T=T, NKEY=NKEY):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     _install_cpu_ops()
     from mega.pytorch_amd import engine
-    cfg, model, frames = _build()
+    cfg, model, frames = _build(T)
     gfor = engine.global_schedule(T, 3, seed=0)
     eng = engine.ClipEngine(model, steps_per_batch=spb, dist_group=dist.group.WORLD, keep_logits=True)
     dets = eng.run(frames, T, gfor, first=0, last=NKEY)
     fe = model.roi_heads.box.feature_extractor
     torch.save({"dets": [(d.bbox, d.get_field("scores"), d.get_field("labels")) for d in dets],
                 "mem": [fe.mem[i]["k"].clone() for i in range(fe.stage)], "frames_computed": eng.frames_computed,
-                "wire": dict(eng.wire), "own_logits": sum(1 for x in eng.logits_log if x is not None)},
+                "wire": dict(eng.wire), "wire_order": list(eng.wire_order),
+                "own_logits": sum(1 for x in eng.logits_log if x is not None)},
                os.path.join(outdir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,spb", [(2, 3), (4, 5)])
-def test_sharded_engine_matches_single_process(world, spb):
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("world,spb,T,NKEY", [(2, 3, 22, 14), (4, 5, 22, 14), (8, 16, 46, 34)])
+def test_sharded_engine_matches_single_process(world, spb, T, NKEY):
+    """world 8 = BASELINE configs[3]'s rank count with bench.py's step-batch rule scaled down (S = 2 N key frames per
+    step-batch instead of 20 N): two full 16-key-frame batches after the cold start, every rank owning two key frames of
+    each."""
     port = 29500 + (os.getpid() * 7 + world) % 2000
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, d, spb), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, d, spb, T, NKEY), nprocs=world, join=True)
         ranks = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(world)]
     _install_cpu_ops()
     torch.set_num_threads(4)
     from mega.pytorch_amd import engine
-    cfg, model, frames = _build()
+    cfg, model, frames = _build(T)
     single_eng = engine.ClipEngine(model, steps_per_batch=spb)
     single = single_eng.run(frames, T, engine.global_schedule(T, 3, seed=0), first=0, last=NKEY)
     assert all(len(r["dets"]) == NKEY for r in ranks) and len(single) == NKEY
@@ -110,23 +114,17 @@ def test_sharded_engine_matches_single_process(world, spb):
     mem_rows = sum(r["wire"]["memory_rows"] for r in ranks) / (D * esz)
     assert mem_rows <= nbatch * world * -(-spb // world) * (10 + 10 + 10), mem_rows
     assert sum(r["own_logits"] for r in ranks) == NKEY         # every key frame aggregated by exactly ONE rank
-
-
-def test_job_schedule_matches_reference_feed():
-    """ClipEngine.jobs_for_step reproduces VIDMEGADataset._get_test (data/datasets/vid_mega.py:95-142) +
-    the frame-0 fill of generalized_rcnn_mega.py:180-193."""
-    _install_cpu_ops()
-    from mega.pytorch_amd import engine
-
-    class M(object):
-        all_frame_interval, key_frame_location, key_num, base_num, global_enable = 25, 12, 300, 75, True
-        cfg = type("C", (), {"INPUT": type("I", (), {"PIXEL_MEAN": (0, 0, 0), "TO_BGR255": True})})
-    eng = engine.ClipEngine(M())
-    gfor = engine.global_schedule(40, 10, seed=0)
-    j0 = eng.jobs_for_step(0, 40, gfor)
-    assert [j[0] for j in j0 if j[2] == "l"] == list(range(13)) and len([j for j in j0 if j[2] == "g"]) == 10
-    assert all(j[1] == 300 for j in j0 if j[2] == "l") and all(j[1] == 75 for j in j0 if j[2] == "g")
-    assert [j[0] for j in eng.jobs_for_step(5, 40, gfor) if j[2] == "l"] == [17]
-    assert [j[0] for j in eng.jobs_for_step(35, 40, gfor) if j[2] == "l"] == [39]      # clamped to seg_len - 1
-    short = eng.jobs_for_step(0, 5, engine.global_schedule(5, 10, seed=0))
-    assert [j[0] for j in short if j[2] == "l"] == [0, 1, 2, 3, 4] + [4] * 8              # short video: tail repeats
+    # ---- order of the collectives (identical on every rank, or the ranks would deadlock / mix buffers): per step-batch the
+    # frame records are gathered BEFORE its aggregation starts, then one memory-row gather per stage set, the detections last
+    for r in ranks[1:]:
+        assert r["wire_order"] == ranks[0]["wire_order"]
+    order = ranks[0]["wire_order"]
+    assert order.count("aggregate") == nbatch
+    pos = [i for i, k in enumerate(order) if k == "aggregate"]
+    for bi, p0 in enumerate(pos):
+        # (the engine enqueues the frame stage of batch i + 1 -- and its record gather -- before it aggregates batch i: what
+        #  must hold is that batch i's records were gathered before ITS aggregation starts)
+        assert order[:p0].count("frame_records") >= bi + 1, (bi, order[:p0])
+        seg = [k for k in order[p0 + 1:pos[bi + 1] if bi + 1 < len(pos) else len(order)] if k != "frame_records"]
+        assert seg.count("detections") == 1 and "memory_rows" in seg[:seg.index("detections")], (bi, seg)
+        assert all(k != "memory_rows" for k in seg[seg.index("detections"):])   # ... and its detections last
