@@ -282,6 +282,11 @@ int mega_split_f32_to_bf16x3(const float* src, void* dst_bf16, int rows, int K, 
 /* dst [rows][2K] bf16 = [hi | lo] of src [rows][K] f32 (K % 8 == 0, both 16-byte aligned). */
 int mega_split_f32_to_planes(const float* src, void* dst_bf16, int rows, int K, void* stream);
 
+/* mega_roi_align_fwd on f32 NHWC features with the pooled rows leaving as planes: out bf16 [K][2 PH PW C] = [hi | lo] of the
+ * f32 row [PH PW C] (same term order as the f32 kernel, ROIAlign_cuda.cu:64-122).  C % 4 == 0. */
+int mega_roi_align_fwd_planes(const float* feat, const float* rois, void* out_planes, int K, int C, int H, int W,
+                              float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, void* stream);
+
 /* conv + FrozenBN (+ split residual) + activation on plane tensors, bf16 matrix cores, f32 accumulation (igemm8 SP kernels):
  *   in       bf16 [N][H][W][ldi]; the contraction runs over Cin channels per tap, SOURCE channel k < kwrap ? k : k - kwrap
  *            (kwrap = 0: no wrap).  Split precision: ldi = 2C, Cin = 3C, kwrap = 2C reads [hi | lo | hi]; with weights

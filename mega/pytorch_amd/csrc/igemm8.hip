@@ -309,6 +309,14 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   //   RAW: L(a,t) waits for A1(t) [6 newer DMAs in flight], L(b,t) for A0 B0 B1 (t+1) [CA1 newer], each one barrier
   //        before the first wave reads them; every half-tile is issued >= 2 segments before the wait that retires it.
 #define MEGA_SB() __builtin_amdgcn_sched_barrier(0)
+  // SP kernels also serve narrow layers (Cout 64 / 128: layer1 / layer2 in the split-precision mode): a wave whose 32 columns
+  // of a B half lie past Cout skips that half's MFMAs (wave-uniform branch; its accumulators stay zero and are never
+  // stored) -- the all-zero columns of a 256-wide tile would otherwise cost 2-4x the layer's matrix-core time.
+  const bool use_b0 = !SP || n0 + wc * 32 < p.Cout, use_b1 = !SP || n0 + 128 + wc * 32 < p.Cout;
+#define MEGA_MMA_IF(c_, acc_, a_, b_) \
+  do {                                 \
+    if (!SP || (c_)) MEGA_MMA(acc_, a_, b_); \
+  } while (0)
   auto tile_phases = [&](auto PAR) {
     constexpr int par = decltype(PAR)::value;
     // ================= phase a: A0 x (B0, B1)
@@ -330,8 +338,8 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      MEGA_MMA(acc[0][0][0], af[0][ks], b0f[ks]); MEGA_MMA(acc[0][1][0], af[1][ks], b0f[ks]);
-      MEGA_MMA(acc[0][0][1], af[0][ks], b1f[ks]); MEGA_MMA(acc[0][1][1], af[1][ks], b1f[ks]);
+      MEGA_MMA_IF(use_b0, acc[0][0][0], af[0][ks], b0f[ks]); MEGA_MMA_IF(use_b0, acc[0][1][0], af[1][ks], b0f[ks]);
+      MEGA_MMA_IF(use_b1, acc[0][0][1], af[0][ks], b1f[ks]); MEGA_MMA_IF(use_b1, acc[0][1][1], af[1][ks], b1f[ks]);
     }
     __builtin_amdgcn_s_setprio(0);
     MEGA_SB();
@@ -357,8 +365,8 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      MEGA_MMA(acc[1][0][1], af[0][ks], b1f[ks]); if (MF1 == 2) MEGA_MMA(acc[1][1][1], af[1][ks], b1f[ks]);
-      MEGA_MMA(acc[1][0][0], af[0][ks], b0f[ks]); if (MF1 == 2) MEGA_MMA(acc[1][1][0], af[1][ks], b0f[ks]);
+      MEGA_MMA_IF(use_b1, acc[1][0][1], af[0][ks], b1f[ks]); if (MF1 == 2) MEGA_MMA_IF(use_b1, acc[1][1][1], af[1][ks], b1f[ks]);
+      MEGA_MMA_IF(use_b0, acc[1][0][0], af[0][ks], b0f[ks]); if (MF1 == 2) MEGA_MMA_IF(use_b0, acc[1][1][0], af[1][ks], b0f[ks]);
       MEGA_SB();
       if (ks == 0) issue_A1(0, 0, par, pa0, ta0 < nkt);
       if (ks == 1) { issue_A1(0, 1, par, pa0, ta0 < nkt); kpos_next(pa0); ++ta0; issue_B1(0, 0, par, tb0, tb0 < nkt); }
@@ -716,6 +724,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #undef MEGA_BAR
 #undef MEGA_MMA
 #undef MEGA_SB
+#undef MEGA_MMA_IF
 #undef MEGA_STAMP
 }
 

@@ -222,7 +222,10 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const T* __restrict__ in,
 // overlapping bilinear taps of neighbouring bins / ROIs miss L2).  Sliced, XCD x (= blockIdx.x & 7) owns the channel
 // slice [x C/8, (x+1) C/8): its working set per frame is 1/8 of the map (1.2 MB for 2048 channels: L2-resident), a
 // block covers 256 / (CV/8) consecutive bins of that slice.  Same arithmetic, same results.
-template <typename T, bool XCD_SLICED>
+// PLANES (f32 input only): the pooled values leave as split-precision planes -- row k of `out` is bf16 [hi | lo] of the
+// [PH PW C] f32 values (hi = bf16(v), lo = bf16(v - hi)): the operand mega_conv2d_nhwc_sp's fc0 reads, written here instead
+// of an f32 tensor that a second pass would have to read back and split (3 + 3 GB per 40-frame batch at C = 2048).
+template <typename T, bool XCD_SLICED, bool PLANES = false>
 __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __restrict__ feat,
                                                                  const float* __restrict__ rois, T* __restrict__ out,
                                                                  int K, int C, int H, int W, float spatial_scale,
@@ -291,11 +294,26 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __rest
                      w4 * Elem<T>::ld(e4 + e));
       }
     }
-    uint4 o;
-    T* oe = reinterpret_cast<T*>(&o);
+    if constexpr (PLANES) {
+      static_assert(!PLANES || sizeof(T) == 4, "planes output: f32 features");
+      float v[4];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] / count);
-    *reinterpret_cast<uint4*>(out + (size_t)bin * C + (size_t)cv * VE) = o;
+      for (int e = 0; e < 4; ++e) v[e] = acc[e] / count;
+      const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+      const unsigned l0 = pack_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+      const unsigned l1 = pack_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+      const size_t plane = (size_t)PH * PW * C;                       // elements per plane of one ROI row
+      unsigned short* row = reinterpret_cast<unsigned short*>(out) + (size_t)k * 2 * plane +
+                            (size_t)(bin - k * PH * PW) * C + (size_t)cv * 4;
+      *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(row + plane) = make_uint2(l0, l1);
+    } else {
+      uint4 o;
+      T* oe = reinterpret_cast<T*>(&o);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] / count);
+      *reinterpret_cast<uint4*>(out + (size_t)bin * C + (size_t)cv * VE) = o;
+    }
   }
 }
 
@@ -942,5 +960,29 @@ extern "C" int mega_stem_pool_bf16(const void* in, int u8, const void* w_n176_bf
   else
     hipLaunchKernelGGL(stem_pool_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)w_n176_bf16, scale,
                        bias, (bf16_t*)out, N, H, W, Ho, Wo, Hp, Wp, 0.f, 0.f, 0.f, 0);
+  return mega_check_launch();
+}
+
+// mega_roi_align_fwd for f32 NHWC features with the result as split-precision planes: out bf16 [K][2 PH PW C] =
+// [hi | lo] of the f32 pooled row [PH PW C] (the same arithmetic, term by term, as the f32 kernel -- ROIAlign_cuda.cu:64-122 --
+// then hi = bf16(v), lo = bf16(v - hi)).  C % 4 == 0.  The A operand of the split-precision fc0 (mega_conv2d_nhwc_sp).
+extern "C" int mega_roi_align_fwd_planes(const float* feat, const float* rois, void* out, int K, int C, int H, int W,
+                                         float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, void* stream) {
+  mega_clear_error();
+  if (K == 0) return MEGA_OK;
+  if (!feat || !rois || !out || K < 0 || C <= 0 || C % 4 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0) return MEGA_ERR_ARG;
+  const int CV = C / 4;
+  const long long total = (long long)K * pooled_h * pooled_w * CV;
+  const bool sliced = CV % 8 == 0 && CV / 8 >= 16 && total / 8 >= 256 * 64;
+  long long nb = ((sliced ? total / 8 : total) + 255) / 256;
+  if (nb > 131072) nb = 131072;
+  dim3 vgrid((unsigned)(sliced ? nb * 8 : nb));
+  hipStream_t st = (hipStream_t)stream;
+  if (sliced)
+    hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, true, true>), vgrid, dim3(256), 0, st, feat, rois, (float*)out, K, C, H,
+                       W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+  else
+    hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, false, true>), vgrid, dim3(256), 0, st, feat, rois, (float*)out, K, C, H,
+                       W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
   return mega_check_launch();
 }

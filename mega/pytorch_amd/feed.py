@@ -178,8 +178,17 @@ class FrameSource(object):
 
         def put(i):
             np.copyto(view[i], futs[i].result())
-        list(self.pool.map(put, range(n)))
-        dev = stage.to(self.device, non_blocking=True)
+        if self.is_cuda and n >= 8:
+            # chunks: the H2D copy of chunk c runs while the workers fill chunk c + 1 of the staging buffer
+            dev = torch.empty(stage.shape, dtype=torch.uint8, device=self.device)
+            nch = 4
+            for c in range(nch):
+                lo, hi = c * n // nch, (c + 1) * n // nch
+                list(self.pool.map(put, range(lo, hi)))
+                dev[lo:hi].copy_(stage[lo:hi], non_blocking=True)
+        else:
+            list(self.pool.map(put, range(n)))
+            dev = stage.to(self.device, non_blocking=True)
         if ev is not None:
             ev.record()
         if self.out_hw == self.in_hw:

@@ -645,17 +645,16 @@ class MEGAFeatureExtractor(_Packed):
         """ROIAlign on the res5 maps -> fc0 + ReLU"""
         pk = self._packed(self.dtype, x5.device)
         if self.mode == "x3":
-            # f32 ROIAlign (exact term order) -> planes -> split-precision fc0, in row chunks: a chunk's planes tensor
+            # f32 ROIAlign (exact term order) writing planes -> split-precision fc0, in row chunks: a chunk's planes tensor
             # ([rows, 2 x 49 C] bf16) stays below the kernels' 2 GiB operand limit.  Rows are independent (split-K depends
             # on K alone), so the chunking does not change a row's bits.
             K = rois5.shape[0]
             per = max(1, min(K, (0x7FF00000 // (4 * self.pooled_c * self.resolution ** 2)) // 64 * 64))
             out = torch.empty((K, self.feat_dim), dtype=torch.float32, device=x5.device)
             for o in range(0, K, per):
-                pooled = ops.roi_align(x5, rois5[o:o + per].contiguous(), self.scale, (self.resolution, self.resolution),
-                                       self.sampling_ratio)
-                out[o:o + per] = ops.linear_sp(ops.split_planes(pooled.view(pooled.shape[0], -1)), pk["fc0_x3"], pk["fc_b"][0],
-                                               relu=True)
+                pooled = ops.roi_align_planes(x5, rois5[o:o + per].contiguous(), self.scale, (self.resolution, self.resolution),
+                                              self.sampling_ratio)
+                out[o:o + per] = ops.linear_sp(pooled, pk["fc0_x3"], pk["fc_b"][0], relu=True)
             return out
         pooled = ops.roi_align(x5, rois5, self.scale, (self.resolution, self.resolution), self.sampling_ratio)
         return ops.linear(pooled.view(pooled.shape[0], -1), pk["fc_w"][0], pk["fc_b"][0], relu=True,

@@ -351,6 +351,25 @@ def roi_align(feat, rois, spatial_scale, pooled, sampling_ratio, in_nhwc=True, o
     return out
 
 
+def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio):
+    """roi_align on f32 NHWC features, the pooled rows as split-precision planes: -> Planes [K, ph*pw*C] (t = bf16
+    [K, 2*ph*pw*C]); equals split_planes(roi_align(...).view(K, -1)) bit for bit, without the f32 tensor in between."""
+    _gpu(feat, rois)
+    lib = _lib.load()
+    B, H, W, C = feat.shape
+    ph, pw = pooled
+    K = rois.shape[0]
+    assert feat.dtype == torch.float32 and feat.is_contiguous() and rois.dtype == torch.float32 and rois.is_contiguous()
+    assert rois.shape[1] == 5 and C % 4 == 0
+    out = torch.empty((K, 2 * ph * pw * C), dtype=torch.bfloat16, device=feat.device)
+    _tok = _pb("roi_align", 0.0, out.numel() * 2 + feat.numel() * 4)
+    rc = lib.mega_roi_align_fwd_planes(_ptr(feat), _ptr(rois), _ptr(out), K, C, H, W, float(spatial_scale), ph, pw,
+                                       int(sampling_ratio), _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_roi_align_fwd_planes")
+    return Planes(out, ph * pw * C)
+
+
 # ------------------------------------------------------------------------------------------------ NMS
 def nms(dets, scores, thr, strict_gt=True):
     """Kept ORIGINAL indices ascending (int64), reference mega_core._C.nms semantics.  One host sync (size)."""

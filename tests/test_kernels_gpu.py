@@ -1105,3 +1105,17 @@ def test_linear_sp_split_k(dev):
     err = (y - ref).abs().max().item() / ref.abs().max().item()
     print("linear_sp split-K: max err / scale = %.3g" % err)
     assert err < 3e-5
+
+
+def test_roi_align_planes_bit_equal_to_split_of_f32(dev):
+    """the f32 ROIAlign writing [hi | lo] planes == split_planes of its f32 output, bit for bit (hot shape: 2048 channels,
+    XCD-sliced grid, and a small unsliced one)"""
+    ops = _ops()
+    for (B, H, W, C, K) in ((2, 38, 63, 2048, 300), (1, 12, 17, 32, 9)):
+        g = torch.Generator().manual_seed(C + K)
+        feat = torch.randn((B, H, W, C), generator=g).to(dev)
+        rois = _random_rois(g, K, B, W * 16, H * 16).to(dev)
+        f32 = ops.roi_align(feat, rois, 1.0 / 16, (7, 7), 0)
+        want = ops.split_planes(f32.view(K, -1).contiguous())
+        got = ops.roi_align_planes(feat, rois, 1.0 / 16, (7, 7), 0)
+        assert got.C == want.C and torch.equal(got.t.view(torch.int16), want.t.view(torch.int16))
