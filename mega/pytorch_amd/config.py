@@ -86,6 +86,9 @@ def _mega_cfg(r50):
         # activations as [hi | lo] bf16 planes, every conv / fc0 as ONE bf16 matrix-core GEMM over K x 3
         # ([hi | lo | hi] . [Wh | Wh | Wl], f32 accumulation: x.W to ~2^-16) -- the parity mode at matrix-core rates
         "F32_CONV": "exact",
+        # with F32_CONV "bf16x3": "auto" = the aggregation head's linear layers (Wq / Wk / Wv projections, stage FCs) run
+        # in split precision too (attention core, position logits, predictor exact f32); "exact" = the whole head exact f32
+        "F32_HEAD_LINEAR": "auto",
         # bfloat16 mode only: "bfloat16" = the residual trunk is a bf16 tensor (rounded at each of the 36 `out += identity`,
         # resnet.py:324-344); "planes" = the trunk is carried as [hi | lo] planes and added in f32 (modeling.conv_mode "wide")
         "RESIDUAL_STREAM": "bfloat16",

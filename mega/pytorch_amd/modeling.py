@@ -585,6 +585,9 @@ class MEGAFeatureExtractor(_Packed):
         self.dtype = compute_dtype(cfg)
         self.stream = stream_dtype(cfg)
         self.mode = conv_mode(cfg)
+        # cfg.F32_HEAD_LINEAR: "auto" (with F32_CONV "bf16x3": the head's Wq / Wk / Wv projections and stage FCs run in
+        # split precision like the frame stage; the attention core, position logits and predictor stay exact f32) | "exact"
+        self.head_x3 = self.mode == "x3" and str(getattr(cfg, "F32_HEAD_LINEAR", "auto")) != "exact"
         if self.mode in ("x3", "wide"):
             for m_ in self.head.modules():
                 if isinstance(m_, Bottleneck):
@@ -598,8 +601,10 @@ class MEGAFeatureExtractor(_Packed):
     def _pack(self, dtype, device):
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         sv = self.stream != dtype      # f32 head stream in bf16 mode: split Wv (relation.project_v)
-        pk = {"local": [RelationWeights(sd, "", "l_", i, dtype, device, with_pos=True, split_v=sv) for i in range(self.stage)],
-              "global": [RelationWeights(sd, "", "g_", i, dtype, device, with_pos=False, split_v=sv)
+        hx3 = self.head_x3             # conv_mode "x3": the head's projections / stage FCs in split precision too
+        pk = {"local": [RelationWeights(sd, "", "l_", i, dtype, device, with_pos=True, split_v=sv, x3=hx3)
+                        for i in range(self.stage)],
+              "global": [RelationWeights(sd, "", "g_", i, dtype, device, with_pos=False, split_v=sv, x3=hx3)
                          for i in range(self.global_res_stage + 1)] if self.global_enable else []}
         # fc0 consumes the bin-major [K, 49, C] ROIAlign output: permute its columns from (c, ph, pw) to (ph, pw, c)
         w0 = self.l_fcs[0].weight.detach()
@@ -614,6 +619,9 @@ class MEGAFeatureExtractor(_Packed):
         if self.conv is not None:
             pk["rc_w"] = _pack_conv(self.conv, dtype).to(device)
             pk["rc_b"] = self.conv.bias.detach().float().to(device).contiguous()
+        if hx3:
+            for i in range(1, self.stage):
+                pk["fc_w"][i] = ops.X3Weight(self.l_fcs[i].weight, device)
         if self.mode == "x3":      # split-precision fc0 (and reduce conv) operands
             pk["fc0_x3"] = ops.split_conv_weight_x3(w0.float().contiguous().view(w0.shape[0], 1, 1, -1)).view(w0.shape[0], -1).to(device)
             if self.conv is not None:

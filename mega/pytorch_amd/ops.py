@@ -230,6 +230,9 @@ def bottleneck64_ds(x, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, bd):
 
 def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None):
     """x [M,K], w [Nout,K] (nn.Linear layout) -> [M,Nout]."""
+    if isinstance(w, X3Weight):      # split-precision: f32 in, f32 out
+        assert x.dtype == torch.float32 and residual is None and scale is None and out_dtype in (None, torch.float32)
+        return linear_sp(split_planes(x.contiguous()), w.w3, bias, relu=relu)
     M, K = x.shape
     y = conv2d_nhwc(x.view(M, 1, 1, K), w.view(w.shape[0], 1, 1, K), scale=scale, bias=bias,
                     residual=None if residual is None else residual.view(M, 1, 1, -1), relu=relu,
@@ -876,7 +879,8 @@ def split_conv_weight_x3(w_ohwi):
     return torch.cat([wh, wh, wl], dim=-1).contiguous()
 
 
-def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_mode="planes", x3=True):
+def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_mode="planes", x3=True,
+              out=None):
     """conv + FrozenBN (+ residual) + activation on split-precision planes (mega_conv2d_nhwc_sp, igemm8 SP kernels).
     x: Planes [N,H,W,C].  x3=True: w = split_conv_weight_x3(W) [Cout,R,S,3C]; the contraction reads the planes as
     [hi | lo | hi] -- x.W to ~2^-16 with f32 accumulation.  x3=False: w plain bf16 [Cout,R,S,C], only the hi plane is read
@@ -896,7 +900,12 @@ def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1
     Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
     mode = {"bf16": 0, "planes": 1, "f32": 2}[out_mode]
-    if mode == 1:
+    ldo = 0
+    if out is not None:      # caller's [N*Ho*Wo, ldo >= Cout] buffer (plain output modes): row stride = its width
+        assert mode != 1 and out.dim() == 2 and out.shape[0] == N * Ho * Wo and out.shape[1] >= Cout and out.is_contiguous()
+        assert out.dtype == (torch.float32 if mode == 2 else torch.bfloat16)
+        ldo = out.shape[1]
+    elif mode == 1:
         out = torch.empty((N, Ho, Wo, 2 * Cout), dtype=torch.bfloat16, device=x.device)
     else:
         out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32 if mode == 2 else torch.bfloat16, device=x.device)
@@ -917,11 +926,47 @@ def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1
     nb = lib.mega_conv2d_nhwc_workspace_bytes(M, Cout, K) if mode == 2 and residual is None else 0
     ws = _ws(nb, x.device) if nb else None
     rc = lib.mega_conv2d_nhwc_sp(_ptr(xt), ldi, 2 * C if x3 else 0, _ptr(w), _ptr(scale), _ptr(bias),
-                                 None if residual is None else _ptr(residual.t), 0, _ptr(out), 0, mode, N, H, W, Cw, Cout,
+                                 None if residual is None else _ptr(residual.t), 0, _ptr(out), ldo, mode, N, H, W, Cw, Cout,
                                  R, S, stride, pad, dil, int(relu), _ptr(ws), nb, _stream())
     _pe(_tok)
     _lib.check(rc, "mega_conv2d_nhwc_sp")
     return Planes(out, Cout) if mode == 1 else out
+
+
+class X3Weight(object):
+    """An f32 linear weight [Nout, K] as the split-precision operand [Wh | Wh | Wl] (bf16 [Nout, 3K]).  ops.linear /
+    ops.linear_transposed take it in place of the f32 matrix and run x.W on the bf16 matrix cores to ~2^-16 with f32
+    accumulation (the aggregation head's projections and stage FCs in conv_mode "x3").  `dtype` reports float32: callers
+    that ask the weight for the dtype of its operands hand over f32 activations."""
+    dtype = torch.float32
+
+    def __init__(self, w32, device):
+        w32 = w32.detach().float()
+        self.shape = tuple(w32.shape)
+        self.w3 = split_conv_weight_x3(w32.contiguous().view(w32.shape[0], 1, 1, w32.shape[1])).view(w32.shape[0], -1).to(device)
+        self.device = self.w3.device
+
+
+def linear_transposed_x3(w, x, ld):
+    """linear_transposed for an X3Weight: out[n][m] = sum_k W[n][k] x[m][k] as f32 [Nout, ld], pad columns zero.  The weight
+    rows are the GEMM's A operand ([Wh | Wh | Wl], plain bf16, K x 3), the activations its B operand as [xh | xl | xh]
+    (ops.split_bf16x3; rows padded with zeros to a multiple of 8: the SP kernels store whole 16-byte vectors along m)."""
+    Nout, K = w.shape
+    M = x.shape[0]
+    assert x.dtype == torch.float32 and x.shape[1] == K and ld >= (M + 7) // 8 * 8
+    M8 = (M + 7) // 8 * 8
+    xs = torch.empty((M8, 3 * K), dtype=torch.bfloat16, device=x.device)
+    if M8 > M:
+        xs[M:].zero_()
+    lib = _lib.load()
+    _gpu(x)
+    rc = lib.mega_split_f32_to_bf16x3(_ptr(x.contiguous()), _ptr(xs), M, K, _stream())
+    _lib.check(rc, "mega_split_f32_to_bf16x3")
+    out = torch.empty((Nout, ld), dtype=torch.float32, device=x.device)
+    if ld > M8:
+        out[:, M8:].zero_()
+    conv2d_sp(w.w3.view(Nout, 1, 1, 3 * K), xs.view(M8, 1, 1, 3 * K), out_mode="f32", x3=False, out=out)
+    return out
 
 
 def linear_sp(x, w3, bias=None, relu=False):
@@ -936,6 +981,9 @@ def linear_transposed(w, x, ld, residual=None):
     out[n][m] = sum_k w[n][k] * x[m][k].  The weight matrix plays the GEMM 'A rows' role, so the
     projected values of one output feature are contiguous over rows m (keys).  residual: [Nout, ld] of the same dtype,
     added in the epilogue (the second pass of a split-weight projection, relation.project_v)."""
+    if isinstance(w, X3Weight):
+        assert residual is None
+        return linear_transposed_x3(w, x, ld)
     _gpu(w, x, residual)
     lib = _lib.load()
     Nout, K = w.shape

@@ -19,7 +19,7 @@ class RelationWeights(object):
     """Kernel-ready weights of one (kind, index) attention: kind 'l_' (local/memory, with position term),
     'g_' (global) or '' (RDN: position term, no u)."""
 
-    def __init__(self, sd, pfx, kind, index, dtype, device, with_pos, split_v=False):
+    def __init__(self, sd, pfx, kind, index, dtype, device, with_pos, split_v=False, x3=False):
         def g(name):
             return sd["%s%s%s.%d%s" % (pfx, kind, name[0], index, name[1])].detach().float()
         ukey = "%s%sus.%d" % (pfx, kind, index)        # RDN's AttentionExtractor (kind '') has no u term
@@ -38,6 +38,11 @@ class RelationWeights(object):
         if split_v and dtype != torch.float32:
             self.wv_lo = (wv32 - self.wv.float().to(wv32.device)).to(device=device, dtype=dtype).contiguous()
         self.bv = g(("Wvs", ".bias")).to(device).contiguous()
+        if x3:      # conv_mode "x3": the three projections as split-precision GEMMs (ops.X3Weight); operands stay f32
+            assert dtype == torch.float32
+            self.wq = ops.X3Weight(g(("Wqs", ".weight")), device)
+            self.wk = ops.X3Weight(g(("Wks", ".weight")), device)
+            self.wv = ops.X3Weight(wv32, device)
         self.with_pos = with_pos
         if with_pos:
             wg = sd["%s%sWgs.%d.weight" % (pfx, kind, index)].detach().float().reshape(16, 64)

@@ -1119,3 +1119,23 @@ def test_roi_align_planes_bit_equal_to_split_of_f32(dev):
         want = ops.split_planes(f32.view(K, -1).contiguous())
         got = ops.roi_align_planes(feat, rois, 1.0 / 16, (7, 7), 0)
         assert got.C == want.C and torch.equal(got.t.view(torch.int16), want.t.view(torch.int16))
+
+
+@pytest.mark.parametrize("M", [1875, 300, 37])
+def test_x3_weight_linear_and_transposed(dev, M):
+    """ops.linear / ops.linear_transposed with an X3Weight (the head's projections in conv_mode "x3") against f64"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M)
+    K, Nout = 1024, 1024
+    x = torch.randn((M, K), generator=g)
+    w = torch.randn((Nout, K), generator=g) / math.sqrt(K)
+    b = torch.randn((Nout,), generator=g) * 0.1
+    xw = ops.X3Weight(w, dev)
+    ref = x.double() @ w.double().t() + b.double()
+    y = ops.linear(x.to(dev), xw, b.to(dev)).cpu().double()
+    assert (y - ref).abs().max().item() / ref.abs().max().item() < 3e-5
+    ld = (M + 31) // 32 * 32
+    yt = ops.linear_transposed(xw, x.to(dev), ld).cpu().double()
+    reft = (x.double() @ w.double().t()).t()
+    assert yt.shape == (Nout, ld) and (yt[:, :M] - reft).abs().max().item() / reft.abs().max().item() < 3e-5
+    assert (yt[:, M:] == 0).all()
