@@ -661,7 +661,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
             if os.path.exists(pmc):
                 ks = json.load(open(pmc))["kernels"]
-                want_ = sym.replace(" ", "")
+                want_ = sym.replace("unsigned short", "bf16").replace(" ", "")      # (tools/pmc_summary.py's short names)
                 k = next((v for name, v in ks.items() if name.replace(" ", "").startswith(want_)), None)
                 if k is None:      # summaries of rounds 1-4: <OT, MF1, CLS, ABL> without the SP parameter
                     k = next((v for name, v in ks.items() if name.replace(" ", "").startswith(want_[:-3])), None)

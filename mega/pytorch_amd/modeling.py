@@ -318,7 +318,9 @@ class ResNet(nn.Module):
         u8_norm = (mean, to_bgr) with x the uint8 frames [N,H,W,3] (bf16 mode): preprocessing fused into the stem.
         conv_mode "x3" / "wide": C4 as an f32 tensor (hi + lo of the planes run_nhwc returns)."""
         y = self.run_nhwc(x, u8_norm)
-        return [_nchw_view(y.float() if isinstance(y, ops.Planes) else y)]
+        if isinstance(y, ops.Planes):      # (the seam's tensor: f32 = hi + lo in mode "x3", the bf16 hi plane in mode "wide")
+            y = y.float() if self.mode == "x3" else y.hi().contiguous()
+        return [_nchw_view(y)]
 
     def run_nhwc(self, x, u8_norm=None):
         """forward() without the NCHW view: -> C4 as a contiguous NHWC tensor, or as ops.Planes (conv_mode "x3" / "wide")"""

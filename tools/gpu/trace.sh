@@ -5,7 +5,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 root=$(pwd)
 # blocks of 40 key frames = two step-batches of 20: the stream tail is F(last batch), B(previous batch), B(last batch)
-args="--steps 40 --steps-per-batch 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-whole-clip --min-seconds 0.01 --max-blocks 3 --no-overlap"
+args="--steps 40 --steps-per-batch 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-h2d-leg --no-whole-clip --min-seconds 0.01 --max-blocks 3 --no-overlap"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $root/$out/t -o t -- python $root/bench.py $args > $root/$out/t.json 2> $root/$out/t.err)
 python - $out <<'PY'
 import sys,csv,glob

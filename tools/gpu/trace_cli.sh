@@ -5,7 +5,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 root=$(pwd)
-args="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-whole-clip --min-seconds 0.01 --max-blocks 4 ${TRACE_ARGS:-}"
+args="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-h2d-leg --no-whole-clip --min-seconds 0.01 --max-blocks 4 ${TRACE_ARGS:-}"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $root/$out/t -o t -- python $root/bench.py $args > $root/$out/t.json 2> $root/$out/t.err)
 python - $out <<'PY'
 import sys,csv,glob,re,json

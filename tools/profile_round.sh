@@ -5,7 +5,7 @@
 # 4. rocprofv3 kernel stats of the bench   5. rocprofv3 PMC passes, ONE counter per pass, kernel trace only
 #    (MI355X_MICROARCH.md HBM section): FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE
 #    -> reduce with tools/pmc_summary.py (per kernel family: HBM bytes per launch, MFMA-busy fraction)
-tag=${1:-r04}
+tag=${1:-r05}
 quick=${2:-}
 out=gpurun_out/$tag
 mkdir -p $out
@@ -19,25 +19,25 @@ else
   timeout 300 python bench.py --no-cpu-baseline > $out/bench_n1.json 2> $out/bench_n1.err; tail -3 $out/bench_n1.err; cut -c1-260 $out/bench_n1.json
 fi
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_n1_driver_cli.json 2> $out/bench_n1_driver_cli.err
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof -o bench -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --min-seconds 1 > $root/$out/bench_under_rocprof.json 2> $root/$out/prof.err); ls $out/prof | head -3
-pmcargs="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-whole-clip --no-graphs --no-overlap --min-seconds 0.01 --max-blocks 1"
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof -o bench -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-h2d-leg --min-seconds 1 > $root/$out/bench_under_rocprof.json 2> $root/$out/prof.err); ls $out/prof | head -3
+pmcargs="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-h2d-leg --no-whole-clip --no-graphs --no-overlap --min-seconds 0.01 --max-blocks 1"
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ${EXTRA_PMC:-}; do
   (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/$out/pmc_$c -o pmc -- python $root/bench.py $pmcargs > $root/$out/pmc_$c.json 2> $root/$out/pmc_$c.err); ls -la $out/pmc_$c | tail -1
 done
 # keep only what the reducers need (the kernel-trace CSVs are large)
 rm -f $out/pmc_*/pmc_kernel_trace.csv $out/prof/bench_kernel_trace.csv
 # the RCCL collectives of the sharded aggregation on ONE GPU (world 1, every key frame owned by rank 0)
-MEGA_FORCE_SHARDED=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_forced_sharded.json 2> $out/bench_n1_forced_sharded.err
-timeout 300 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_100step_blocks.json 2> $out/bench_n1_100step_blocks.err
-# A/B legs on the same box: the round-3 head (bf16 activation stream), the eager aggregation, the unfused layer1 blocks
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --head-stream bfloat16 > $out/bench_n1_bf16_head_stream.json 2> $out/bench_n1_bf16_head_stream.err
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --aggregation batched-eager > $out/bench_n1_eager_aggregation.json 2> $out/bench_n1_eager_aggregation.err
-MEGA_FUSE_BOTTLENECK=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_unfused_layer1.json 2> $out/bench_n1_unfused_layer1.err
-MEGA_ATTN_SEGMENTS=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_copied_key_sets.json 2> $out/bench_n1_copied_key_sets.err
-MEGA_L3_SPLIT=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_layer3_in_two_halves.json 2> $out/bench_n1_layer3_in_two_halves.err
-MEGA_STEM_POOL=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_stem_pool_two_kernels.json 2> $out/bench_n1_stem_pool_two_kernels.err
-timeout 300 python bench.py --steps 20 --warmup 5 --steps-per-batch 10 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_two_batches_per_block.json 2> $out/bench_n1_two_batches_per_block.err
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg > $out/bench_n1_driver_cli_again.json 2> $out/bench_n1_driver_cli_again.err
+leg="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-h2d-leg"
+MEGA_FORCE_SHARDED=1 timeout 300 python bench.py $leg > $out/bench_n1_forced_sharded.json 2> $out/bench_n1_forced_sharded.err
+timeout 300 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-h2d-leg > $out/bench_n1_100step_blocks.json 2> $out/bench_n1_100step_blocks.err
+# round 5's modes as the main configuration (kernel families of each in the line)
+timeout 300 python bench.py --steps 20 --warmup 5 --dtype bf16x3 --no-cpu-baseline --no-f32-leg --no-h2d-leg --min-seconds 2 > $out/bench_n1_bf16x3.json 2> $out/bench_n1_bf16x3.err
+timeout 300 python bench.py --steps 20 --warmup 5 --dtype wide --no-cpu-baseline --no-f32-leg --no-h2d-leg --min-seconds 2 > $out/bench_n1_wide_trunk.json 2> $out/bench_n1_wide_trunk.err
+# A/B legs on the same box: the round-3 head (bf16 activation stream), the unfused layer1 blocks, two batches per block
+timeout 300 python bench.py $leg --head-stream bfloat16 > $out/bench_n1_bf16_head_stream.json 2> $out/bench_n1_bf16_head_stream.err
+MEGA_FUSE_BOTTLENECK=0 timeout 300 python bench.py $leg > $out/bench_n1_unfused_layer1.json 2> $out/bench_n1_unfused_layer1.err
+timeout 300 python bench.py $leg --steps-per-batch 10 > $out/bench_n1_two_batches_per_block.json 2> $out/bench_n1_two_batches_per_block.err
+timeout 300 python bench.py $leg > $out/bench_n1_driver_cli_again.json 2> $out/bench_n1_driver_cli_again.err
 for f in $out/bench_n1*.err; do echo "$(basename $f .err): $(grep -h "\] timed region:" $f | head -1 | cut -c1-150)"; done | tee $out/ab_legs.txt
 # kernel timeline of the steady state (per-kernel busy time of one step-batch: tools/trace_summary.py)
 bash tools/gpu/trace.sh $tag/trace > /dev/null 2>&1; python tools/trace_summary.py $out/trace/tail.csv > $out/trace_summary.txt 2>&1; head -3 $out/trace_summary.txt
@@ -46,4 +46,4 @@ timeout 120 python tools/gpu/bneck_bench.py > $out/bneck_bench.txt 2>&1; tail -5
 # the other BASELINE configurations
 for c in 1 2 5; do timeout 300 python tools/bench_configs.py --config $c > $out/config$c.json 2> $out/config$c.err; cut -c1-160 $out/config$c.json; done
 timeout 300 python tools/bench_configs.py --config 1 --dtype float32 --no-cpu-baseline > $out/config1_f32.json 2> $out/config1_f32.err; cut -c1-160 $out/config1_f32.json
-grep -E "ATTRIBUTION|^H |^F bf16|^B bf16|CALIBRATED|calibrated f32|config [125]|cfg[15] |R-101 600x1000|roi_align bf16|bf16 key frame|graph aggregation:|common-mode" $out/pytest_gpu.log | cut -c1-460 > $out/pytest_prints.txt
+grep -E "ATTRIBUTION|^H |^F bf16|^B bf16|^W wide|^X bf16x3|^bf16x3 |CALIBRATED|calibrated f32|config [125]|cfg[15] |R-101 600x1000|roi_align bf16|bf16 key frame|graph aggregation:|common-mode|conv2d_sp x3|linear_sp" $out/pytest_gpu.log | cut -c1-460 > $out/pytest_prints.txt
