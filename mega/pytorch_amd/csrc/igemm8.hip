@@ -457,10 +457,22 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
     float scv[OVE], biv[OVE];
     {
       const bool colok = !SP || ncol < p.Cout;
+      // (16-byte loads when the vectors are 16-byte aligned -- every tensor torch allocates is; element loads otherwise:
+      //  the C ABI does not promise an alignment for scale / bias)
+      const bool al16 = ((reinterpret_cast<size_t>(p.scale) | reinterpret_cast<size_t>(p.bias)) & 15) == 0;
 #pragma unroll
       for (int t = 0; t < OVE; t += 4) {
-        const f32x4_t s4 = p.scale && colok ? *reinterpret_cast<const f32x4_t*>(p.scale + ncol + t) : f32x4_t{1.f, 1.f, 1.f, 1.f};
-        const f32x4_t b4 = p.bias && colok ? *reinterpret_cast<const f32x4_t*>(p.bias + ncol + t) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        f32x4_t s4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+        if (al16) {
+          if (p.scale && colok) s4 = *reinterpret_cast<const f32x4_t*>(p.scale + ncol + t);
+          if (p.bias && colok) b4 = *reinterpret_cast<const f32x4_t*>(p.bias + ncol + t);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (p.scale && colok) s4[u] = p.scale[ncol + t + u];
+            if (p.bias && colok) b4[u] = p.bias[ncol + t + u];
+          }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { scv[t + u] = s4[u]; biv[t + u] = b4[u]; }
       }
