@@ -30,7 +30,17 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
     return y.contiguous().to(out_dtype or x.dtype)
 
 
+def _w32(w):
+    """an ops.X3Weight as its f32 matrix Wh + Wl"""
+    from mega.pytorch_amd import ops
+    if isinstance(w, ops.X3Weight):
+        K = w.shape[1]
+        return w.w3[:, :K].float() + w.w3[:, 2 * K:].float()
+    return w
+
+
 def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None):
+    w = _w32(w)
     M, K = x.shape
     y = conv2d_nhwc(x.view(M, 1, 1, K), w.view(w.shape[0], 1, 1, K), scale=scale, bias=bias,
                     residual=None if residual is None else residual.view(M, 1, 1, -1), relu=relu, out_dtype=out_dtype)
@@ -38,6 +48,7 @@ def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=Non
 
 
 def linear_transposed(w, x, ld, residual=None):
+    w = _w32(w)
     out = torch.zeros((w.shape[0], ld), dtype=x.dtype)
     y = (x.float() @ w.float().t()).t()
     if residual is not None:
@@ -228,7 +239,51 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
     return (out, w[:, 0]) if want_weights else out
 
 
-ALL = ["cast_bf16", "cat_rows_cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+# ---- split-precision planes (conv_mode "x3" / "wide"): the twins compute on hi + lo (or hi) in f32 and re-split
+def _planes(x32):
+    from mega.pytorch_amd import ops
+    hi = x32.to(torch.bfloat16)
+    lo = (x32 - hi.float()).to(torch.bfloat16)
+    return ops.Planes(torch.cat([hi, lo], dim=-1).contiguous(), x32.shape[-1])
+
+
+def split_planes(x):
+    return _planes(x.float())
+
+
+def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_mode="planes", x3=True,
+              out=None):
+    from mega.pytorch_amd import ops
+    if isinstance(x, ops.Planes):
+        C = x.C
+        xin = x.float() if x3 else x.hi().float()
+    else:
+        C, xin = x.shape[-1], x.float()
+    w32 = (w[..., :C].float() + w[..., 2 * C:].float()) if x3 else w.float()      # [Wh | Wh | Wl] -> Wh + Wl
+    assert w32.shape[-1] == C
+    y = conv2d_nhwc(xin, w32, scale, bias, None if residual is None else residual.float(), stride, pad, dil, relu,
+                    out_dtype=torch.float32)
+    if out is not None:
+        out[:, :y.shape[-1]] = y.reshape(out.shape[0], -1).to(out.dtype)
+        return out
+    return _planes(y) if out_mode == "planes" else y.to(torch.float32 if out_mode == "f32" else torch.bfloat16)
+
+
+def linear_sp(x, w3, bias=None, relu=False):
+    M, K = x.shape
+    w32 = w3[:, :K].float() + w3[:, 2 * K:].float()
+    y = x.float() @ w32.t()
+    if bias is not None:
+        y = y + bias
+    return F.relu(y) if relu else y
+
+
+def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio):
+    y = roi_align(feat, rois, spatial_scale, pooled, sampling_ratio)
+    return _planes(y.reshape(y.shape[0], -1).float())
+
+
+ALL = ["split_planes", "conv2d_sp", "linear_sp", "roi_align_planes", "cast_bf16", "cat_rows_cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames", "position_logits_batched",
        "relation_attention_batched", "postprocess_batched"]
 

@@ -695,3 +695,54 @@ def test_static_batch_aggregation_equals_eager(monkeypatch):
         for t in range(S):
             for j in range(4):
                 assert torch.equal(want[t][j], got[t][j])
+
+
+@pytest.mark.parametrize("mode", ["x3", "wide"])
+def test_planes_modes_run_the_same_detector_on_cpu_twins(monkeypatch, mode):
+    """conv_mode "x3" (cfg.F32_CONV = bf16x3) and "wide" (cfg.RESIDUAL_STREAM = planes): the host plumbing of the planes
+    path -- Bottleneck.run_sp through layer1-3 and res5, the RPN head on a planes C4, fc0 in row chunks on ROIAlign's planes
+    output, the head's X3Weight linears -- on CPU twins that compute hi + lo in f32.  The x3 twin differs from the f32
+    detector only by the planes' 2^-17 representation error: same proposals to 1e-2 px, logits to 1e-3, same detections as
+    a set; the wide twin additionally rounds conv inputs to bf16, so it is only checked to run the whole path with sane
+    outputs (shapes, counts, finite scores)."""
+    cpu_ops.install(monkeypatch)
+    monkeypatch.setattr(modeling, "_FUSE_STEM_POOL", False)      # (the bf16 stem + pool kernel has no twin: two twins instead)
+    torch.set_num_threads(8)
+    from mega.pytorch_amd import engine
+    H, W, T, nkey = 96, 128, 16, 3
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    frames = synth.preprocess_cpu(synth.make_clip(T, H, W, seed=2))
+
+    def run(cfgmod):
+        cfg = _small_cfg()
+        cfgmod(cfg)
+        model = modeling.build_detection_model(cfg)
+        model.load_state_dict(sd)
+        assert modeling.conv_mode(cfg) == {"f": "f32", "x": "x3", "w": "wide"}[cfgmod.__name__[0]]
+        eng = engine.ClipEngine(model, steps_per_batch=2, keep_logits=True)
+        dets = eng.run(frames, T, engine.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0), first=0, last=nkey)
+        return dets, eng
+
+    def f32(cfg):
+        pass
+
+    def x3(cfg):
+        cfg.F32_CONV = "bf16x3"
+
+    def wide(cfg):
+        cfg.DTYPE, cfg.RESIDUAL_STREAM = "bfloat16", "planes"
+    ref, eref = run(f32)
+    got, eg = run(x3 if mode == "x3" else wide)
+    assert len(got) == nkey
+    for k in range(nkey):
+        assert torch.isfinite(got[k].get_field("scores")).all() and got[k].bbox.shape[1] == 4
+        if mode == "wide":
+            assert abs(len(got[k]) - len(ref[k])) <= max(3, 0.1 * len(ref[k]))
+            continue
+        assert (eg.key_boxes_log[k] - eref.key_boxes_log[k]).abs().max() < 1e-2
+        assert (eg.logits_log[k] - eref.logits_log[k]).abs().max() < 1e-3
+        assert len(got[k]) == len(ref[k])
+        # (the seeded model's class scores are near-ties: a 1e-4 logit difference moves single detections across the
+        #  300-detection cut / an NMS tie; the sorted score lists agree in the bulk)
+        ds = (got[k].get_field("scores").sort().values - ref[k].get_field("scores").sort().values).abs()
+        assert ds.median() < 1e-4 and ds.max() < 5e-3
