@@ -245,13 +245,15 @@ def cpu_baseline(arch, sd, H, W, n_timed):
     from oracle import mega_oracle as mo
     from mega.pytorch_amd import synth
     avail = host_cores()
-    cores = min(avail, 64)
+    cores = min(avail, 16)       # the untimed fill: torch-CPU on this path is fastest at 8-32 threads (sweep below)
     torch.set_num_threads(cores)
     log("cpu baseline: fill on %d threads (affinity %d, cpu_count %s)" % (cores, avail, os.cpu_count()))
     r50 = arch.startswith("R-50")
     ocfg = mo.OracleCfg(blocks=(3, 4, 6) if r50 else (3, 4, 23), reduce_channel=r50, global_res_stage=0 if r50 else 1)
     fill = ocfg.all_frame_interval + 1            # key frames 0..25: every memory deque holds 25 entries afterwards
-    sweep = sorted(set(c for c in (8, 32, 64, avail) if c <= avail))
+    # never more than 64: on the 256-thread MI355X hosts ONE steady key frame took 247 s at 256 threads (2.6 s at 8, 2.7 s at
+    # 32, 4.0 s at 64: profiles/r05_bench_n1.json) -- torch's intra-op pool thrashes on this path's many small ops
+    sweep = sorted(set(c for c in (8, 16, 32, 64) if c <= avail)) or [avail]
     T = fill + len(sweep) + n_timed + 13
     frames = synth.preprocess_cpu(synth.make_clip(8, H, W, seed=0))
     frames = frames[torch.arange(T) % frames.shape[0]]
