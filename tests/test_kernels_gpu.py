@@ -1139,3 +1139,27 @@ def test_x3_weight_linear_and_transposed(dev, M):
     reft = (x.double() @ w.double().t()).t()
     assert yt.shape == (Nout, ld) and (yt[:, :M] - reft).abs().max().item() / reft.abs().max().item() < 3e-5
     assert (yt[:, M:] == 0).all()
+
+
+def test_conv_scale_bias_at_unaligned_addresses(dev):
+    """The C ABI promises no alignment for the FrozenBN vectors: igemm8's read-out takes 16-byte loads only when both
+    pointers are 16-byte aligned and element loads otherwise -- same bits either way (plain and SP kernels)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C, Cout = 2, 38, 63, 256, 512
+    x = torch.randn((N, H, W, C), generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn((Cout, 1, 1, C), generator=g) / 16).to(torch.bfloat16).to(dev)
+    sc = (torch.rand((Cout + 8,), generator=g) + 0.5).to(dev)
+    bi = (torch.randn((Cout + 8,), generator=g) * 0.1).to(dev)
+    a_s, a_b = sc[:Cout].clone(), bi[:Cout].clone()                  # 16-byte aligned copies
+    u_s, u_b = sc[1:Cout + 1], bi[3:Cout + 3]                         # 4-byte aligned views
+    u_s.copy_(a_s); u_b.copy_(a_b)
+    assert u_s.data_ptr() % 16 != 0 and u_b.data_ptr() % 16 != 0 and u_s.is_contiguous()
+    ya = ops.conv2d_nhwc(x, w, a_s, a_b, relu=True)
+    yu = ops.conv2d_nhwc(x, w, u_s, u_b, relu=True)
+    assert torch.equal(ya.view(torch.int16), yu.view(torch.int16))
+    xp = ops.split_planes(x.float())
+    w3 = ops.split_conv_weight_x3(w.float())
+    pa = ops.conv2d_sp(xp, w3, a_s, a_b, relu=True, out_mode="f32")
+    pu = ops.conv2d_sp(xp, w3, u_s, u_b, relu=True, out_mode="f32")
+    assert torch.equal(pa, pu)
