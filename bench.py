@@ -59,6 +59,7 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+HALF_MODES = ("bfloat16", "wide", "float16")      # --dtype values whose frame stage runs on 16-bit matrix-core operands
 ALGO_GFLOP_PER_FRAME = 729.0   # minimal algorithmic work per steady-state key frame, R-101 MEGA
 
 
@@ -68,8 +69,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=60)     # three step-batches of 20 key frames
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--arch", default="R-101")
-    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32", "bf16x3", "wide"],
-                    help="bfloat16 (BASELINE configs[2], the headline) | float32 (exact-f32 MFMA parity mode) | bf16x3 (float32 "
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16", "float32", "bf16x3", "wide"],
+                    help="bfloat16 (BASELINE configs[2], the headline) | float16 (the same kernels on IEEE-half operands: the "
+                         "frame stage in fp16, 11 significant bits at the bf16 rate) | float32 (exact-f32 MFMA parity mode) | bf16x3 (float32 "
                          "with the split-precision frame stage, cfg.F32_CONV) | wide (bfloat16 with the residual trunk as "
                          "[hi | lo] planes, cfg.RESIDUAL_STREAM)")
     ap.add_argument("--steps-per-batch", type=int, default=0,
@@ -311,6 +313,12 @@ def cpu_baseline(arch, sd, H, W, n_timed):
                          min(mem))}
 
 
+# what tests/test_e2e_gpu.py::test_r101_600x1000_f16_vs_oracle / test_r101_calibrated_f16_agreement assert for the fp16 mode
+F16_PARITY = ("against the f32 oracle, R-101 600x1000, 28 key frames incl. the memory-full regime: see "
+              "tests/test_e2e_gpu.py::test_r101_600x1000_f16_vs_oracle (seeded fixture) and test_r101_calibrated_f16_agreement "
+              "(fixture with margins); predicted on the CPU twins before the kernels existed: profiles/r06_fp16_prediction.txt")
+
+
 def f32_parity_leg(args, device, clip, gfor, T, spb, mode="float32", head_mode=None):
     """mode "bf16x3": the split-precision parity mode (cfg.F32_CONV = "bf16x3": the frame stage's convs / fc0 as bf16
     matrix-core GEMMs over [hi | lo | hi] . [Wh | Wh | Wl], f32 accumulation; aggregation head exact f32) -- pinned by
@@ -364,6 +372,19 @@ def f32_parity_leg(args, device, clip, gfor, T, spb, mode="float32", head_mode=N
     el = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     fps = spb / el
     x3 = mode == "bf16x3"
+    if mode == "float16":
+        out = {"dtype": "f16 (frame stage on IEEE-half operands: v_mfma_f32_32x32x16_f16, 11 significant bits at the bf16 MFMA rate "
+                        "and bytes; f32 accumulation; the head is the bf16 head on an f32 activation stream)",
+               "fps": round(fps, 2), "ms_per_key_frame": round(1e3 * el / spb, 4),
+               "frac_of_2500TF": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / 2500e12, 4) if args.arch == "R-101" else None,
+               "peak_tflops": 2500.0, "key_frames_per_block": spb, "timed_blocks": len(blocks),
+               "timed_blocks_ms": [round(1e3 * b, 2) for b in blocks], "pools_full": bool(st0["pools_full"]),
+               "graph_captures_in_timed_region": (g1["captured"] - g0["captured"]) + (g1["eager"] - g0["eager"])
+               + (g1.get("agg_captured", 0) - g0.get("agg_captured", 0)),
+               "parity": F16_PARITY}
+        del runner, model, frame_model
+        torch.cuda.empty_cache()
+        return out
     out = {"dtype": ("bf16x3 (f32 activations as bf16 [hi | lo] planes, 3 bf16 MFMA passes per product, f32 accumulation; %s)"
                      % ("f32 head" if head_mode is None else "bf16 head on an f32 activation stream")) if x3 else "f32", "fps": round(fps, 2), "ms_per_key_frame": round(1e3 * el / spb, 4),
            "frac_of_157TF": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / 157.3e12, 4) if args.arch == "R-101" else None,
@@ -442,7 +463,7 @@ def main():
     max_blocks = max(1, min(args.max_blocks, -(-6000 // KF)))
     prof_steps = 0 if args.no_roofline else spb       # the instrumented pass runs the steady batch shape
     # (+ the with-H2D leg's blocks: one GPU only -- the clip is resident on every rank, 1.8 MB per frame)
-    h2d_T = (62 * KF + 40 * max(spb, 1) + 8) if (world == 1 and not args.no_h2d_leg and args.dtype in ("bfloat16", "wide")) else 0
+    h2d_T = (62 * KF + 40 * max(spb, 1) + 8) if (world == 1 and not args.no_h2d_leg and args.dtype in HALF_MODES) else 0
     T = pre + KF + extra_cap + KF * max_blocks + 2 * prof_steps + 1 + KF + 13 + h2d_T
     clip = make_clip(T, args.height, args.width, device)
     gfor = eng.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
@@ -546,7 +567,7 @@ def main():
     #      test-time feed) copies each step-batch's frames into pinned staging buffers and issues ONE async H2D copy per
     #      batch; the engine, its graphs and the video state are the ones of the timed region.
     h2d_leg = None
-    if world == 1 and not args.no_h2d_leg and args.dtype in ("bfloat16", "wide"):
+    if world == 1 and not args.no_h2d_leg and args.dtype in HALF_MODES:
         try:
             from mega.pytorch_amd import feed
             host = clip[:16].cpu().numpy()
@@ -625,10 +646,10 @@ def main():
         # instrumented pass of the timed configuration.  igemm8's streaming launch class ("igemm8s_*": 1x1 layers with
         # K <= 512, bound by HBM / the CU fetch rate) is reported in roofline_hbm; every other igemm symbol (fc0's f32-output
         # split-K launch among them) has its own row in roofline_mfma.
-        tag = "bf16" if args.dtype in ("bfloat16", "wide") else "f32"
+        tag = "f16" if args.dtype == "float16" else ("bf16" if args.dtype in ("bfloat16", "wide") else "f32")
         igemms = {k: v for k, v in summ.items() if k.startswith(("igemm_" + tag, "igemm8_" + tag, "igemm8s_" + tag, "igemm8_sp"))}
         mm = {k: v for k, v in igemms.items() if not k.startswith("igemm8s_")}
-        peak = 2500.0 if args.dtype in ("bfloat16", "wide", "bf16x3") else 157.3
+        peak = 2500.0 if args.dtype in HALF_MODES + ("bf16x3",) else 157.3
 
         def symbol_of(famname):
             """profiler family -> the rocprofv3 symbol of its launches"""
@@ -637,10 +658,10 @@ def main():
             parts = famname.split("_")
             t_ = parts[2].split("x")
             f32o = famname.endswith("_f32out")
-            if parts[0] in ("igemm8", "igemm8s"):
-                return "igemm8_kernel<%s, %d, %d, 0, 0>" % ("float" if f32o else "unsigned short", 2 if t_[0] == "256" else 1,
-                                                            1 if parts[0] == "igemm8s" else 0)
-            et = "unsigned short" if parts[1] == "bf16" else "float"
+            et = {"bf16": "unsigned short", "f16": "_Float16"}.get(parts[1], "float")
+            if parts[0] in ("igemm8", "igemm8s"):      # <OT, MF1, CLS, ABL, SP, HT> (HT: the 16-bit operand type, round 6)
+                return "igemm8_kernel<%s, %d, %d, 0, 0, %s>" % ("float" if f32o else et, 2 if t_[0] == "256" else 1,
+                                                                1 if parts[0] == "igemm8s" else 0, et)
             return "igemm_kernel<%s, %s, %s, %s>" % (et, "float" if (f32o or parts[1] == "f32") else et, t_[0], t_[1])
         for k, v in sorted(mm.items(), key=lambda kv: -kv[1]["ms"]):
             a_ = v["flops"] / (v["ms"] * 1e9) if v["ms"] > 0 else 0.0
@@ -661,14 +682,19 @@ def main():
         # profiled run of this code, not of this run.
         traffic, traffic_src = None, None
         sym = symbol_of(dom)
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
-            pmc = os.path.join(ROOT, "profiles", rnd + "_pmc_summary.json")
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", rnd + ("_f16" if args.dtype == "float16" else "") + "_pmc_summary.json")
             if os.path.exists(pmc):
                 ks = json.load(open(pmc))["kernels"]
                 want_ = sym.replace("unsigned short", "bf16").replace(" ", "")      # (tools/pmc_summary.py's short names)
                 k = next((v for name, v in ks.items() if name.replace(" ", "").startswith(want_)), None)
+                if k is None:      # summaries of round 5: <OT, MF1, CLS, ABL, SP> without the operand-type parameter
+                    w5 = want_[:want_.rindex(",")] + ">"
+                    k = next((v for name, v in ks.items() if name.replace(" ", "").startswith(w5)), None)
                 if k is None:      # summaries of rounds 1-4: <OT, MF1, CLS, ABL> without the SP parameter
-                    k = next((v for name, v in ks.items() if name.replace(" ", "").startswith(want_[:-3])), None)
+                    w4 = want_[:want_.rindex(",")]
+                    w4 = w4[:w4.rindex(",")]
+                    k = next((v for name, v in ks.items() if name.replace(" ", "").startswith(w4)), None)
                 if k:
                     traffic, traffic_src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/%s_pmc_summary.json" % rnd
                     break
@@ -748,8 +774,13 @@ def main():
     except Exception as e:  # noqa: BLE001  (an optional extra must never cost the headline line)
         log("whole-clip measurement skipped: %r" % (e,))
 
-    f32_leg = x3_leg = None
+    f32_leg = x3_leg = f16_leg = None
     if world == 1 and args.dtype == "bfloat16" and not args.no_f32_leg:
+        try:
+            f16_leg = f32_parity_leg(args, device, clip, gfor, T, spb, mode="float16")
+            log("fp16-mode leg: %.1f frames/s (%.3f ms per key frame)" % (f16_leg["fps"], f16_leg["ms_per_key_frame"]))
+        except Exception as e:  # noqa: BLE001  (an extra leg must never cost the headline line)
+            log("fp16-mode leg skipped: %r" % (e,))
         try:
             f32_leg = f32_parity_leg(args, device, clip, gfor, T, spb)
             log("f32 parity-mode leg: %.1f frames/s (%.3f ms per key frame, %.3f of the 157 TF/s f32 MFMA peak)" % (
@@ -775,7 +806,7 @@ def main():
             "metric": "frames/sec MEGA %s inference, %dx%d VID clip" % (args.arch, args.width, args.height),
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": live_world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bfloat16": "bf16", "wide": "bf16", "bf16x3": "bf16x3"}.get(args.dtype, "f32"), "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bfloat16": "bf16", "wide": "bf16", "bf16x3": "bf16x3", "float16": "f16"}.get(args.dtype, "f32"), "data": "synthetic",
             "config": {"workload": "MEGA %s-C4, %dx%d frames, 25 local + 10 global frames + 25-frame memory, "
                                    "300 key / 75 ref proposals, 3 attention stages (BASELINE configs[2]%s)"
                                    % (args.arch, args.width, args.height, "" if world == 1 else " sharded = configs[3]"),
@@ -798,9 +829,9 @@ def main():
                        "avg_detections": round(ndet, 1),
                        "key_proposals_last_frame": int(model.records[model.key_frame_location]["boxes"].shape[0]),
                        "whole_clip_incl_cold_start": whole_clip,
-                       "head_stream": str(getattr(cfg, "HEAD_STREAM", None)) if args.dtype in ("bfloat16", "wide") else "float32",
+                       "head_stream": str(getattr(cfg, "HEAD_STREAM", None)) if args.dtype in HALF_MODES else "float32",
                        "conv_mode": modeling_conv_mode,
-                       "f32_parity_mode": f32_leg, "bf16x3_parity_mode": x3_leg, "with_h2d": h2d_leg},
+                       "fp16_mode": f16_leg, "f32_parity_mode": f32_leg, "bf16x3_parity_mode": x3_leg, "with_h2d": h2d_leg},
             "roofline": roofline, "roofline_mfma": roofline_mfma, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
             "kernel_families": fam,
         }

@@ -7,7 +7,10 @@
  *     3 = workspace too small.  Nothing is allocated inside: the caller owns outputs and workspaces.
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All work is
  *     enqueued on that stream; no call synchronises the device or copies to the host.
- *   - dtype codes: MEGA_F32 = 0 (exact-f32 MFMA path, parity mode), MEGA_BF16 = 1.
+ *   - dtype codes: MEGA_F32 = 0 (exact-f32 MFMA path, parity mode), MEGA_BF16 = 1, MEGA_F16 = 2 (IEEE half: the same
+ *     kernels instantiated for _Float16 operands -- the bf16 MFMA rate and bytes with 11 significant bits instead of 8,
+ *     values bounded by 65 504; accumulation is f32 in every mode).  Wherever an entry point takes a dtype code, MEGA_F16
+ *     is accepted where MEGA_BF16 is, unless its comment says otherwise (the split-precision plane kernels are bf16 only).
  *   - activations are NHWC; GEMM weights are OHWI ([Cout][R][S][Cin]) so both operands are K-contiguous.
  *
  * Each prototype cites the reference interface it replaces (paths relative to the reference tree
@@ -24,6 +27,7 @@ extern "C" {
 
 #define MEGA_F32 0
 #define MEGA_BF16 1
+#define MEGA_F16 2
 
 #define MEGA_OK 0
 #define MEGA_ERR_ARG 1
@@ -93,6 +97,10 @@ int mega_stem_conv_bn_relu_bf16_u8(const void* frames_u8, const void* w_n176_bf1
  * 64-channel map is never written.  Same bits as mega_stem_conv_bn_relu_bf16[_u8] + mega_maxpool3x3s2_nhwc. */
 int mega_stem_pool_bf16(const void* in, int u8, const void* w_n176_bf16, const float* scale, const float* bias, void* out,
                         int N, int H, int W, float mean0, float mean1, float mean2, int to_bgr, void* stream);
+
+/* mega_stem_pool_bf16 for either 16-bit type: dtype = MEGA_BF16 or MEGA_F16 is the type of w_n176 and of `out`. */
+int mega_stem_pool_dt(const void* in, int u8, const void* w_n176, const float* scale, const float* bias, void* out, int N,
+                      int H, int W, float mean0, float mean1, float mean2, int to_bgr, int dtype, void* stream);
 
 /* F.max_pool2d(kernel 3, stride 2, padding 1) on NHWC (resnet.py:365). */
 int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, void* stream);
@@ -269,6 +277,14 @@ int mega_bottleneck64_ds_fwd(const void* x, const void* w1, const float* s1, con
                              const float* b2, const void* w3, const float* s3, const float* b3, const void* wd, const float* sd,
                              const float* bd, void* out, int N, int H, int W, void* stream);
 
+/* The two fused bottlenecks above for either 16-bit type (dtype = MEGA_BF16 / MEGA_F16: the type of x, every w and out). */
+int mega_bottleneck64_fwd_dt(const void* x, const void* w1, const float* s1, const float* b1, const void* w2, const float* s2,
+                             const float* b2, const void* w3, const float* s3, const float* b3, void* out, int N, int H, int W,
+                             int dtype, void* stream);
+int mega_bottleneck64_ds_fwd_dt(const void* x, const void* w1, const float* s1, const float* b1, const void* w2, const float* s2,
+                                const float* b2, const void* w3, const float* s3, const float* b3, const void* wd, const float* sd,
+                                const float* bd, void* out, int N, int H, int W, int dtype, void* stream);
+
 /* dst [rows][3K] bf16 = [hi | lo | hi] of src [rows][K] f32 (hi = bf16(v), lo = bf16(v - hi); K % 8 == 0): the A operand
  * of a split-precision GEMM on the bf16 matrix cores against weight rows [Wh | Wh | Wl] -- v.W to ~2^-16.  Used for the
  * stage FCs of the aggregation head (roi_box_feature_extractors.py:826-827) when the activation stream is f32. */
@@ -306,6 +322,11 @@ int mega_conv2d_nhwc_sp(const void* in, int ldi, int kwrap, const void* w, const
  * SOURCE bytes per row, a multiple of 32; 16-byte aligned on both sides): a concatenation of f32 row blocks delivered as the
  * rounded copy the bf16 projections read (roi_box_feature_extractors.py:812-814 pools with an f32 activation stream). */
 int mega_copy_cast_segments(const void* segs, int n, void* stream);
+
+/* mega_cast_f32_to_bf16 / mega_copy_cast_segments with the destination type as a code (MEGA_BF16 / MEGA_F16): the rounded
+ * copies of the head's f32 activation stream that its 16-bit projections read. */
+int mega_cast_f32_to_half(const float* src, void* dst, size_t n, int dtype, void* stream);
+int mega_copy_cast_segments_dt(const void* segs, int n, int dtype, void* stream);
 
 /* hipGetErrorString of the last launch failure any entry point of this library reported (MEGA_ERR_LAUNCH). */
 const char* mega_last_error_string(void);

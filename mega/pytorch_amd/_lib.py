@@ -21,6 +21,7 @@ SIGNATURES = {
     "mega_stem_conv_bn_relu_bf16": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "mega_stem_conv_bn_relu_bf16_u8": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
     "mega_stem_pool_bf16": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
+    "mega_stem_pool_dt": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_float] * 3 + [c_int, c_int, c_void_p]),
     "mega_maxpool3x3s2_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "mega_avgpool2x2_ceil_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "mega_roi_align_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] + [c_int] * 7 + [c_void_p]),
@@ -65,6 +66,10 @@ SIGNATURES = {
     "mega_copy_cast_segments": (c_int, [c_void_p, c_int, c_void_p]),
     "mega_bottleneck64_fwd": (c_int, [c_void_p] * 11 + [c_int] * 3 + [c_void_p]),
     "mega_bottleneck64_ds_fwd": (c_int, [c_void_p] * 14 + [c_int] * 3 + [c_void_p]),
+    "mega_bottleneck64_fwd_dt": (c_int, [c_void_p] * 11 + [c_int] * 4 + [c_void_p]),
+    "mega_bottleneck64_ds_fwd_dt": (c_int, [c_void_p] * 14 + [c_int] * 4 + [c_void_p]),
+    "mega_cast_f32_to_half": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "mega_copy_cast_segments_dt": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "mega_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mega_split_f32_to_bf16x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mega_split_f32_to_planes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -76,7 +76,9 @@ def get_cfg(arch="R-101", method="mega"):
 
 def _mega_cfg(r50):
     return CfgNode({
-        "DTYPE": "float32",                      # defaults.py:541; "bfloat16" selects the bf16 MFMA path
+        "DTYPE": "float32",                      # defaults.py:541; "bfloat16" selects the bf16 MFMA path, "float16" the same
+                                                 # kernels on IEEE-half operands (11 significant bits, values < 65 504)
+        "HEAD_DTYPE": "bfloat16",                # float16 mode only: operand type of the aggregation head (modeling.head_dtype)
         # bf16 mode only: dtype of the aggregation head's activation stream (fc0 output -> x + attention -> stage FCs ->
         # predictor, roi_box_feature_extractors.py:806-829,:898-933).  "float32" (default): the stream is never rounded
         # to bf16 and the stage FCs / predictor run in exact-f32 MFMA (logits within ~1e-4 of the f32 path);

@@ -79,21 +79,23 @@ __global__ __launch_bounds__(256) void copy_any_kernel(CopyBatch b) {
 }
 
 // f32 -> bf16 (round to nearest even, the hardware conversion every epilogue uses), 8 elements per thread
+template <typename HT>      // bf16_t, or f16_t (IEEE half)
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n8,
                                                             size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
     u32x4_t o;
-    o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w); o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
+    o[0] = Half16<HT>::pack2(a.x, a.y); o[1] = Half16<HT>::pack2(a.z, a.w); o[2] = Half16<HT>::pack2(b.x, b.y); o[3] = Half16<HT>::pack2(b.z, b.w);
     reinterpret_cast<u32x4_t*>(dst)[i] = o;
   }
   if (blockIdx.x == 0)       // tail (n not a multiple of 8)
-    for (size_t i = n8 * 8 + threadIdx.x; i < n; i += 256) dst[i] = f32_to_bf16(src[i]);
+    for (size_t i = n8 * 8 + threadIdx.x; i < n; i += 256) dst[i] = Half16<HT>::cvt(src[i]);
 }
 
 // copy_segments with an f32 -> bf16 conversion on the way: a concatenation of f32 row blocks delivered as bf16 (the key / value
 // sources of the relation modules when the head's activation stream is f32: only their rounded copy is ever read).  A segment
 // is [rows][8 * units_per_row] f32 elements; each thread converts 8 elements (32 B in, 16 B out).
+template <typename HT>
 __global__ __launch_bounds__(256) void copy_cast_segments_kernel(CopyBatch b) {
   const unsigned total = b.ubase[b.n];
   for (unsigned unit = blockIdx.x * 256u + threadIdx.x; unit < total; unit += gridDim.x * 256u) {
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void copy_cast_segments_kernel(CopyBatch b) {
     const float4* src = reinterpret_cast<const float4*>(s.src + (long long)r * s.src_stride + (size_t)c * 32);
     const float4 a = src[0], q = src[1];
     u32x4_t o;
-    o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w); o[2] = pack_bf16x2(q.x, q.y); o[3] = pack_bf16x2(q.z, q.w);
+    o[0] = Half16<HT>::pack2(a.x, a.y); o[1] = Half16<HT>::pack2(a.z, a.w); o[2] = Half16<HT>::pack2(q.x, q.y); o[3] = Half16<HT>::pack2(q.z, q.w);
     *reinterpret_cast<u32x4_t*>(s.dst + (long long)r * s.dst_stride + (size_t)c * 16) = o;
   }
 }
@@ -173,16 +175,24 @@ extern "C" int mega_split_f32_to_planes(const float* src, void* dst, int rows, i
 // dst[i] = bf16(src[i]) for n contiguous elements (both 16-byte aligned).  The aggregation head keeps its activation
 // stream in f32 (cfg.HEAD_STREAM) and feeds the bf16 projections (Wq / Wk / Wv) a rounded copy: the rounding the bf16
 // GEMM's A operand needs anyway, without rounding the stream itself.
-extern "C" int mega_cast_f32_to_bf16(const float* src, void* dst, size_t n, void* stream) {
+extern "C" int mega_cast_f32_to_half(const float* src, void* dst, size_t n, int dtype, void* stream) {
   mega_clear_error();
   if (n == 0) return MEGA_OK;
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
   if (!src || !dst || (reinterpret_cast<size_t>(src) & 15) || (reinterpret_cast<size_t>(dst) & 15)) return MEGA_ERR_ARG;
   const size_t n8 = n / 8;
   size_t nb = (n8 + 255) / 256;
   if (nb > 4096) nb = 4096;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n8, n);
+  if (dtype == MEGA_F16)
+    hipLaunchKernelGGL(cast_f32_bf16_kernel<f16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n8, n);
+  else
+    hipLaunchKernelGGL(cast_f32_bf16_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n8, n);
   return mega_check_launch();
+}
+
+extern "C" int mega_cast_f32_to_bf16(const float* src, void* dst, size_t n, void* stream) {
+  return mega_cast_f32_to_half(src, dst, n, MEGA_BF16, stream);
 }
 
 struct MegaCopySegC {
@@ -192,10 +202,10 @@ struct MegaCopySegC {
 // segs[n] as for mega_copy_segments, but the source blocks are f32 and the destination blocks bf16: row_bytes counts the
 // SOURCE bytes of a row (a multiple of 32: 8 elements per thread), strides are bytes of the respective tensor, both sides
 // 16-byte aligned.  dst = bf16(src), round to nearest even.
-extern "C" int mega_copy_cast_segments(const void* segs, int n, void* stream) {
+extern "C" int mega_copy_cast_segments_dt(const void* segs, int n, int dtype, void* stream) {
   mega_clear_error();
   if (n == 0) return MEGA_OK;
-  if (!segs || n < 0) return MEGA_ERR_ARG;
+  if (!segs || n < 0 || (dtype != MEGA_BF16 && dtype != MEGA_F16)) return MEGA_ERR_ARG;
   const MegaCopySegC* d = (const MegaCopySegC*)segs;
   for (int i = 0; i < n; ++i) {
     const MegaCopySegC& g = d[i];
@@ -214,7 +224,8 @@ extern "C" int mega_copy_cast_segments(const void* segs, int n, void* stream) {
     b.ubase[b.n] = (unsigned)units;
     unsigned long long nb = (units + 1023) / 1024;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(copy_cast_segments_kernel, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, st, b);
+    if (dtype == MEGA_F16) hipLaunchKernelGGL(copy_cast_segments_kernel<f16_t>, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL(copy_cast_segments_kernel<bf16_t>, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), 0, st, b);
     b.n = 0;
     units = 0;
   };
@@ -234,6 +245,10 @@ extern "C" int mega_copy_cast_segments(const void* segs, int n, void* stream) {
   }
   flush();
   return mega_check_launch();
+}
+
+extern "C" int mega_copy_cast_segments(const void* segs, int n, void* stream) {
+  return mega_copy_cast_segments_dt(segs, n, MEGA_BF16, stream);
 }
 
 // segs[n]: copy rows x row_bytes bytes from src (+ r * src_stride) to dst (+ r * dst_stride).  Segments must not

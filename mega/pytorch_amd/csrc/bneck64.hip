@@ -59,20 +59,26 @@ struct Bneck64Params {
   int N, H, W, tiles_y, tiles_x, ntiles;
 };
 
+// HT (every kernel / helper below): the 16-bit element type, bf16_t or f16_t (IEEE half, round 6).  The parameter structs keep
+// raw 16-bit pointers (bf16_t = unsigned short): only the MFMA, the f32 <-> 16-bit conversions and the residual unpack differ.
+template <typename HT>
 __device__ __forceinline__ f32x16_t bk_mma(f32x16_t acc, const uint4& a, const uint4& b) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  return Half16<HT>::mfma32(__builtin_bit_cast(u32x4_t, a), __builtin_bit_cast(u32x4_t, b), acc);
 }
 
 // ReLU on the ROUNDED value (the igemm / igemm8 fast epilogues' form): one packed max per pair, a negative gives +0
+template <typename HT>
 __device__ __forceinline__ unsigned bk_relu_pack(float a, float b) {
   const s16x2_t z = {0, 0};
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pack_bf16x2(a, b)), z));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, Half16<HT>::pack2(a, b)), z));
 }
+template <typename HT>
 __device__ __forceinline__ bf16_t bk_relu1(float a) {
-  const bf16_t h = f32_to_bf16(a);
+  const bf16_t h = Half16<HT>::cvt(a);
   return (short)h < 0 ? (bf16_t)0 : h;
 }
 
+template <typename HT>
 __global__ __launch_bounds__(BK_NT, 2) void bneck64_kernel(Bneck64Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const w2l = smem + BK_OFF_W2;
@@ -178,8 +184,8 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_kernel(Bneck64Params p) {
           const uint4 a = *reinterpret_cast<const uint4*>(xbl + a1_base + (((unsigned)(2 * ks + h) ^ a1_sw) << 4));
           const uint4 b0 = *reinterpret_cast<const uint4*>(w1l + b1_base + ks * 32);
           const uint4 b1 = *reinterpret_cast<const uint4*>(w1l + 32 * BK_WROW + b1_base + ks * 32);
-          c1a = bk_mma(c1a, a, b0);
-          c1b = bk_mma(c1b, a, b1);
+          c1a = bk_mma<HT>(c1a, a, b0);
+          c1b = bk_mma<HT>(c1b, a, b1);
         }
       }
       __syncthreads();                          // every wave is done with this chunk
@@ -202,8 +208,8 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_kernel(Bneck64Params p) {
           const int py = R / BK_PX, pxx = R - py * BK_PX;
           const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
           const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-          const bf16_t va = in ? bk_relu1(c1a[r] * s1a + b1a) : (bf16_t)0;
-          const bf16_t vb = in ? bk_relu1(c1b[r] * s1b + b1b) : (bf16_t)0;
+          const bf16_t va = in ? bk_relu1<HT>(c1a[r] * s1a + b1a) : (bf16_t)0;
+          const bf16_t vb = in ? bk_relu1<HT>(c1b[r] * s1b + b1b) : (bf16_t)0;
           unsigned char* base = t1l + R * 128;
           const int sw = (pxx >> 1) & 7;
           *reinterpret_cast<bf16_t*>(base + (((lo >> 3) ^ sw) * 16) + (lo & 7) * 2) = va;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_kernel(Bneck64Params p) {
           const uint4 a = *reinterpret_cast<const uint4*>(t1l + a2_base + (kh * BK_PX + kw) * 128 +
                                                           (((unsigned)(2 * ks + h) ^ sw2) << 4));
           const uint4 b = *reinterpret_cast<const uint4*>(w2l + b2_off + (kh * 3 + kw) * 128 + ks * 32);
-          c2 = bk_mma(c2, a, b);
+          c2 = bk_mma<HT>(c2, a, b);
         }
     // ---- t2 = relu(bn2(.)) as bf16 [128 px][64 ch], rows swizzled for conv3's A fragments
     {
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_kernel(Bneck64Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int P = 32 * mb2 + (r & 3) + 8 * (r >> 2) + 4 * ho;
-        *reinterpret_cast<bf16_t*>(t2l + P * 128 + (((c >> 3) ^ ((P >> 1) & 7)) * 16) + (c & 7) * 2) = bk_relu1(c2[r] * s2v + b2v);
+        *reinterpret_cast<bf16_t*>(t2l + P * 128 + (((c >> 3) ^ ((P >> 1) & 7)) * 16) + (c & 7) * 2) = bk_relu1<HT>(c2[r] * s2v + b2v);
       }
     }
     __syncthreads();                            // t2 is visible
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_kernel(Bneck64Params p) {
           const unsigned o = (yy < p.H && xx < p.W) ? res_base : OOB;
           const unsigned short q = __builtin_amdgcn_raw_buffer_load_b16(
               rs_x, o, ((2 * mb + (r >> 3)) * p.W + (r & 3) + 8 * ((r >> 2) & 1)) * 512, 0);
-          rs[r] = __uint_as_float((unsigned)q << 16);
+          rs[r] = Half16<HT>::one(q);
         }
         f32x16_t c3;
 #pragma unroll
@@ -274,14 +280,14 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_kernel(Bneck64Params p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const uint4 a = *reinterpret_cast<const uint4*>(t2l + mb * 4096 + a3_base + (((unsigned)(2 * ks + h) ^ a3_sw) << 4));
-          c3 = bk_mma(c3, a, bf[ks]);
+          c3 = bk_mma<HT>(c3, a, bf[ks]);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           float v0 = c3[2 * q] * s3v + b3v, v1 = c3[2 * q + 1] * s3v + b3v;      // (the f32 value igemm8 stages ...)
           v0 += rs[2 * q];                                                        // (... and the residual added to it)
           v1 += rs[2 * q + 1];
-          pk[mb][q] = bk_relu_pack(v0, v1);
+          pk[mb][q] = bk_relu_pack<HT>(v0, v1);
         }
       }
     }
@@ -342,6 +348,7 @@ struct Bneck64DsParams {
   int N, H, W, tiles_y, tiles_x, ntiles;
 };
 
+template <typename HT>
 __global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const w2l = smem + BD_OFF_W2;
@@ -432,8 +439,8 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p)
         const uint4 a = *reinterpret_cast<const uint4*>(xpl + a1_base + (((unsigned)(2 * ks + h) ^ a1_sw) << 4));
         const uint4 b0 = *reinterpret_cast<const uint4*>(wrl + bw_base + ks * 32);
         const uint4 b1 = *reinterpret_cast<const uint4*>(wrl + 32 * BK_WROW + bw_base + ks * 32);
-        c1a = bk_mma(c1a, a, b0);
-        c1b = bk_mma(c1b, a, b1);
+        c1a = bk_mma<HT>(c1a, a, b0);
+        c1b = bk_mma<HT>(c1b, a, b1);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -442,8 +449,8 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p)
           const int py = R / BK_PX, pxx = R - py * BK_PX;
           const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
           const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-          const bf16_t va = in ? bk_relu1(c1a[r] * s1a + b1a) : (bf16_t)0;
-          const bf16_t vb = in ? bk_relu1(c1b[r] * s1b + b1b) : (bf16_t)0;
+          const bf16_t va = in ? bk_relu1<HT>(c1a[r] * s1a + b1a) : (bf16_t)0;
+          const bf16_t vb = in ? bk_relu1<HT>(c1b[r] * s1b + b1b) : (bf16_t)0;
           unsigned char* base = t1l + R * 128;
           const int sw = (pxx >> 1) & 7;
           *reinterpret_cast<bf16_t*>(base + (((lo >> 3) ^ sw) * 16) + (lo & 7) * 2) = va;
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p)
           const uint4 a = *reinterpret_cast<const uint4*>(t1l + a2_base + (kh * BK_PX + kw) * 128 +
                                                           (((unsigned)(2 * ks + h) ^ sw2) << 4));
           const uint4 b = *reinterpret_cast<const uint4*>(w2l + b2_off + (kh * 3 + kw) * 128 + ks * 32);
-          c2 = bk_mma(c2, a, b);
+          c2 = bk_mma<HT>(c2, a, b);
         }
     __syncthreads();                            // every wave is done with t1 (t2 takes its place); wd is visible
     {
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int P = 32 * mb2 + (r & 3) + 8 * (r >> 2) + 4 * ho;
-        *reinterpret_cast<bf16_t*>(t2l + P * 128 + (((c >> 3) ^ ((P >> 1) & 7)) * 16) + (c & 7) * 2) = bk_relu1(c2[r] * s2v + b2v);
+        *reinterpret_cast<bf16_t*>(t2l + P * 128 + (((c >> 3) ^ ((P >> 1) & 7)) * 16) + (c & 7) * 2) = bk_relu1<HT>(c2[r] * s2v + b2v);
       }
     }
     // ================= the identity branch: bnd(convd(x)) on the patch's centre pixels, rounded to bf16 (two per register)
@@ -503,10 +510,10 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const uint4 a = *reinterpret_cast<const uint4*>(xpl + xa + (((unsigned)(2 * ks + h) ^ xs) << 4));
-          cd = bk_mma(cd, a, bf[ks]);
+          cd = bk_mma<HT>(cd, a, bf[ks]);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pk[mb][q] = pack_bf16x2(cd[2 * q] * sdv + bdv, cd[2 * q + 1] * sdv + bdv);
+        for (int q = 0; q < 8; ++q) pk[mb][q] = Half16<HT>::pack2(cd[2 * q] * sdv + bdv, cd[2 * q + 1] * sdv + bdv);
       }
     }
     __syncthreads();                            // t2 is visible; every wave is done with wd
@@ -529,14 +536,14 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const uint4 a = *reinterpret_cast<const uint4*>(t2l + mb * 4096 + a3_base + (((unsigned)(2 * ks + h) ^ a3_sw) << 4));
-          c3 = bk_mma(c3, a, bf[ks]);
+          c3 = bk_mma<HT>(c3, a, bf[ks]);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           float v0 = c3[2 * q] * s3v + b3v, v1 = c3[2 * q + 1] * s3v + b3v;
-          v0 += __uint_as_float(pk[mb][q] << 16);
-          v1 += __uint_as_float(pk[mb][q] & 0xffff0000u);
-          pk[mb][q] = bk_relu_pack(v0, v1);
+          v0 += Half16<HT>::lo(pk[mb][q]);
+          v1 += Half16<HT>::hi(pk[mb][q]);
+          pk[mb][q] = bk_relu_pack<HT>(v0, v1);
         }
       }
     }
@@ -571,10 +578,11 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p)
 
 // y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + x) for a 256 -> 64 -> 64 (3x3, pad 1) -> 256 identity bottleneck,
 // NHWC bf16, FrozenBN as f32 scale / bias vectors.  Bit-identical to the three mega_conv2d_nhwc launches it replaces.
-extern "C" int mega_bottleneck64_fwd(const void* x, const void* w1, const float* s1, const float* b1, const void* w2,
-                                     const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
-                                     void* out, int N, int H, int W, void* stream) {
+extern "C" int mega_bottleneck64_fwd_dt(const void* x, const void* w1, const float* s1, const float* b1, const void* w2,
+                                        const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
+                                        void* out, int N, int H, int W, int dtype, void* stream) {
   mega_clear_error();
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
   if (!x || !w1 || !s1 || !b1 || !w2 || !s2 || !b2 || !w3 || !s3 || !b3 || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
   if ((size_t)N * H * W * 256 * 2 >= 0x7FF00000ull) return MEGA_ERR_ARG;          // 32-bit buffer offsets
   Bneck64Params p;
@@ -599,18 +607,30 @@ extern "C" int mega_bottleneck64_fwd(const void* x, const void* w1, const float*
     cus = cached[dev];
   }
   const int grid = (int)(tiles < cus ? tiles : cus);
-  (void)hipFuncSetAttribute((const void*)bneck64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS);
-  hipLaunchKernelGGL(bneck64_kernel, dim3(grid), dim3(BK_NT), BK_LDS, (hipStream_t)stream, p);
+  if (dtype == MEGA_F16) {
+    (void)hipFuncSetAttribute((const void*)bneck64_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS);
+    hipLaunchKernelGGL(bneck64_kernel<f16_t>, dim3(grid), dim3(BK_NT), BK_LDS, (hipStream_t)stream, p);
+  } else {
+    (void)hipFuncSetAttribute((const void*)bneck64_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS);
+    hipLaunchKernelGGL(bneck64_kernel<bf16_t>, dim3(grid), dim3(BK_NT), BK_LDS, (hipStream_t)stream, p);
+  }
   return mega_check_launch();
+}
+
+extern "C" int mega_bottleneck64_fwd(const void* x, const void* w1, const float* s1, const float* b1, const void* w2,
+                                     const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
+                                     void* out, int N, int H, int W, void* stream) {
+  return mega_bottleneck64_fwd_dt(x, w1, s1, b1, w2, s2, b2, w3, s3, b3, out, N, H, W, MEGA_BF16, stream);
 }
 
 // The stage's first block with the 1x1 downsample branch: x NHWC bf16 [N][H][W][64] -> out [N][H][W][256],
 //   out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + bnd(convd(x))).  Bit-identical to the four launches it replaces.
-extern "C" int mega_bottleneck64_ds_fwd(const void* x, const void* w1, const float* s1, const float* b1, const void* w2,
-                                        const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
-                                        const void* wd, const float* sd, const float* bd, void* out, int N, int H, int W,
-                                        void* stream) {
+extern "C" int mega_bottleneck64_ds_fwd_dt(const void* x, const void* w1, const float* s1, const float* b1, const void* w2,
+                                           const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
+                                           const void* wd, const float* sd, const float* bd, void* out, int N, int H, int W,
+                                           int dtype, void* stream) {
   mega_clear_error();
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
   if (!x || !w1 || !s1 || !b1 || !w2 || !s2 || !b2 || !w3 || !s3 || !b3 || !wd || !sd || !bd || !out || N <= 0 || H <= 0 || W <= 0)
     return MEGA_ERR_ARG;
   if ((size_t)N * H * W * 256 * 2 >= 0x7FF00000ull) return MEGA_ERR_ARG;          // 32-bit buffer offsets
@@ -636,7 +656,19 @@ extern "C" int mega_bottleneck64_ds_fwd(const void* x, const void* w1, const flo
     cus = cached[dev];
   }
   const int grid = (int)(tiles < cus ? tiles : cus);
-  (void)hipFuncSetAttribute((const void*)bneck64_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BD_LDS);
-  hipLaunchKernelGGL(bneck64_ds_kernel, dim3(grid), dim3(BK_NT), BD_LDS, (hipStream_t)stream, p);
+  if (dtype == MEGA_F16) {
+    (void)hipFuncSetAttribute((const void*)bneck64_ds_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, BD_LDS);
+    hipLaunchKernelGGL(bneck64_ds_kernel<f16_t>, dim3(grid), dim3(BK_NT), BD_LDS, (hipStream_t)stream, p);
+  } else {
+    (void)hipFuncSetAttribute((const void*)bneck64_ds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, BD_LDS);
+    hipLaunchKernelGGL(bneck64_ds_kernel<bf16_t>, dim3(grid), dim3(BK_NT), BD_LDS, (hipStream_t)stream, p);
+  }
   return mega_check_launch();
+}
+
+extern "C" int mega_bottleneck64_ds_fwd(const void* x, const void* w1, const float* s1, const float* b1, const void* w2,
+                                        const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
+                                        const void* wd, const float* sd, const float* bd, void* out, int N, int H, int W,
+                                        void* stream) {
+  return mega_bottleneck64_ds_fwd_dt(x, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, bd, out, N, H, W, MEGA_BF16, stream);
 }

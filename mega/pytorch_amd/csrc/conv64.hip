@@ -37,6 +37,8 @@ constexpr int C64_LDS = C64_WBYTES + C64_PBYTES + C64_SBYTES;   // 148992
 constexpr int C64_NT = 512;
 constexpr int C64_PRE = (C64_NPIX * 8 + C64_NT - 1) / C64_NT;   // 16-byte patch pieces per thread (6)
 
+// HT: bf16_t or f16_t (IEEE half, round 6) -- the element type of in / w / out
+template <typename HT>
 __global__ __launch_bounds__(C64_NT, 2) void conv3x3_c64_kernel(ConvParams p, int tiles_y, int tiles_x, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const wl = smem;
@@ -44,8 +46,8 @@ __global__ __launch_bounds__(C64_NT, 2) void conv3x3_c64_kernel(ConvParams p, in
   unsigned char* const sl = smem + C64_WBYTES + C64_PBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const bf16_t* __restrict__ in = (const bf16_t*)p.in;
-  bf16_t* __restrict__ out = (bf16_t*)p.out;
+  const unsigned short* __restrict__ in = (const unsigned short*)p.in;
+  unsigned short* __restrict__ out = (unsigned short*)p.out;
 
   // ---- weights -> LDS, once
   {
@@ -123,14 +125,12 @@ __global__ __launch_bounds__(C64_NT, 2) void conv3x3_c64_kernel(ConvParams p, in
       for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const uint4 a = *reinterpret_cast<const uint4*>(pl + a_off[kw][ks] + kh * (C64_P * 128));
+          const u32x4_t a = *reinterpret_cast<const u32x4_t*>(pl + a_off[kw][ks] + kh * (C64_P * 128));
           const int kb = (kh * 3 + kw) * 128 + ks * 32;
-          const uint4 b0 = *reinterpret_cast<const uint4*>(wl + b_off0 + kb);
-          const uint4 b1 = *reinterpret_cast<const uint4*>(wl + b_off1 + kb);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b0),
-                                                         acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b1),
-                                                         acc1, 0, 0, 0);
+          const u32x4_t b0 = *reinterpret_cast<const u32x4_t*>(wl + b_off0 + kb);
+          const u32x4_t b1 = *reinterpret_cast<const u32x4_t*>(wl + b_off1 + kb);
+          acc0 = Half16<HT>::mfma32(a, b0, acc0);
+          acc1 = Half16<HT>::mfma32(a, b1, acc1);
         }
     __syncthreads();                        // every wave is done with this tile's patch
     // ---- 2. next tile's patch into LDS; this tile's outputs into the staging area (pixel-major, 128 B per pixel)
@@ -139,18 +139,18 @@ __global__ __launch_bounds__(C64_NT, 2) void conv3x3_c64_kernel(ConvParams p, in
     for (int r = 0; r < 16; ++r) {
       const int pix = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       float v0 = acc0[r] * sc0 + bi0, v1 = acc1[r] * sc1 + bi1;
-      bf16_t h0, h1;
+      unsigned short h0, h1;
       if (p.relu == 1) {       // ReLU on the ROUNDED value, as the igemm / igemm8 fast epilogues do it (max of the packed bits
-        h0 = f32_to_bf16(v0);  // with 0: a negative input gives +0, never -0; a NaN with the sign bit set gives 0 as well) --
-        h1 = f32_to_bf16(v1);  // bit identity with the generic tiles includes the sign of zero
-        h0 = (short)h0 < 0 ? (bf16_t)0 : h0;
-        h1 = (short)h1 < 0 ? (bf16_t)0 : h1;
+        h0 = Half16<HT>::cvt(v0);  // with 0: a negative input gives +0, never -0; a NaN with the sign bit set gives 0 as well) --
+        h1 = Half16<HT>::cvt(v1);  // bit identity with the generic tiles includes the sign of zero
+        h0 = (short)h0 < 0 ? (unsigned short)0 : h0;
+        h1 = (short)h1 < 0 ? (unsigned short)0 : h1;
       } else {
-        h0 = f32_to_bf16(v0 > 0.f ? v0 : v0 * neg_slope);
-        h1 = f32_to_bf16(v1 > 0.f ? v1 : v1 * neg_slope);
+        h0 = Half16<HT>::cvt(v0 > 0.f ? v0 : v0 * neg_slope);
+        h1 = Half16<HT>::cvt(v1 > 0.f ? v1 : v1 * neg_slope);
       }
-      *reinterpret_cast<bf16_t*>(sl + pix * 128 + l31 * 2) = h0;
-      *reinterpret_cast<bf16_t*>(sl + pix * 128 + (32 + l31) * 2) = h1;
+      *reinterpret_cast<unsigned short*>(sl + pix * 128 + l31 * 2) = h0;
+      *reinterpret_cast<unsigned short*>(sl + pix * 128 + (32 + l31) * 2) = h1;
     }
     __syncthreads();
     // ---- 3. read-out: 16-byte stores, a tile row = 2 KB of contiguous memory; then request the patch after next
@@ -184,7 +184,8 @@ int mega_conv64_supports(const ConvParams& p, int out_f32) {
   return tiles >= 128;
 }
 
-int mega_conv64_launch(const ConvParams& p, hipStream_t st) {
+int mega_conv64_launch(const ConvParams& p, int half_dtype, hipStream_t st) {
+  if (half_dtype != MEGA_BF16 && half_dtype != MEGA_F16) return MEGA_ERR_ARG;
   const int ty = cdiv(p.H, C64_T), tx = cdiv(p.W, C64_T);
   const long tiles = (long)p.N * ty * tx;
   if (tiles > 0x7FFFFFFF) return MEGA_ERR_ARG;
@@ -200,7 +201,12 @@ int mega_conv64_launch(const ConvParams& p, hipStream_t st) {
     cus = cached[dev];
   }
   const int grid = (int)(tiles < cus ? tiles : cus);
-  (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
-  hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(C64_NT), C64_LDS, st, p, ty, tx, (int)tiles);
+  if (half_dtype == MEGA_F16) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<f16_t>, dim3(grid), dim3(C64_NT), C64_LDS, st, p, ty, tx, (int)tiles);
+  } else {
+    (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<bf16_t>, dim3(grid), dim3(C64_NT), C64_LDS, st, p, ty, tx, (int)tiles);
+  }
   return mega_check_launch();
 }

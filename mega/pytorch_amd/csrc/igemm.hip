@@ -37,6 +37,11 @@ template <> struct Mma<bf16_t> {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
   }
 };
+template <> struct Mma<f16_t> {
+  __device__ static __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+  }
+};
 template <> struct Mma<float> {
   // a, b: 4 f32 along K; MFMA e consumes component e (K order is permuted identically for A and B)
   __device__ static __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
@@ -307,9 +312,9 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
             for (int d = 0; d < 4; ++d) {
               if constexpr (RELU) {
                 const s16x2_t z = {0, 0};
-                o[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pack_bf16x2(v[2 * d], v[2 * d + 1])), z));
+                o[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, Half16<OT>::pack2(v[2 * d], v[2 * d + 1])), z));
               } else {
-                o[d] = pack_bf16x2(act(v[2 * d]), act(v[2 * d + 1]));
+                o[d] = Half16<OT>::pack2(act(v[2 * d]), act(v[2 * d + 1]));
               }
             }
           } else {
@@ -467,12 +472,19 @@ inline void choose_tile(int M, int Cout, int K, int z, bool bf16, int& kind, int
 template <typename T, typename OT>
 int dispatch_tile(const ConvParams& p, hipStream_t st) {
   int kind = 0, bm = 0, bn = 0, rc;
-  constexpr bool is_bf16 = sizeof(T) == 2;
+  constexpr bool is_bf16 = sizeof(T) == 2;                     // (a 16-bit operand type: bf16 or f16)
   choose_tile(p.M, p.Cout, p.K, p.ksplit, is_bf16, kind, bm, bn);
   if (kind == 8 && !(is_bf16 && mega_igemm8_supports(p))) {    // forced onto a shape it cannot take
     kind = 0; bm = 128; bn = 128;
   }
-  if (kind == 8) rc = mega_igemm8_launch(p, bm, sizeof(OT) == 4, st);
+  if constexpr (is_bf16) {
+    if (kind == 8) {
+      rc = mega_igemm8_launch(p, bm, sizeof(OT) == 4, Half16<T>::CODE, st);
+      if (rc == MEGA_OK && p.ksplit > 1) rc = launch_finalize<T, OT>(p, st);
+      return rc;
+    }
+  }
+  if (kind == 8) rc = MEGA_ERR_ARG;
   else if (bm == 256 && bn == 256) rc = launch<T, OT, 256, 256>(p, st);
   else if (bm == 256 && bn == 128) rc = launch<T, OT, 256, 128>(p, st);
   else if (bm == 128 && bn == 128) rc = launch<T, OT, 128, 128>(p, st);
@@ -511,11 +523,11 @@ extern "C" int mega_conv2d_nhwc_plan_ex(int N, int H, int W, int Cin, int Cout, 
   p.ldr = p.ldo;
   p.res = has_residual ? (const void*)&p : nullptr;      // (only tested against null)
   p.ksplit = 1;
-  const size_t esz = in_dtype == MEGA_BF16 ? 2 : 4;
+  const size_t esz = in_dtype == MEGA_F32 ? 4 : 2;
   const size_t ib = (size_t)N * H * W * Cin * esz, wb = (size_t)Cout * p.K * esz;
   p.in_bytes = ib >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned)ib;
   p.w_bytes = wb >= 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned)wb;
-  return plan_of(p, in_dtype == MEGA_BF16, out_dtype == MEGA_F32);
+  return plan_of(p, in_dtype != MEGA_F32, out_dtype == MEGA_F32);
 }
 
 // the (M, Cout, K) form: a 1x1 layer / linear of that GEMM shape (bf16 or f32 output does not change the tile)
@@ -561,7 +573,8 @@ extern "C" int mega_conv2d_nhwc_ws(const void* in, const void* w, const float* s
     }
   }
   {
-    const size_t esz = in_dtype == MEGA_BF16 ? 2 : 4;
+    if (in_dtype != MEGA_F32 && in_dtype != MEGA_BF16 && in_dtype != MEGA_F16) return MEGA_ERR_ARG;
+    const size_t esz = in_dtype == MEGA_F32 ? 4 : 2;
     const size_t ib = (size_t)N * H * W * Cin * esz, wb = (size_t)Cout * p.K * esz;
     if (ib >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull) return MEGA_ERR_ARG;  // 32-bit buffer offsets
     p.in_bytes = (unsigned)ib;
@@ -572,9 +585,16 @@ extern "C" int mega_conv2d_nhwc_ws(const void* in, const void* w, const float* s
     if (Cin % 64 != 0) return MEGA_ERR_ARG;
     // layer1's 3x3 64 -> 64 conv: its own persistent streaming kernel (a forced tile, MEGA_IGEMM_TILE, keeps it on the
     // generic path: that is how the bit-equality test compares the two)
-    if (out_dtype == MEGA_BF16 && !getenv("MEGA_IGEMM_TILE") && mega_conv64_supports(p, 0)) return mega_conv64_launch(p, st);
+    if (out_dtype == MEGA_BF16 && !getenv("MEGA_IGEMM_TILE") && mega_conv64_supports(p, 0)) return mega_conv64_launch(p, MEGA_BF16, st);
     if (out_dtype == MEGA_BF16) return dispatch_tile<bf16_t, bf16_t>(p, st);
     if (out_dtype == MEGA_F32) return dispatch_tile<bf16_t, float>(p, st);
+    return MEGA_ERR_ARG;
+  }
+  if (in_dtype == MEGA_F16) {      // IEEE half operands: the same kernels instantiated for f16_t (same tiles, same K order)
+    if (Cin % 64 != 0) return MEGA_ERR_ARG;
+    if (out_dtype == MEGA_F16 && !getenv("MEGA_IGEMM_TILE") && mega_conv64_supports(p, 0)) return mega_conv64_launch(p, MEGA_F16, st);
+    if (out_dtype == MEGA_F16) return dispatch_tile<f16_t, f16_t>(p, st);
+    if (out_dtype == MEGA_F32) return dispatch_tile<f16_t, float>(p, st);
     return MEGA_ERR_ARG;
   }
   if (in_dtype == MEGA_F32) {
@@ -645,7 +665,7 @@ extern "C" int mega_conv2d_nhwc_sp(const void* in, int ldi, int kwrap, const voi
   // one block per CU: the row count that wastes the fewest CU-rounds (the rule of choose_tile)
   const long t256 = (long)cdiv(p.M, 256) * cdiv(Cout, 256) * p.ksplit, t192 = (long)cdiv(p.M, 192) * cdiv(Cout, 256) * p.ksplit;
   const long c256 = cdiv((int)t256, 256) * 256L * 8, c192 = cdiv((int)t192, 256) * 192L * 9;
-  int rc = mega_igemm8_launch(p, c192 < c256 ? 192 : 256, out_mode == 2, st);
+  int rc = mega_igemm8_launch(p, c192 < c256 ? 192 : 256, out_mode == 2, MEGA_BF16, st);
   if (rc == MEGA_OK && p.ksplit > 1) rc = launch_finalize<bf16_t, float>(p, st);
   return rc;
 }

@@ -86,8 +86,11 @@ __device__ __forceinline__ int fast_div(int n, unsigned mg, unsigned sh) {   // 
   return (int)((__umulhi((unsigned)n, mg) + (unsigned)n) >> sh);
 }
 
-template <typename OT, int MF1, int CLS = 0, int ABL = 0, int SP = 0>
+// HT: the 16-bit operand type (bf16_t, or f16_t = IEEE half: round 6) of in / w / residual; OT = HT or float.
+template <typename OT, int MF1, int CLS = 0, int ABL = 0, int SP = 0, typename HT = bf16_t>
 __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
+  static_assert(!SP || std::is_same<HT, bf16_t>::value, "split-precision planes are bf16 pairs");
+  static_assert(sizeof(OT) == 4 || std::is_same<OT, HT>::value, "16-bit outputs have the operands' type");
   constexpr int BM = 128 + 64 * MF1;
   constexpr int BN = 256;
   constexpr int WROWS1 = 32 * MF1;     // rows a wave owns in A1
@@ -268,8 +271,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #define MEGA_MMA(acc_, a_, b_)                                                                                          \
   do {                                                                                                                  \
     if (ABL != 3)                                                                                                       \
-      acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b_), __builtin_bit_cast(bf16x8_t, a_), \
-                                                     acc_, 0, 0, 0);                                                    \
+      acc_ = Half16<HT>::mfma32(b_, a_, acc_);                                                                          \
     else                                                                                                                \
       asm volatile("" ::"v"(a_), "v"(b_));                                                                              \
   } while (0)
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   static_assert(64 * CST * 4 <= LDS8, "staging slab must fit");
   float* cs = reinterpret_cast<float*>(smem);
   OT* __restrict__ out = (OT*)p.out;
-  const bf16_t* __restrict__ res = (const bf16_t*)p.res;
+  const HT* __restrict__ res = (const HT*)p.res;
   constexpr int OVE = 16 / (int)sizeof(OT);
   constexpr int VPR = BN / OVE;
   const float neg_slope = p.relu == 1 ? 0.f : (p.relu == 2 ? 0.1f : 1.f);
@@ -546,8 +548,8 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
               asm volatile("" : "+v"(r4));             // unpack HERE: hoisted, the 64 unpacked floats of two slabs spill
 #pragma unroll
               for (int d = 0; d < 4; ++d) {
-                v[2 * d] += __uint_as_float(r4[d] << 16);
-                v[2 * d + 1] += __uint_as_float(r4[d] & 0xffff0000u);
+                v[2 * d] += Half16<HT>::lo(r4[d]);
+                v[2 * d + 1] += Half16<HT>::hi(r4[d]);
               }
             }
             if constexpr (HAS_RES && SP) {             // residual value = hi + lo (exact in f32), then one add
@@ -588,9 +590,9 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
                 for (int d = 0; d < 4; ++d) {
                   if constexpr (RELU) {
                     const s16x2_t z = {0, 0};
-                    o[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pack_bf16x2(v[2 * d], v[2 * d + 1])), z));
+                    o[d] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, Half16<HT>::pack2(v[2 * d], v[2 * d + 1])), z));
                   } else {
-                    o[d] = pack_bf16x2(act(v[2 * d]), act(v[2 * d + 1]));
+                    o[d] = Half16<HT>::pack2(act(v[2 * d]), act(v[2 * d + 1]));
                   }
                 }
               } else {
@@ -707,11 +709,11 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
         }
         if (vec_ok && n + OVE <= p.Cout) {
           if (res_vec) {
-            const bf16_t* re = reinterpret_cast<const bf16_t*>(&rres[it]);
+            const HT* re = reinterpret_cast<const HT*>(&rres[it]);
 #pragma unroll
-            for (int t = 0; t < OVE; ++t) v[t] += bf16_to_f32(re[t]);
+            for (int t = 0; t < OVE; ++t) v[t] += Elem<HT>::ld(re + t);
           } else if (res) {
-            for (int t = 0; t < OVE; ++t) v[t] += bf16_to_f32(res[(size_t)m * p.ldr + n + t]);
+            for (int t = 0; t < OVE; ++t) v[t] += Elem<HT>::ld(res + (size_t)m * p.ldr + n + t);
           }
           uint4 o;
           OT* oe = reinterpret_cast<OT*>(&o);
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
         } else {
           for (int t = 0; t < OVE && n + t < p.Cout; ++t) {
             float x = v[t];
-            if (res) x += bf16_to_f32(res[(size_t)m * p.ldr + n + t]);
+            if (res) x += Elem<HT>::ld(res + (size_t)m * p.ldr + n + t);
             Elem<OT>::st(out + (size_t)m * p.ldo + n + t, act(x));
           }
         }
@@ -747,7 +749,7 @@ inline void magic_div(int d, unsigned& mg, unsigned& sh) {
   mg = (unsigned)((((1ull << sh) - (unsigned long long)d) << 32) / (unsigned long long)d + 1ull);
 }
 
-template <typename OT, int MF1, int CLS = 0, int ABL = 0, int SP = 0>
+template <typename OT, int MF1, int CLS = 0, int ABL = 0, int SP = 0, typename HT = bf16_t>
 int launch8(const ConvParams& p0, hipStream_t st) {
   constexpr int BM = 128 + 64 * MF1;
   ConvParams p = p0;
@@ -755,8 +757,8 @@ int launch8(const ConvParams& p0, hipStream_t st) {
   magic_div(p.Wo, p.mg_wo, p.sh_wo);
   const int ntm = cdiv(p.M, BM), ntn = cdiv(p.Cout, 256);
   // set on every launch (a per-process flag would miss the second device of a multi-GPU process)
-  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1, CLS, ABL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_ALLOC);
-  hipLaunchKernelGGL((igemm8_kernel<OT, MF1, CLS, ABL, SP>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8_ALLOC, st, p);
+  (void)hipFuncSetAttribute((const void*)igemm8_kernel<OT, MF1, CLS, ABL, SP, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_ALLOC);
+  hipLaunchKernelGGL((igemm8_kernel<OT, MF1, CLS, ABL, SP, HT>), dim3(ntm * ntn, 1, p.ksplit), dim3(NT8), LDS8_ALLOC, st, p);
   return mega_check_launch();
 }
 
@@ -771,7 +773,17 @@ int mega_igemm8_supports(const ConvParams& p) {
   return p.Cin % 64 == 0 && p.in_bytes < 0x7FF00000u && p.w_bytes < 0x7FF00000u && (p.K >> 6) >= 1;
 }
 
-int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st) {
+int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, int half_dtype, hipStream_t st) {
+  if (half_dtype == MEGA_F16) {        // IEEE half operands (same tiles, same launch classes; no split-precision planes)
+    if (p.sp) return MEGA_ERR_ARG;
+    const bool streamf = mega_igemm8_streaming(p.R * p.S, p.K) && p.ksplit == 1;
+    if (bm == 256 && streamf) return out_f32 ? launch8<float, 2, 1, 0, 0, f16_t>(p, st) : launch8<f16_t, 2, 1, 0, 0, f16_t>(p, st);
+    if (bm == 192 && streamf) return out_f32 ? launch8<float, 1, 1, 0, 0, f16_t>(p, st) : launch8<f16_t, 1, 1, 0, 0, f16_t>(p, st);
+    if (bm == 256) return out_f32 ? launch8<float, 2, 0, 0, 0, f16_t>(p, st) : launch8<f16_t, 2, 0, 0, 0, f16_t>(p, st);
+    if (bm == 192) return out_f32 ? launch8<float, 1, 0, 0, 0, f16_t>(p, st) : launch8<f16_t, 1, 0, 0, 0, f16_t>(p, st);
+    return MEGA_ERR_ARG;
+  }
+  if (half_dtype != MEGA_BF16) return MEGA_ERR_ARG;
 #ifdef MEGA_EXPERIMENTS
   // Timing ablations / s_memtime timeline (tools/gpu/ablate8.py).  NOT part of the product library: this block
   // allocates, synchronises and prints, and its kernels return garbage by construction -- it only exists in a library

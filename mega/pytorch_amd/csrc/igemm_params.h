@@ -30,11 +30,12 @@ struct ConvParams {
 };
 
 // igemm8.hip: bf16 operands, 8 waves, 256 (BM8 rows) x 256 tile; returns MEGA_OK / MEGA_ERR_*.  out_f32: 0 bf16, 1 f32.
-int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, hipStream_t st);
+// half_dtype: MEGA_BF16 / MEGA_F16 = the 16-bit type of in / w / residual (and of the output when out_f32 == 0)
+int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, int half_dtype, hipStream_t st);
 // 1 when the shape is one igemm8 can take (bf16, Cin % 64 == 0, operands < 2 GiB, ...)
 int mega_igemm8_supports(const ConvParams& p);
 // 1 when a launch of `taps` = R * S kernel taps and GEMM depth K belongs to igemm8's streaming class (1x1, K <= 512)
 int mega_igemm8_streaming(int taps, int K);
 // conv64.hip: persistent 3x3 / 64 -> 64 channel kernel (layer1's conv2); bit-identical to the generic tiles
 int mega_conv64_supports(const ConvParams& p, int out_f32);
-int mega_conv64_launch(const ConvParams& p, hipStream_t st);
+int mega_conv64_launch(const ConvParams& p, int half_dtype, hipStream_t st);

@@ -666,7 +666,8 @@ __host__ __device__ constexpr int sp_group_off(int g) {
   return (gg / 7) * (SP_PH * SP_PS) + (gg % 7) * SP_PS;
 }
 
-template <bool U8>
+// HT: bf16_t or f16_t (IEEE half, round 6) = the type of the patch / weights in LDS and of the pooled output
+template <bool U8, typename HT = bf16_t>
 __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const void* __restrict__ in_, const bf16_t* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ bias,
                                                         bf16_t* __restrict__ out, int N, int H, int W, int Ho, int Wo, int Hp,
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const void* __restric
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int e = tid + 256 * i;
-    if (e < 3 * SP_PH * SP_PS) patch[e] = f32_to_bf16(pv[i]);
+    if (e < 3 * SP_PH * SP_PS) patch[e] = Half16<HT>::cvt(pv[i]);
   }
 #pragma unroll
   for (int i = 0; i < NWL; ++i) {
@@ -739,18 +740,16 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const void* __restric
   }
 #pragma unroll
   for (int ks = 0; ks < SM_K / 16; ++ks) {
-    uint4 bfr[2];
+    u32x4_t bfr[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const uint4*>(&wl[(j * 32 + p) * SM_WS + ks * 16 + half * 8]);
+    for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const u32x4_t*>(&wl[(j * 32 + p) * SM_WS + ks * 16 + half * 8]);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (wave + 4 * b < SP_NBLK) {    // (wave-uniform)
         const unsigned* base = reinterpret_cast<const unsigned*>(patch + pbase[b] + (half ? sp_group_off(2 * ks + 1) : sp_group_off(2 * ks)));
-        const uint4 a = make_uint4(base[0], base[1], base[2], base[3]);
+        const u32x4_t a = {base[0], base[1], base[2], base[3]};
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bfr[j]),
-                                                              acc[b][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[b][j] = Half16<HT>::mfma32(a, bfr[j], acc[b][j]);
       }
     }
   }
@@ -769,7 +768,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const void* __restric
           const int r = pix / SP_TX, c = pix - r * SP_TX;
           const int oy = oy0 + r, ox = ox0 + c;
           const bool ok = pix < SP_NPIX && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo;
-          *reinterpret_cast<unsigned short*>(smem + pix * OUT_PS + ch * 2) = ok ? (unsigned short)(f32_to_bf16(fmaxf(acc[b][j][q] * sc + bi, 0.f)) & 0x7fffu) : (unsigned short)0;   // +0, never -0: the pool below orders bit patterns
+          *reinterpret_cast<unsigned short*>(smem + pix * OUT_PS + ch * 2) = ok ? (unsigned short)(Half16<HT>::cvt(fmaxf(acc[b][j][q] * sc + bi, 0.f)) & 0x7fffu) : (unsigned short)0;   // +0, never -0: the pool below orders bit patterns
         }
       }
     }
@@ -789,7 +788,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const void* __restric
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const u16x8_t q = *reinterpret_cast<const u16x8_t*>(smem + ((2 * ty + dy) * SP_TX + 2 * tx + dx) * OUT_PS + cv * 16);
-        m = __builtin_elementwise_max(m, q);      // (non-negative bf16 values order like their bit patterns)
+        m = __builtin_elementwise_max(m, q);      // (non-negative bf16 / f16 values order like their bit patterns)
       }
     if (oy < Hp && ox < Wp) *reinterpret_cast<u16x8_t*>(out + (((size_t)n * Hp + oy) * Wp + ox) * 64 + cv * 8) = m;
   }
@@ -852,6 +851,12 @@ extern "C" int mega_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, i
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL((maxpool_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, N, H,
                        W, C, Ho, Wo);
+  } else if (dtype == MEGA_F16) {
+    if (C % 8) return MEGA_ERR_ARG;
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL((maxpool_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, (const f16_t*)in, (f16_t*)out, N, H,
+                       W, C, Ho, Wo);
   } else if (dtype == MEGA_F32) {
     if (C % 4) return MEGA_ERR_ARG;
     const size_t total = (size_t)N * Ho * Wo * (C / 4);
@@ -872,8 +877,8 @@ extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out
   if (!feat || !rois || !out || K < 0 || C <= 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0)
     return MEGA_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (in_nhwc && out_nhwc && dtype == out_dtype && C % (dtype == MEGA_BF16 ? 8 : 4) == 0) {
-    const int CV = C / (dtype == MEGA_BF16 ? 8 : 4);
+  if (in_nhwc && out_nhwc && dtype == out_dtype && C % (dtype != MEGA_F32 ? 8 : 4) == 0) {
+    const int CV = C / (dtype != MEGA_F32 ? 8 : 4);
     const long long total = (long long)K * pooled_h * pooled_w * CV;
     static const bool no_slice = getenv("MEGA_ROI_NO_XCD_SLICE") != nullptr;       // A/B switch (experiments)
     const bool sliced = !no_slice && CV % 8 == 0 && CV / 8 >= 16 && total / 8 >= 256 * 64;
@@ -883,6 +888,15 @@ extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out
     static const bool no_sep = getenv("MEGA_ROI_NO_SEPARABLE") != nullptr;         // A/B switch (experiments)
     // the separable per-ROI form: adaptive grid only (sampling_ratio > 0 spreads a bin's samples over a sparse patch);
     // ROIs whose patch exceeds its tables fall back inside the kernel, so no bound on the boxes is assumed here
+    if (dtype == MEGA_F16 && !no_sep && sampling_ratio <= 0 && pooled_w <= RS_MAXPW && pooled_h <= RS_MAXPW) {
+      if (!no_slice && CV % 8 == 0 && CV / 8 >= 16)
+        hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<f16_t, 8>), dim3((unsigned)(K * 8)), dim3(256), 0, st,
+                           (const f16_t*)feat, rois, (f16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w);
+      else
+        hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<f16_t, 1>), dim3((unsigned)K), dim3(256), 0, st,
+                           (const f16_t*)feat, rois, (f16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w);
+      return mega_check_launch();
+    }
     if (dtype == MEGA_BF16 && !no_sep && sampling_ratio <= 0 && pooled_w <= RS_MAXPW && pooled_h <= RS_MAXPW) {
       if (!no_slice && CV % 8 == 0 && CV / 8 >= 16)
         hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<bf16_t, 8>), dim3((unsigned)(K * 8)), dim3(256), 0, st,
@@ -898,6 +912,12 @@ extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out
     else if (dtype == MEGA_BF16)
       hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<bf16_t, false>), vgrid, dim3(256), 0, st, (const bf16_t*)feat, rois,
                          (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+    else if (dtype == MEGA_F16 && sliced)
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<f16_t, true>), vgrid, dim3(256), 0, st, (const f16_t*)feat, rois,
+                         (f16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+    else if (dtype == MEGA_F16)
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<f16_t, false>), vgrid, dim3(256), 0, st, (const f16_t*)feat, rois,
+                         (f16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
     else if (dtype == MEGA_F32 && sliced)
       hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, true>), vgrid, dim3(256), 0, st, (const float*)feat, rois,
                          (float*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
@@ -913,6 +933,9 @@ extern "C" int mega_roi_align_fwd(const void* feat, const float* rois, void* out
   if (dtype == MEGA_BF16 && out_dtype == MEGA_BF16)
     hipLaunchKernelGGL((roi_align_kernel<bf16_t, bf16_t>), grid, dim3(threads), 0, st, (const bf16_t*)feat, rois,
                        (bf16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio, in_nhwc, out_nhwc);
+  else if (dtype == MEGA_F16 && out_dtype == MEGA_F16)
+    hipLaunchKernelGGL((roi_align_kernel<f16_t, f16_t>), grid, dim3(threads), 0, st, (const f16_t*)feat, rois,
+                       (f16_t*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio, in_nhwc, out_nhwc);
   else if (dtype == MEGA_F32 && out_dtype == MEGA_F32)
     hipLaunchKernelGGL((roi_align_kernel<float, float>), grid, dim3(threads), 0, st, (const float*)feat, rois,
                        (float*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio, in_nhwc, out_nhwc);
@@ -946,21 +969,34 @@ extern "C" int mega_avgpool2x2_ceil_nhwc(const void* in, void* out, int N, int H
 // (u8 = 0) or the uint8 frames [N][H][W][3] RGB with the preprocessing on the patch load (u8 = 1, as
 // mega_stem_conv_bn_relu_bf16_u8); out: NHWC bf16 [N][Hp][Wp][64], Hp = (Ho - 1) / 2 + 1 with Ho = (H - 1) / 2 + 1.
 // Bit-identical to mega_stem_conv_bn_relu_bf16[_u8] followed by mega_maxpool3x3s2_nhwc.
-extern "C" int mega_stem_pool_bf16(const void* in, int u8, const void* w_n176_bf16, const float* scale, const float* bias,
-                                   void* out, int N, int H, int W, float mean0, float mean1, float mean2, int to_bgr,
-                                   void* stream) {
+// dtype: MEGA_BF16, or MEGA_F16 (weights and output IEEE half).
+extern "C" int mega_stem_pool_dt(const void* in, int u8, const void* w_n176, const float* scale, const float* bias,
+                                 void* out, int N, int H, int W, float mean0, float mean1, float mean2, int to_bgr,
+                                 int dtype, void* stream) {
   mega_clear_error();
-  if (!in || !w_n176_bf16 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
+  if (!in || !w_n176 || !scale || !bias || !out || N <= 0 || H <= 0 || W <= 0) return MEGA_ERR_ARG;
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
   dim3 grid(cdiv(Wp, SP_PX), cdiv(Hp, SP_PY), N);
-  if (u8)
-    hipLaunchKernelGGL(stem_pool_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)w_n176_bf16, scale,
-                       bias, (bf16_t*)out, N, H, W, Ho, Wo, Hp, Wp, mean0, mean1, mean2, to_bgr);
-  else
-    hipLaunchKernelGGL(stem_pool_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, (const bf16_t*)w_n176_bf16, scale,
-                       bias, (bf16_t*)out, N, H, W, Ho, Wo, Hp, Wp, 0.f, 0.f, 0.f, 0);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* w = (const bf16_t*)w_n176;
+  bf16_t* o = (bf16_t*)out;
+  if (!u8) { mean0 = mean1 = mean2 = 0.f; to_bgr = 0; }
+  if (dtype == MEGA_F16) {
+    if (u8) hipLaunchKernelGGL((stem_pool_kernel<true, f16_t>), grid, dim3(256), 0, st, in, w, scale, bias, o, N, H, W, Ho, Wo, Hp, Wp, mean0, mean1, mean2, to_bgr);
+    else hipLaunchKernelGGL((stem_pool_kernel<false, f16_t>), grid, dim3(256), 0, st, in, w, scale, bias, o, N, H, W, Ho, Wo, Hp, Wp, mean0, mean1, mean2, to_bgr);
+  } else {
+    if (u8) hipLaunchKernelGGL((stem_pool_kernel<true, bf16_t>), grid, dim3(256), 0, st, in, w, scale, bias, o, N, H, W, Ho, Wo, Hp, Wp, mean0, mean1, mean2, to_bgr);
+    else hipLaunchKernelGGL((stem_pool_kernel<false, bf16_t>), grid, dim3(256), 0, st, in, w, scale, bias, o, N, H, W, Ho, Wo, Hp, Wp, mean0, mean1, mean2, to_bgr);
+  }
   return mega_check_launch();
+}
+
+extern "C" int mega_stem_pool_bf16(const void* in, int u8, const void* w_n176_bf16, const float* scale, const float* bias,
+                                   void* out, int N, int H, int W, float mean0, float mean1, float mean2, int to_bgr,
+                                   void* stream) {
+  return mega_stem_pool_dt(in, u8, w_n176_bf16, scale, bias, out, N, H, W, mean0, mean1, mean2, to_bgr, MEGA_BF16, stream);
 }
 
 // mega_roi_align_fwd for f32 NHWC features with the result as split-precision planes: out bf16 [K][2 PH PW C] =

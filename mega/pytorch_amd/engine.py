@@ -312,7 +312,7 @@ class ClipEngine(object):
         # bf16 mode on the device: the stem reads the uint8 frames itself (preprocessing on its patch load: no f32 image
         # in HBM, no preprocess launch -- same bits); everything else gets the preprocessed f32 batch
         from .modeling import compute_dtype
-        u8 = (raw is not None and raw.is_cuda and compute_dtype(m.cfg) == torch.bfloat16
+        u8 = (raw is not None and raw.is_cuda and compute_dtype(m.cfg) in (torch.bfloat16, torch.float16)
               and getattr(m, "stem_reads_u8", False))
         norm = (raw.mean, raw.to_bgr) if u8 else None
 

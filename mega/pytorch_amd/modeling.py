@@ -27,7 +27,9 @@ from .relation import (RelationWeights, cat_rows, cat_rows_many, position_logits
 from .structures import BoxList, cat_boxlist, to_image_list
 from .synth import _cell_anchors
 
-_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float": torch.float32, "bf16": torch.bfloat16}
+_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float": torch.float32, "bf16": torch.bfloat16,
+           "float16": torch.float16, "fp16": torch.float16, "half": torch.float16}
+_HALF = (torch.bfloat16, torch.float16)      # the 16-bit matrix-core operand types (same MFMA rate, 8 / 11 significant bits)
 
 
 def compute_dtype(cfg):
@@ -43,7 +45,23 @@ def stream_dtype(cfg):
     bf16 roundings of the stream: logit error median 1.7e-3 against the f32 oracle instead of ~1e-4)."""
     if compute_dtype(cfg) == torch.float32:
         return torch.float32
-    return _DTYPES[str(getattr(cfg, "HEAD_STREAM", "float32"))]
+    st = _DTYPES[str(getattr(cfg, "HEAD_STREAM", "float32"))]
+    if compute_dtype(cfg) == torch.float16 and st != torch.float32:
+        raise ValueError("DTYPE float16 keeps the head's activation stream in float32 (HEAD_STREAM)")
+    return st
+
+
+def head_dtype(cfg):
+    """operand dtype of the aggregation head's matrix-core GEMMs / attention (Wq, Wk, Wv projections, Q K^T, P V).  The
+    compute dtype, except in float16 mode: there cfg.HEAD_DTYPE chooses -- "bfloat16" (default): the FRAME STAGE runs in
+    fp16 and the head is the bf16 head (f32 activation stream, bf16 rounded copies into the projections / Q K^T / P V;
+    its own error, 1.0-1.8e-4 of the logits, is not what limits the mode: tools/fp16_prediction_cpu.py, the head in fp16
+    moves the logit error from 5.5e-4 to 5.4e-4); "float16": fp16 operands in the head too (CPU twins only: relation.hip has
+    no fp16 instantiation)."""
+    d = compute_dtype(cfg)
+    if d == torch.float16:
+        return _DTYPES[str(getattr(cfg, "HEAD_DTYPE", "bfloat16"))]
+    return d
 
 
 def conv_mode(cfg):
@@ -54,12 +72,16 @@ def conv_mode(cfg):
               accumulation (x.W to ~2^-16); the stem, the narrow RPN outputs and ROIAlign stay exact f32.  The parity mode
               at matrix-core rates.
       "bf16"  cfg.DTYPE bfloat16 (what bench.py times)
+      "f16"   cfg.DTYPE float16 (round 6): the same kernels instantiated for IEEE half operands -- identical MFMA rate and
+              bytes, 11 significant bits instead of 8 (1/8 of the rounding noise); activations are bounded by 65 504
       "wide"  cfg.DTYPE bfloat16 + cfg.RESIDUAL_STREAM "planes": bf16 convolutions, but the residual trunk of layer1-3 /
               res5 (resnet.py:324-344 `out += identity`, 33 + 3 times in R-101-C4) is carried as planes: a conv reads the
               hi plane (= the bf16 tensor it always read), conv3 adds hi + lo in f32 and writes both planes, so the trunk is
               never rounded to 8 bits."""
     if compute_dtype(cfg) == torch.float32:
         return "x3" if str(getattr(cfg, "F32_CONV", "exact")) == "bf16x3" else "f32"
+    if compute_dtype(cfg) == torch.float16:
+        return "f16"
     return "wide" if str(getattr(cfg, "RESIDUAL_STREAM", "bfloat16")) == "planes" else "bf16"
 
 
@@ -209,13 +231,13 @@ class Bottleneck(_Packed):
     fuse = True        # layer1's identity blocks as ONE kernel (ops.bottleneck64); False / MEGA_FUSE_BOTTLENECK=0: three launches
 
     def _fusable(self, x):
-        return (self.fuse and x.dtype == torch.bfloat16 and x.is_cuda and self.downsample is None and self.stride == 1
+        return (self.fuse and x.dtype in _HALF and x.is_cuda and self.downsample is None and self.stride == 1
                 and self.dilation == 1 and self.conv1.in_channels == 256 and self.conv1.out_channels == 64
                 and self.conv3.out_channels == 256 and x.shape[0] * (-(-x.shape[1] // 8)) * (-(-x.shape[2] // 16)) >= 128
                 and os.environ.get("MEGA_FUSE_BOTTLENECK", "1") != "0")
 
     def _fusable_ds(self, x):
-        return (self.fuse and x.dtype == torch.bfloat16 and x.is_cuda and self.downsample is not None and self.stride == 1
+        return (self.fuse and x.dtype in _HALF and x.is_cuda and self.downsample is not None and self.stride == 1
                 and self.down_stride == 1 and self.dilation == 1 and self.conv1.in_channels == 64
                 and self.conv1.out_channels == 64 and self.conv3.out_channels == 256
                 and x.shape[0] * (-(-x.shape[1] // 8)) * (-(-x.shape[2] // 16)) >= 128
@@ -269,21 +291,22 @@ class BaseStem(_Packed):
         s, b = self.bn1.folded()
         w = self.conv1.weight.detach().float().permute(1, 2, 3, 0).reshape(147, 64).contiguous()
         pk = {"w": w.to(device), "s": s.to(device), "b": b.to(device), "w160": None}
-        if dtype == torch.bfloat16:
-            pk["w160"] = ops.pack_stem_weight_bf16(self.conv1.weight).to(device)
+        if dtype in _HALF:
+            pk["w160"] = ops.pack_stem_weight_bf16(self.conv1.weight, dtype).to(device)
         return pk
 
     def run(self, img_nchw_f32, dtype):
         pk = self._packed(dtype, img_nchw_f32.device)
-        if pk["w160"] is not None and _FUSE_STEM_POOL:
+        # (float16 on the device: the fused kernel only -- stem_mfma_kernel / stem_conv_kernel have no fp16 instantiation)
+        if pk["w160"] is not None and (_FUSE_STEM_POOL or (dtype == torch.float16 and img_nchw_f32.is_cuda)):
             return ops.stem_pool(img_nchw_f32, pk["w160"], pk["s"], pk["b"])
         y = ops.stem(img_nchw_f32, pk["w"], pk["s"], pk["b"], dtype, w_n160=pk["w160"])
         return ops.maxpool3x3s2(y)
 
-    def run_u8(self, frames_u8, mean, to_bgr):
-        """bf16 mode: the stem reads the uint8 frames [N,H,W,3] themselves (preprocessing on the patch load)"""
-        pk = self._packed(torch.bfloat16, frames_u8.device)
-        if _FUSE_STEM_POOL:
+    def run_u8(self, frames_u8, mean, to_bgr, dtype=torch.bfloat16):
+        """bf16 / f16 mode: the stem reads the uint8 frames [N,H,W,3] themselves (preprocessing on the patch load)"""
+        pk = self._packed(dtype, frames_u8.device)
+        if _FUSE_STEM_POOL or dtype == torch.float16:
             return ops.stem_pool(frames_u8, pk["w160"], pk["s"], pk["b"], mean, to_bgr)
         return ops.maxpool3x3s2(ops.stem_u8(frames_u8, pk["w160"], pk["s"], pk["b"], mean, to_bgr))
 
@@ -325,8 +348,8 @@ class ResNet(nn.Module):
     def run_nhwc(self, x, u8_norm=None):
         """forward() without the NCHW view: -> C4 as a contiguous NHWC tensor, or as ops.Planes (conv_mode "x3" / "wide")"""
         if u8_norm is not None:
-            assert self.dtype == torch.bfloat16 and x.dtype == torch.uint8
-            y = self.stem.run_u8(x.contiguous(), u8_norm[0], u8_norm[1])
+            assert self.dtype in _HALF and x.dtype == torch.uint8
+            y = self.stem.run_u8(x.contiguous(), u8_norm[0], u8_norm[1], self.dtype)
         else:
             y = self.stem.run(x.float().contiguous(), self.dtype)
         if self.mode == "x3":
@@ -334,7 +357,7 @@ class ResNet(nn.Module):
         for name in self.stages:
             blocks = list(getattr(self, name))
             n = y.shape[0]
-            if name == "layer3" and _L3_SPLIT and not isinstance(y, ops.Planes) and y.is_cuda and y.dtype == torch.bfloat16 and n >= 32 and n % 2 == 0:
+            if name == "layer3" and _L3_SPLIT and not isinstance(y, ops.Planes) and y.is_cuda and y.dtype in _HALF and n >= 32 and n % 2 == 0:
                 # layer3 in two halves of the batch, each through all its blocks: at 20 frames of 600x1000 the working set of a
                 # conv3 + residual layer (221 MB) stays in the 256 MB Infinity Cache -- 4.6 TB/s of algorithmic bytes against
                 # 3.5-3.8 at 40 frames (tools/gpu/l3_tiles.py); every conv is batch-invariant, so the bits do not change
@@ -584,7 +607,8 @@ class MEGAFeatureExtractor(_Packed):
         else:
             self.global_res_stage = 0
         self.out_channels = rep
-        self.dtype = compute_dtype(cfg)
+        self.dtype = compute_dtype(cfg)      # frame stage: res5, ROIAlign, fc0
+        self.hdtype = head_dtype(cfg)        # the head's matrix-core operands (= self.dtype except in float16 mode, see head_dtype)
         self.stream = stream_dtype(cfg)
         self.mode = conv_mode(cfg)
         # cfg.F32_HEAD_LINEAR: "auto" (with F32_CONV "bf16x3": the head's Wq / Wk / Wv projections and stage FCs run in
@@ -602,11 +626,12 @@ class MEGAFeatureExtractor(_Packed):
     # ---- kernel operands
     def _pack(self, dtype, device):
         sd = {k: v.detach() for k, v in self.state_dict().items()}
-        sv = self.stream != dtype      # f32 head stream in bf16 mode: split Wv (relation.project_v)
+        hd = self.hdtype if dtype == self.dtype else dtype
+        sv = self.stream != hd         # f32 head stream over 16-bit operands: split Wv (relation.project_v)
         hx3 = self.head_x3             # conv_mode "x3": the head's projections / stage FCs in split precision too
-        pk = {"local": [RelationWeights(sd, "", "l_", i, dtype, device, with_pos=True, split_v=sv, x3=hx3)
+        pk = {"local": [RelationWeights(sd, "", "l_", i, hd, device, with_pos=True, split_v=sv, x3=hx3)
                         for i in range(self.stage)],
-              "global": [RelationWeights(sd, "", "g_", i, dtype, device, with_pos=False, split_v=sv, x3=hx3)
+              "global": [RelationWeights(sd, "", "g_", i, hd, device, with_pos=False, split_v=sv, x3=hx3)
                          for i in range(self.global_res_stage + 1)] if self.global_enable else []}
         # fc0 consumes the bin-major [K, 49, C] ROIAlign output: permute its columns from (c, ph, pw) to (ph, pw, c)
         w0 = self.l_fcs[0].weight.detach()

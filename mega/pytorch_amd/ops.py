@@ -13,15 +13,16 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+F32, BF16, F16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_HALF = (torch.bfloat16, torch.float16)      # 16-bit matrix-core operand types
 
 
 def _dt(t):
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise TypeError("unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
+        raise TypeError("unsupported dtype %s (float32 / bfloat16 / float16 only)" % t.dtype)
 
 
 _LAUNCH = threading.local()
@@ -130,9 +131,9 @@ def _igemm_family(lib, M, Cout, K, dtype, shape=None):
     # one family = one rocprofv3 symbol: igemm8_kernel<OT, ...> is instantiated per OUTPUT type, so a bf16 launch that writes
     # f32 (fc0's split-K partial sums, the RPN head's f32 logits) is a different symbol from the bf16-output launches of the
     # same tile ("_f32out")
-    f32out = shape is not None and dtype == torch.bfloat16 and (shape[-1] == torch.float32 or (kind in (7, 8) and lib.mega_conv2d_nhwc_workspace_bytes(M, Cout, K) > 0))
-    return "igemm%s_%s_%dx%d%s" % ({8: "8", 7: "8s"}.get(kind, ""), "bf16" if dtype == torch.bfloat16 else "f32", t // 1000,
-                                   t % 1000, "_f32out" if f32out else "")
+    f32out = shape is not None and dtype in _HALF and (shape[-1] == torch.float32 or (kind in (7, 8) and lib.mega_conv2d_nhwc_workspace_bytes(M, Cout, K) > 0))
+    return "igemm%s_%s_%dx%d%s" % ({8: "8", 7: "8s"}.get(kind, ""), {torch.bfloat16: "bf16", torch.float16: "f16"}.get(dtype, "f32"),
+                                   t // 1000, t % 1000, "_f32out" if f32out else "")
 
 
 def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,
@@ -184,10 +185,10 @@ def bottleneck64(x, w1, s1, b1, w2, s2, b2, w3, s3, b3):
     _gpu(x, w1, s1, b1, w2, s2, b2, w3, s3, b3)
     lib = _lib.load()
     N, H, W, C = x.shape
-    assert C == 256 and x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert C == 256 and x.dtype in _HALF and x.is_contiguous()
     assert tuple(w1.shape) == (64, 1, 1, 256) and tuple(w2.shape) == (64, 3, 3, 64) and tuple(w3.shape) == (256, 1, 1, 64)
     for t in (w1, w2, w3):
-        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+        assert t.dtype == x.dtype and t.is_contiguous()
     for v, n in ((s1, 64), (b1, 64), (s2, 64), (b2, 64), (s3, 256), (b3, 256)):
         assert v.dtype == torch.float32 and v.numel() == n and v.is_contiguous()
     if x.numel() * 2 >= 0x7FF00000:
@@ -195,10 +196,10 @@ def bottleneck64(x, w1, s1, b1, w2, s2, b2, w3, s3, b3):
     out = torch.empty_like(x)
     px = float(N * H * W)
     _tok = _pb("bneck64_fused", 2.0 * px * (256 * 64 + 576 * 64 + 64 * 256), px * 1024.0)
-    rc = lib.mega_bottleneck64_fwd(_ptr(x), _ptr(w1), _ptr(s1), _ptr(b1), _ptr(w2), _ptr(s2), _ptr(b2), _ptr(w3), _ptr(s3),
-                                   _ptr(b3), _ptr(out), N, H, W, _stream())
+    rc = lib.mega_bottleneck64_fwd_dt(_ptr(x), _ptr(w1), _ptr(s1), _ptr(b1), _ptr(w2), _ptr(s2), _ptr(b2), _ptr(w3), _ptr(s3),
+                                      _ptr(b3), _ptr(out), N, H, W, _dt(x), _stream())
     _pe(_tok)
-    _lib.check(rc, "mega_bottleneck64_fwd")
+    _lib.check(rc, "mega_bottleneck64_fwd_dt")
     return out
 
 
@@ -209,22 +210,22 @@ def bottleneck64_ds(x, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, bd):
     _gpu(x, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, bd)
     lib = _lib.load()
     N, H, W, C = x.shape
-    assert C == 64 and x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert C == 64 and x.dtype in _HALF and x.is_contiguous()
     assert tuple(w1.shape) == (64, 1, 1, 64) and tuple(w2.shape) == (64, 3, 3, 64)
     assert tuple(w3.shape) == (256, 1, 1, 64) and tuple(wd.shape) == (256, 1, 1, 64)
     for t in (w1, w2, w3, wd):
-        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+        assert t.dtype == x.dtype and t.is_contiguous()
     for v, n in ((s1, 64), (b1, 64), (s2, 64), (b2, 64), (s3, 256), (b3, 256), (sd, 256), (bd, 256)):
         assert v.dtype == torch.float32 and v.numel() == n and v.is_contiguous()
-    out = torch.empty((N, H, W, 256), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((N, H, W, 256), dtype=x.dtype, device=x.device)
     if out.numel() * 2 >= 0x7FF00000:
         raise ValueError("bottleneck64_ds: output of %.2f GiB; 32-bit buffer offsets (< 2 GiB)" % (out.numel() * 2 / 2.0 ** 30))
     px = float(N * H * W)
     _tok = _pb("bneck64_fused", 2.0 * px * (64 * 64 + 576 * 64 + 2 * 64 * 256), px * 640.0)
-    rc = lib.mega_bottleneck64_ds_fwd(_ptr(x), _ptr(w1), _ptr(s1), _ptr(b1), _ptr(w2), _ptr(s2), _ptr(b2), _ptr(w3), _ptr(s3),
-                                      _ptr(b3), _ptr(wd), _ptr(sd), _ptr(bd), _ptr(out), N, H, W, _stream())
+    rc = lib.mega_bottleneck64_ds_fwd_dt(_ptr(x), _ptr(w1), _ptr(s1), _ptr(b1), _ptr(w2), _ptr(s2), _ptr(b2), _ptr(w3), _ptr(s3),
+                                         _ptr(b3), _ptr(wd), _ptr(sd), _ptr(bd), _ptr(out), N, H, W, _dt(x), _stream())
     _pe(_tok)
-    _lib.check(rc, "mega_bottleneck64_ds_fwd")
+    _lib.check(rc, "mega_bottleneck64_ds_fwd_dt")
     return out
 
 
@@ -297,25 +298,25 @@ def stem_pool(x, w_n160, scale, bias, mean=None, to_bgr=True):
         assert x.dtype == torch.float32
         mean = (0.0, 0.0, 0.0)
     assert C == 3 and x.is_contiguous()
-    assert w_n160.dtype == torch.bfloat16 and tuple(w_n160.shape) == (64, 176) and w_n160.is_contiguous()
+    assert w_n160.dtype in _HALF and tuple(w_n160.shape) == (64, 176) and w_n160.is_contiguous()
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
-    out = torch.empty((N, Hp, Wp, 64), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((N, Hp, Wp, 64), dtype=w_n160.dtype, device=x.device)      # (the weights' 16-bit type is the output's)
     _tok = _pb("stem", 2.0 * N * Ho * Wo * 64 * 147, x.numel() * x.element_size() + out.numel() * 2)
-    rc = lib.mega_stem_pool_bf16(_ptr(x), int(u8), _ptr(w_n160), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
-                                 float(mean[0]), float(mean[1]), float(mean[2]), int(to_bgr), _stream())
+    rc = lib.mega_stem_pool_dt(_ptr(x), int(u8), _ptr(w_n160), _ptr(scale), _ptr(bias), _ptr(out), N, H, W,
+                               float(mean[0]), float(mean[1]), float(mean[2]), int(to_bgr), _dt(w_n160), _stream())
     _pe(_tok)
-    _lib.check(rc, "mega_stem_pool_bf16")
+    _lib.check(rc, "mega_stem_pool_dt")
     return out
 
 
-def pack_stem_weight_bf16(w_oihw):
-    """conv1.weight [64,3,7,7] -> bf16 [64,176]: column k = ((c*7+r)*8 + s for the 7 taps s of kernel row (c, r); the
+def pack_stem_weight_bf16(w_oihw, dtype=torch.bfloat16):
+    """conv1.weight [64,3,7,7] -> bf16 (or f16) [64,176]: column k = ((c*7+r)*8 + s for the 7 taps s of kernel row (c, r); the
     8th column of every group and columns 168..175 are zero (the kernel reads 8 consecutive patch pixels per group)."""
     w = torch.zeros((64, 22, 8), dtype=torch.float32, device=w_oihw.device)
     w[:, :21, :7] = w_oihw.detach().float().reshape(64, 21, 7)
     w = w.reshape(64, 176)
-    return w.to(torch.bfloat16).contiguous()
+    return w.to(dtype).contiguous()
 
 
 def maxpool3x3s2(x):
@@ -499,7 +500,7 @@ def position_logits(rois_q, rois_k, wg_t, bg, dim_mat, precise=True, tiled=False
     lib = _lib.load()
     Nq, Nk = rois_q.shape[0], rois_k.shape[0]
     if tiled:
-        assert not precise
+        assert not precise and tiled in (True, torch.bfloat16), "the tile-ordered position logits are bf16"
         kt = (Nk + 31) // 32
         out = torch.empty((16, kt, Nq, 32), dtype=torch.bfloat16, device=rois_q.device)
         _tok = _pb("pos_logits", 2.0 * Nq * Nk * 1024, out.numel() * 2.0)
@@ -576,6 +577,7 @@ def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, t
     ONE launch per 20 problems, the f32 forms fall back to one call per problem."""
     if not tiled:
         return [position_logits(a, b, wg_t, bg, dim_mat, precise=precise, tiled=False) for a, b in zip(rois_qs, rois_ks)]
+    assert tiled in (True, torch.bfloat16), "the tile-ordered position logits are bf16"
     _gpu(wg_t, bg, dim_mat, *rois_qs, *rois_ks)
     lib = _lib.load()
     outs, keep = [], []
@@ -729,13 +731,15 @@ def multi_cat(groups):
     return outs
 
 
-def cat_rows_cast_bf16(pieces):
-    """torch.cat(pieces, 0).to(bfloat16) for f32 row blocks [n_i, K] (K % 8 == 0, unit column stride) in ONE launch that
-    never writes the f32 concatenation: the K / V sources of the relation modules under an f32 activation stream."""
+def cat_rows_cast_bf16(pieces, dtype=torch.bfloat16):
+    """torch.cat(pieces, 0).to(dtype) (bfloat16 / float16) for f32 row blocks [n_i, K] (K % 8 == 0, unit column stride) in
+    ONE launch that never writes the f32 concatenation: the K / V sources of the relation modules under an f32 activation
+    stream."""
     pieces = [p for p in pieces if p.shape[0] > 0]
     lib = _lib.load()
     K = pieces[0].shape[1]
-    out = torch.empty((sum(p.shape[0] for p in pieces), K), dtype=torch.bfloat16, device=pieces[0].device)
+    assert dtype in _HALF
+    out = torch.empty((sum(p.shape[0] for p in pieces), K), dtype=dtype, device=pieces[0].device)
     arr = (_CopySeg * len(pieces))()
     o, nbytes = 0, 0
     for i, p in enumerate(pieces):
@@ -748,9 +752,9 @@ def cat_rows_cast_bf16(pieces):
         o += p.shape[0]
         nbytes += p.numel() * 6
     _tok = _pb("assemble", 0.0, nbytes)
-    rc = lib.mega_copy_cast_segments(ctypes.addressof(arr), len(pieces), _stream())
+    rc = lib.mega_copy_cast_segments_dt(ctypes.addressof(arr), len(pieces), _DT[dtype], _stream())
     _pe(_tok)
-    _lib.check(rc, "mega_copy_cast_segments")
+    _lib.check(rc, "mega_copy_cast_segments_dt")
     return out
 
 
@@ -791,19 +795,23 @@ def preprocess_frames(frames_u8, mean, to_bgr=True, out=None):
     return out
 
 
-def cast_bf16(x):
-    """f32 -> bf16 copy (round to nearest even) of a contiguous tensor; a bf16 input is returned as it is."""
-    if x.dtype == torch.bfloat16:
+def cast_half(x, dtype):
+    """f32 -> bf16 / f16 copy (round to nearest even) of a contiguous tensor; an input of that dtype is returned as it is."""
+    if x.dtype == dtype:
         return x
     _gpu(x)
     lib = _lib.load()
-    assert x.dtype == torch.float32 and x.is_contiguous()
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    assert x.dtype == torch.float32 and x.is_contiguous() and dtype in _HALF
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
     _tok = _pb("assemble", 0.0, x.numel() * 6.0)
-    rc = lib.mega_cast_f32_to_bf16(_ptr(x), _ptr(out), x.numel(), _stream())
+    rc = lib.mega_cast_f32_to_half(_ptr(x), _ptr(out), x.numel(), _DT[dtype], _stream())
     _pe(_tok)
-    _lib.check(rc, "mega_cast_f32_to_bf16")
+    _lib.check(rc, "mega_cast_f32_to_half")
     return out
+
+
+def cast_bf16(x):
+    return cast_half(x, torch.bfloat16)
 
 
 def split_bf16x3(x):

@@ -55,7 +55,7 @@ class RelationWeights(object):
 def op_dtype(w, t):
     """t as a GEMM operand of w's projections: the bf16 mode with an f32 activation stream (cfg.HEAD_STREAM) hands the
     matrix cores a ROUNDED COPY of the stream (ops.cast_bf16) -- the stream itself, the attention's residual, stays f32."""
-    return t if t.dtype == w.wq.dtype else ops.cast_bf16(t.contiguous())
+    return t if t.dtype == w.wq.dtype else ops.cast_half(t.contiguous(), w.wq.dtype)
 
 
 def project_v(w, ref, ld):
@@ -96,7 +96,7 @@ def relation_attention_forward(w, x, ref, rois_q=None, rois_k=None, residual=Tru
     pos = None
     if w.with_pos:
         fast = w.wq.dtype != torch.float32   # bf16 mode: matrix-core kernel, bf16 logits in the attention's tile order
-        pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
+        pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=w.wq.dtype if fast else False)
     out = ops.relation_attention(q, k_all, vt_all, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
     return (out, k, vt) if return_kv else out
 
@@ -196,7 +196,7 @@ def relation_project_batched(w, xs, refs, want_x=False, also_cat=(), pad_refs=Fa
         # launch, the f32 concatenation is never written (ops.cat_rows_cast_bf16)
         cats = cat_rows_many([xf] + [list(c) for c in also_cat])
         x_all, cats = cats[0], [None] + cats
-        r_op = ops.cat_rows_cast_bf16(rf)
+        r_op = ops.cat_rows_cast_bf16(rf, w.wq.dtype)
     else:
         cats = cat_rows_many([rf, xf] + [list(c) for c in also_cat])
         x_all = cats[1]
@@ -234,7 +234,7 @@ def relation_attend(w, x, q, k, vt, rois_q=None, rois_k=None, mem_kv=None, resid
     pos = None
     if w.with_pos:
         fast = w.wq.dtype != torch.float32
-        pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
+        pos = ops.position_logits(rois_q, rois_k, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=w.wq.dtype if fast else False)
     return ops.relation_attention(q, k, vv, Nk, pos=pos, resid=x if residual else None, bias_v=w.bv)
 
 
@@ -288,4 +288,5 @@ def position_logits_for(w, rois_qs, rois_ks):
     20 problems in bf16 mode).  They depend on boxes only, so a caller that knows the key sets' boxes of a stage before its
     features can compute them early, beside other work (MEGAFeatureExtractor.aggregate_batch does, on a side stream)."""
     fast = w.wq.dtype != torch.float32
-    return ops.position_logits_batched(rois_qs, rois_ks, w.wg_t, w.bg, w.dim_mat, precise=not fast, tiled=fast)
+    return ops.position_logits_batched(rois_qs, rois_ks, w.wg_t, w.bg, w.dim_mat, precise=not fast,
+                                       tiled=w.wq.dtype if fast else False)

@@ -142,8 +142,8 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     s = torch.bmm(qh, kh.transpose(1, 2)) / math.sqrt(64.0)
     if pos is not None:
         s = s + pos[:, :, :Nk]
-    if q.dtype == torch.bfloat16:      # the kernel's bf16 mode: P rounded for the PV MFMA, row sum over the rounded values
-        e = torch.exp(s - s.max(dim=2, keepdim=True).values).to(torch.bfloat16).float()
+    if q.dtype in (torch.bfloat16, torch.float16):   # the kernel's 16-bit modes: P rounded for the PV MFMA, row sum over the rounded values
+        e = torch.exp(s - s.max(dim=2, keepdim=True).values).to(q.dtype).float()
         p = e / e.sum(dim=2, keepdim=True)
     else:
         p = F.softmax(s, dim=2)
@@ -160,8 +160,12 @@ def cast_bf16(x):
     return x.to(torch.bfloat16)
 
 
-def cat_rows_cast_bf16(pieces):
-    return torch.cat([p for p in pieces if p.shape[0] > 0], dim=0).to(torch.bfloat16)
+def cast_half(x, dtype):
+    return x.to(dtype)
+
+
+def cat_rows_cast_bf16(pieces, dtype=torch.bfloat16):
+    return torch.cat([p for p in pieces if p.shape[0] > 0], dim=0).to(dtype)
 
 
 def split_bf16x3(x):
@@ -283,7 +287,7 @@ def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio):
     return _planes(y.reshape(y.shape[0], -1).float())
 
 
-ALL = ["split_planes", "conv2d_sp", "linear_sp", "roi_align_planes", "cast_bf16", "cat_rows_cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+ALL = ["split_planes", "conv2d_sp", "linear_sp", "roi_align_planes", "cast_bf16", "cast_half", "cat_rows_cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames", "position_logits_batched",
        "relation_attention_batched", "postprocess_batched"]
 
@@ -301,8 +305,8 @@ def resize_bilinear_u8(frames_u8, out_hw, tables=None):
     return torch.from_numpy(np.stack([pil_resize.resize_bilinear_u8(f, out_hw[0], out_hw[1]) for f in a]))
 
 
-def pack_stem_weight_bf16(w_oihw):
-    return torch.zeros((64, 176), dtype=torch.bfloat16)      # (the twin's stem() reads the f32 taps; a placeholder operand)
+def pack_stem_weight_bf16(w_oihw, dtype=torch.bfloat16):
+    return torch.zeros((64, 176), dtype=dtype)      # (the twin's stem() reads the f32 taps; a placeholder operand)
 
 
 def install(monkeypatch):
