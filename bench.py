@@ -301,7 +301,14 @@ def cpu_baseline(arch, sd, H, W, n_timed):
                   "measured": "build container, %d threads: reference %.2f s / port %.2f s per steady key frame"
                               % (r["host_threads"], r["mega_r101"]["reference_steady_s"], r["mega_r101"]["port_steady_s"]),
                   "source": "profiles/r03_cpu_port_vs_reference.json"}
+    ref_eq = None
+    if vs_ref is not None:     # the reference's own CPU path on these cores = the port's rate x the measured factor
+        ref_eq = {"value": vs_ref["reference_equivalent_frames_per_s"], "unit": "frames/s",
+                  "factor": vs_ref["port_over_reference_time"], "factor_is": "port seconds / reference seconds per steady key frame "
+                  "(unmodified mega_core through oracle/ref_shim.py against oracle/mega_oracle.py, same weights, frames and threads)",
+                  "factor_source": vs_ref["source"], "factor_measured_on": vs_ref["measured"], "cores": cores}
     return {"value": round(fps, 4), "unit": "frames/s", "cores": cores, "kind": "port", "memory_frames": min(mem),
+            "reference_equivalent": ref_eq,
             "host_threads_available": avail,
             "thread_sweep_s_per_key_frame": {str(c): round(v, 3) for c, v in swept.items()},
             "vs_unmodified_reference": vs_ref,

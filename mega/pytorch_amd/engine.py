@@ -187,8 +187,10 @@ class ClipEngine(object):
         self.owner_aligned = bool(self.batch_aggregation and static_aggregation is False and hasattr(model, "base_num")
                                   and getattr(fe, "cache_memory_kv", False))
         self.wire = {}                    # bytes this rank contributed to each kind of collective (tests, diagnostics)
-        self.wire_order = []              # and the kinds in issue order, with "aggregate" marking the start of a step-batch's
-                                          # aggregation (tests: a batch's frame records are gathered before it is aggregated)
+        # and the kinds in issue order, with "aggregate" marking the start of a step-batch's aggregation (tests: a batch's
+        # frame records are gathered before it is aggregated) -- a diagnostic: bounded, so that a long multi-GPU run does not
+        # grow it without end
+        self.wire_order = deque(maxlen=4096)
         self.group_agg = dist_group       # the aggregation's collectives run on another stream than the frame stage's:
         if dist_group is not None and self.world > 1:      # their own communicator
             # (the members are the ranks of dist_group itself -- a sub-group's global ranks are not 0 .. world-1 -- and
@@ -848,6 +850,12 @@ class ClipEngine(object):
         prefetch(0)
         prefetch(1)
         staged = frame_stage(batches[0]) if batches else None
+        if hasattr(clip, "stage_ahead") and last < T and self.world == 1 and not self.reuse_records and batches:
+            # read-ahead across calls: the step-batch that FOLLOWS this range is staged (host copies + H2D on the source's own
+            # stream) while this range's frame stage / aggregation run -- a caller that walks the video block by block (the
+            # benchmark's with-H2D leg, inference.py's loop) never waits for a batch's 72 MB at the top of its block
+            nb = (last, min(T, last + self.steps_per_batch))
+            clip.stage_ahead([j[0] for i in range(*nb) for j in self.jobs_for_step(i, T, gfor)])
         prev_pending = None
         for bi, b in enumerate(batches):
             t0 = _time.perf_counter()

@@ -127,6 +127,11 @@ class FrameSource(object):
         self.is_cuda = self.device.type == "cuda"
         self.shape = (self.seg_len, self.out_hw[0], self.out_hw[1], 3)
         self.decoded = 0
+        # read-ahead (stage_ahead): ONE batch staged beyond what has been fetched -- key, device tensor, the event of its last
+        # H2D copy, the thread that fills the pinned buffer and issues the copies on the copy stream
+        self._ahead = None
+        self._copy_stream = None
+        self.ahead_hits = 0
 
     def _open(self, frame_id):
         from PIL import Image
@@ -150,7 +155,69 @@ class FrameSource(object):
         while len(self.cache) > self.cache_frames:
             self.cache.popitem(last=False)
 
+    def stage_ahead(self, ids):
+        """Start bringing a LATER batch onto the device now: a background thread fills a pinned buffer from the decode cache and
+        issues the H2D copies on the source's own copy stream, so they run beside whatever the device is doing for the
+        current batch; fetch(ids) with the same ids then only waits for that event.  One batch of read-ahead; a fetch of
+        anything else drops it.  (ClipEngine.run() calls this with the step-batch that FOLLOWS the range it was asked for --
+        a caller that walks the video block by block finds every block's frames already in HBM: the reference's loader
+        overlaps its H2D the same way, one DataLoader batch ahead of the forward, engine/inference.py:24-42.)"""
+        if not self.is_cuda:
+            return
+        key = tuple(int(f) for f in ids)
+        if not key or (self._ahead is not None and self._ahead["key"] == key):
+            return
+        self._drop_ahead()
+        self.prefetch(key)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        import threading
+        ent = {"key": key, "dev": None, "ev": None, "err": None}
+
+        def work():
+            try:
+                with torch.cuda.stream(self._copy_stream):
+                    ent["dev"] = self._to_device(key)
+                    ent["ev"] = torch.cuda.Event()
+                    ent["ev"].record(self._copy_stream)
+            except Exception as e:  # noqa: BLE001  (surfaced by the fetch that asks for this batch)
+                ent["err"] = e
+        ent["thread"] = threading.Thread(target=work, daemon=True)
+        ent["thread"].start()
+        self._ahead = ent
+
+    def _drop_ahead(self):
+        ent, self._ahead = self._ahead, None
+        if ent is not None:
+            ent["thread"].join()
+            if ent["ev"] is not None:
+                ent["ev"].synchronize()      # its staging buffer and device tensor may be re-used after this
+
     def fetch(self, ids):
+        ent = self._ahead
+        if ent is not None and ent["key"] == tuple(int(f) for f in ids):
+            self._ahead = None
+            ent["thread"].join()
+            if ent["err"] is not None:
+                raise ent["err"]
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ent["ev"])
+            ent["dev"].record_stream(cur)
+            self.ahead_hits += 1
+            return self._resized(ent["dev"])
+        if ent is not None:
+            self._drop_ahead()
+        return self._resized(self._to_device(ids))
+
+    def _resized(self, dev):
+        if self.out_hw == self.in_hw:
+            return dev
+        if self.tables is None:
+            self.tables = ResizeTables(self.in_hw, self.out_hw, self.device)
+        return ops.resize_bilinear_u8(dev, self.out_hw, self.tables)
+
+    def _to_device(self, ids):
+        """the decoded frames `ids` as ONE uint8 device tensor [n,Hi,Wi,3] (host copies + H2D on the CURRENT stream)"""
         self.prefetch(ids)
         n = len(ids)
         # pinned staging buffers are a small ring per batch size, re-used once the H2D copy that read them has completed
@@ -176,6 +243,8 @@ class FrameSource(object):
         # the copies into the staging buffer run on the worker threads too (numpy releases the GIL): 40 frames of 1.8 MB
         # are ~10 ms on one thread, which would sit serially in front of every frame-stage launch
 
+        # (put() tasks wait on decode futures that run on the SAME pool: deadlock-free because ThreadPoolExecutor starts its
+        #  tasks in submission order and every decode was submitted -- by prefetch() or the line above -- before any put())
         def put(i):
             np.copyto(view[i], futs[i].result())
         if self.is_cuda and n >= 8:
@@ -191,11 +260,9 @@ class FrameSource(object):
             dev = stage.to(self.device, non_blocking=True)
         if ev is not None:
             ev.record()
-        if self.out_hw == self.in_hw:
-            return dev
-        if self.tables is None:
-            self.tables = ResizeTables(self.in_hw, self.out_hw, self.device)
-        return ops.resize_bilinear_u8(dev, self.out_hw, self.tables)
+        return dev
 
     def close(self):
+        self._drop_ahead()
         self.pool.shutdown(wait=False)
+        self._stage = {}          # (the pinned staging rings: up to 3 buffers of n x H x W x 3 per batch size seen -- ADVICE r05)

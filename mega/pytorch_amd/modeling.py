@@ -637,8 +637,9 @@ class MEGAFeatureExtractor(_Packed):
         w0 = self.l_fcs[0].weight.detach()
         r2 = self.resolution ** 2
         w0 = w0.view(w0.shape[0], self.pooled_c, r2).permute(0, 2, 1).reshape(w0.shape[0], -1)
-        pk["fc_w"] = [w0.contiguous().to(dtype).to(device)] + [self.l_fcs[i].weight.detach().to(dtype).to(device).contiguous()
-                                                                for i in range(1, self.stage)]
+        # (conv_mode "x3" reads fc0 as pk["fc0_x3"] only: no resident f32 copy of the 411 MB matrix beside it -- ADVICE r05)
+        pk["fc_w"] = [None if self.mode == "x3" else w0.contiguous().to(dtype).to(device)] + [
+            self.l_fcs[i].weight.detach().to(dtype).to(device).contiguous() for i in range(1, self.stage)]
         pk["fc_b"] = [self.l_fcs[i].bias.detach().float().to(device).contiguous() for i in range(self.stage)]
         if self.stream != dtype:      # f32 activation stream in bf16 mode: the stage FCs read and write it at ~2^-16 --
             for i in range(1, self.stage):     # split-precision operands on the bf16 matrix cores (ops.split_bf16x3)
@@ -664,7 +665,12 @@ class MEGAFeatureExtractor(_Packed):
     def res5_features(self, feat_nhwc):
         """the proposal-independent half of box_features: res5 (+1x1 reduce) on the full C4 maps"""
         pk = self._packed(self.dtype, feat_nhwc.device)
-        if isinstance(feat_nhwc, ops.Planes):      # conv_mode "x3" / "wide": -> a plain f32 / bf16 map for ROIAlign
+        if self.mode in ("x3", "wide") and not isinstance(feat_nhwc, ops.Planes):
+            # the reference call signature (forward(x, proposals): x = the backbone's C4 TENSOR, f32 = hi + lo in mode "x3",
+            # the bf16 hi plane in mode "wide"): back to planes, so that res5's blocks -- which run on planes in these modes --
+            # end in a plain map for ROIAlign (ADVICE r05: the tensor branch handed a Planes object to the reduce conv)
+            feat_nhwc = ops.split_planes(feat_nhwc.float().contiguous()) if self.mode == "x3" else feat_nhwc.contiguous()
+        if isinstance(feat_nhwc, ops.Planes) or (self.mode == "wide" and self.head.layer4[0].sp_mode is not None):
             plain = "f32" if self.mode == "x3" else "bf16"
             if self.conv is None:
                 return self.head.run(feat_nhwc, out_mode=plain)

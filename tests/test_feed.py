@@ -121,3 +121,47 @@ def test_frame_source_gpu_equals_pillow_chain(dev, tmp_path):
         [np.asarray(Image.fromarray(clip0[i]).resize((999, 562), Image.BILINEAR)) for i in ids])))
     assert torch.equal(got, want)
     src.close()
+
+
+@pytest.mark.gpu
+def test_frame_source_read_ahead_is_the_same_batch(dev):
+    """FrameSource.stage_ahead(ids): the batch brought over by the background thread on the copy stream is, bit for bit, the
+    batch fetch(ids) delivers on its own -- for batches that go through the chunked staging ring (n >= 8) and small ones, with
+    and without the resize -- a fetch of OTHER ids drops the read-ahead, and ClipEngine.run() walking a video block by block
+    finds every block after the first already staged (and returns the detections of the resident clip)."""
+    from mega.pytorch_amd import engine
+    T, H0, W0 = 64, 96, 160
+    host = synth.make_clip(16, H0, W0, seed=5).numpy()
+    for size in ((96, 160), (120, 200)):
+        src = feed.FrameSource(None, None, T, dev, min_size=size[0], max_size=size[1], opener=lambda f: host[f % 16], workers=4)
+        for ids in ([3, 9, 1, 1, 15, 40, 22, 8, 63, 2], [5, 6]):
+            want = src.fetch(ids).clone()
+            src.stage_ahead(ids)
+            got = src.fetch(ids)
+            torch.cuda.synchronize()
+            assert src.ahead_hits >= 1 and torch.equal(got, want)
+        n0 = src.ahead_hits
+        src.stage_ahead([1, 2, 3])
+        other = src.fetch([4, 5, 6])              # not what was staged: dropped, fetched the ordinary way
+        assert src.ahead_hits == n0 and torch.equal(other.cpu(), src.fetch([4, 5, 6]).cpu())
+        src.close()
+    cfg = config.get_cfg("R-50")
+    cfg.DTYPE = "bfloat16"
+    cfg.MODEL.DEVICE = str(dev)
+    sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+    src = feed.FrameSource(None, None, T, dev, min_size=H0, max_size=W0, opener=lambda f: host[f % 16], workers=4)
+    clip = torch.from_numpy(np.stack([host[f % 16] for f in range(T)])).to(dev)
+    gfor = engine.global_schedule(T, cfg.MODEL.VID.MEGA.GLOBAL.SIZE, seed=0)
+    outs = {}
+    for name, c in (("resident", clip), ("source", src)):
+        model = modeling.build_detection_model(cfg)
+        model.load_state_dict(sd)
+        eng = engine.ClipEngine(model.to(dev), steps_per_batch=4)
+        dets = eng.run(c, T, gfor, first=0, last=1)
+        for first in (1, 5, 9, 13):                 # the video block by block: every block after the cold start is read ahead
+            dets += eng.run(c, T, gfor, first=first, last=first + 4)
+        outs[name] = dets
+    assert src.ahead_hits >= 3, src.ahead_hits
+    for a, b in zip(outs["resident"], outs["source"]):
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
+    src.close()

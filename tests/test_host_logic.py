@@ -746,3 +746,47 @@ def test_planes_modes_run_the_same_detector_on_cpu_twins(monkeypatch, mode):
         #  300-detection cut / an NMS tie; the sorted score lists agree in the bulk)
         ds = (got[k].get_field("scores").sort().values - ref[k].get_field("scores").sort().values).abs()
         assert ds.median() < 1e-4 and ds.max() < 5e-3
+
+
+@pytest.mark.parametrize("mode", ["x3", "wide", "f16"])
+def test_reference_call_signature_of_the_feature_extractor_in_planes_and_f16_modes(monkeypatch, mode):
+    """the REFERENCE call convention -- x = model.backbone(images)[0] (a tensor), then
+    roi_heads.box.feature_extractor(x, proposals, pre_calculate=True) (roi_box_feature_extractors.py:885-896) -- in the
+    modes whose engine path hands C4 over as ops.Planes (conv_mode "x3" / "wide": the tensor branch used to pass a Planes
+    object on to the reduce conv / ROIAlign and crashed) and in float16 mode.  On the CPU twins: the call runs, returns
+    [K, 1024] features in the head's stream dtype, and equals the engine-path frame stage on the same proposals."""
+    cpu_ops.install(monkeypatch)
+    monkeypatch.setattr(modeling, "_FUSE_STEM_POOL", False)
+    torch.set_num_threads(8)
+    from mega.pytorch_amd.structures import BoxList
+    H, W = 96, 128
+    for r50 in (True, False):       # R-50: with the 1x1 reduce conv after res5; R-101 layout (here 1-1-1 blocks): without
+        cfg = _small_cfg() if r50 else None
+        if cfg is None:
+            cfg = config.get_cfg("R-101")
+            cfg.MODEL.DEVICE = "cpu"
+        if mode == "x3":
+            cfg.F32_CONV = "bf16x3"
+        elif mode == "wide":
+            cfg.DTYPE, cfg.RESIDUAL_STREAM = "bfloat16", "planes"
+        else:
+            cfg.DTYPE = "float16"
+        if r50:
+            sd = synth.make_state_dict(blocks=(3, 4, 6), reduce_channel=True, global_res_stage=0, seed=5)
+        else:
+            sd = synth.make_state_dict(blocks=(3, 4, 23), seed=5)
+        model = modeling.build_detection_model(cfg)
+        model.load_state_dict(sd)
+        imgs = synth.preprocess_cpu(synth.make_clip(2, H, W, seed=2))
+        with torch.no_grad():
+            x = model.backbone(imgs)[0]
+            assert torch.is_tensor(x) and x.shape[1] == 1024
+            props = [BoxList(torch.tensor([[4.0, 6.0, 60.0, 50.0], [10.0, 12.0, 100.0, 90.0], [0.0, 0.0, 127.0, 95.0]]), (W, H), "xyxy")
+                     for _ in range(2)]
+            fe = model.roi_heads.box.feature_extractor
+            feats = fe(x, props, pre_calculate=True)
+            assert feats.shape == (6, 1024) and feats.dtype == fe.stream and torch.isfinite(feats).all()
+            # the engine path (C4 as it leaves run_nhwc: Planes in the planes modes) on the same ROIs
+            c4 = model.frame_stage_a0(imgs)
+            want = fe.box_features(c4, modeling.convert_to_roi_format(props))
+            assert (feats.float() - want.float()).abs().max() <= 2e-2 * want.float().abs().max()
