@@ -59,7 +59,7 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-HALF_MODES = ("bfloat16", "wide", "float16")      # --dtype values whose frame stage runs on 16-bit matrix-core operands
+HALF_MODES = ("bfloat16", "wide", "float16", "f16x2")      # --dtype values whose frame stage runs on 16-bit matrix-core operands
 ALGO_GFLOP_PER_FRAME = 729.0   # minimal algorithmic work per steady-state key frame, R-101 MEGA
 
 
@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=60)     # three step-batches of 20 key frames
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--arch", default="R-101")
-    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16", "float32", "bf16x3", "wide"],
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16", "f16x2", "float32", "bf16x3", "wide"],
                     help="bfloat16 (BASELINE configs[2], the headline) | float16 (the same kernels on IEEE-half operands: the "
                          "frame stage in fp16, 11 significant bits at the bf16 rate) | float32 (exact-f32 MFMA parity mode) | bf16x3 (float32 "
                          "with the split-precision frame stage, cfg.F32_CONV) | wide (bfloat16 with the residual trunk as "
@@ -220,6 +220,8 @@ def build_model(arch, dtype, device, head_stream=None):
         dtype, cfg.F32_CONV = "float32", "bf16x3"
     elif dtype == "wide":
         dtype, cfg.RESIDUAL_STREAM = "bfloat16", "planes"
+    elif dtype == "f16x2":       # float16, two-pass form: fp16 [hi | lo] activation planes against weights rounded to fp16 once
+        dtype, cfg.F16_CONV = "float16", "x2"
     cfg.DTYPE = dtype
     if head_stream is not None:
         cfg.HEAD_STREAM = head_stream
@@ -326,6 +328,11 @@ F16_PARITY = ("against the f32 oracle, R-101 600x1000, 28 key frames incl. the m
               "(fixture with margins); predicted on the CPU twins before the kernels existed: profiles/r06_fp16_prediction.txt")
 
 
+F16X2_PARITY = ("against the f32 oracle, R-101 600x1000, 28 key frames incl. the memory-full regime: "
+                "tests/test_e2e_gpu.py::test_r101_600x1000_f16x2_vs_oracle; predicted on the CPU twins (variant 2pass-bound of "
+                "profiles/r06_fp16_prediction.txt)")
+
+
 def f32_parity_leg(args, device, clip, gfor, T, spb, mode="float32", head_mode=None):
     """mode "bf16x3": the split-precision parity mode (cfg.F32_CONV = "bf16x3": the frame stage's convs / fc0 as bf16
     matrix-core GEMMs over [hi | lo | hi] . [Wh | Wh | Wl], f32 accumulation; aggregation head exact f32) -- pinned by
@@ -379,16 +386,20 @@ def f32_parity_leg(args, device, clip, gfor, T, spb, mode="float32", head_mode=N
     el = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     fps = spb / el
     x3 = mode == "bf16x3"
-    if mode == "float16":
-        out = {"dtype": "f16 (frame stage on IEEE-half operands: v_mfma_f32_32x32x16_f16, 11 significant bits at the bf16 MFMA rate "
-                        "and bytes; f32 accumulation; the head is the bf16 head on an f32 activation stream)",
+    if mode in ("float16", "f16x2"):
+        out = {"dtype": ("f16 (frame stage on IEEE-half operands: v_mfma_f32_32x32x16_f16, 11 significant bits at the bf16 MFMA rate "
+                         "and bytes; f32 accumulation; the head is the bf16 head on an f32 activation stream)") if mode == "float16" else
+                        ("f16x2 (frame stage in the two-pass fp16 form: activations as float16 [hi | lo] planes against weights rounded "
+                         "to fp16 once, K x 2 per conv / fc0, f32 accumulation; exact-f32 stem / RPN logits / ROIAlign; the bf16 head)"),
                "fps": round(fps, 2), "ms_per_key_frame": round(1e3 * el / spb, 4),
                "frac_of_2500TF": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / 2500e12, 4) if args.arch == "R-101" else None,
                "peak_tflops": 2500.0, "key_frames_per_block": spb, "timed_blocks": len(blocks),
                "timed_blocks_ms": [round(1e3 * b, 2) for b in blocks], "pools_full": bool(st0["pools_full"]),
                "graph_captures_in_timed_region": (g1["captured"] - g0["captured"]) + (g1["eager"] - g0["eager"])
                + (g1.get("agg_captured", 0) - g0.get("agg_captured", 0)),
-               "parity": F16_PARITY}
+               "parity": F16_PARITY if mode == "float16" else F16X2_PARITY}
+        if mode == "f16x2":
+            out["frac_of_2500TF_at_2x_flops"] = round(2 * ALGO_GFLOP_PER_FRAME * 1e9 * fps / 2500e12, 4) if args.arch == "R-101" else None
         del runner, model, frame_model
         torch.cuda.empty_cache()
         return out
@@ -653,7 +664,7 @@ def main():
         # instrumented pass of the timed configuration.  igemm8's streaming launch class ("igemm8s_*": 1x1 layers with
         # K <= 512, bound by HBM / the CU fetch rate) is reported in roofline_hbm; every other igemm symbol (fc0's f32-output
         # split-K launch among them) has its own row in roofline_mfma.
-        tag = "f16" if args.dtype == "float16" else ("bf16" if args.dtype in ("bfloat16", "wide") else "f32")
+        tag = "f16" if args.dtype in ("float16", "f16x2") else ("bf16" if args.dtype in ("bfloat16", "wide") else "f32")
         igemms = {k: v for k, v in summ.items() if k.startswith(("igemm_" + tag, "igemm8_" + tag, "igemm8s_" + tag, "igemm8_sp"))}
         mm = {k: v for k, v in igemms.items() if not k.startswith("igemm8s_")}
         peak = 2500.0 if args.dtype in HALF_MODES + ("bf16x3",) else 157.3
@@ -786,6 +797,8 @@ def main():
         try:
             f16_leg = f32_parity_leg(args, device, clip, gfor, T, spb, mode="float16")
             log("fp16-mode leg: %.1f frames/s (%.3f ms per key frame)" % (f16_leg["fps"], f16_leg["ms_per_key_frame"]))
+            f16_leg["two_pass"] = f32_parity_leg(args, device, clip, gfor, T, spb, mode="f16x2")
+            log("fp16 two-pass leg: %.1f frames/s" % f16_leg["two_pass"]["fps"])
         except Exception as e:  # noqa: BLE001  (an extra leg must never cost the headline line)
             log("fp16-mode leg skipped: %r" % (e,))
         try:
@@ -813,7 +826,7 @@ def main():
             "metric": "frames/sec MEGA %s inference, %dx%d VID clip" % (args.arch, args.width, args.height),
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": live_world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bfloat16": "bf16", "wide": "bf16", "bf16x3": "bf16x3", "float16": "f16"}.get(args.dtype, "f32"), "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bfloat16": "bf16", "wide": "bf16", "bf16x3": "bf16x3", "float16": "f16", "f16x2": "f16x2"}.get(args.dtype, "f32"), "data": "synthetic",
             "config": {"workload": "MEGA %s-C4, %dx%d frames, 25 local + 10 global frames + 25-frame memory, "
                                    "300 key / 75 ref proposals, 3 attention stages (BASELINE configs[2]%s)"
                                    % (args.arch, args.width, args.height, "" if world == 1 else " sharded = configs[3]"),

@@ -318,6 +318,18 @@ int mega_conv2d_nhwc_sp(const void* in, int ldi, int kwrap, const void* w, const
                         int Cout, int R, int S, int stride, int pad, int dil, int relu, void* ws, size_t ws_bytes,
                         void* stream);
 
+/* The plane kernels above for either 16-bit type (dtype = MEGA_BF16 / MEGA_F16: the type of the [hi | lo] pairs and of the
+ * weights).  MEGA_F16 carries the TWO-PASS form of the fp16 mode (conv_mode "h2"): ldi = 2C, Cin = 2C, kwrap = 0 reads the planes
+ * as [hi | lo] against weights packed [W | W] per tap, W rounded to fp16 once -- x_hi.W + x_lo.W: exact activations (to ~2^-22)
+ * against single-rounded weights, f32 accumulation, twice the matrix-core work of the one-pass fp16 mode. */
+int mega_split_f32_to_planes_dt(const float* src, void* dst, int rows, int K, int dtype, void* stream);
+int mega_roi_align_fwd_planes_dt(const float* feat, const float* rois, void* out_planes, int K, int C, int H, int W,
+                                 float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, int dtype, void* stream);
+int mega_conv2d_nhwc_sp_dt(const void* in, int ldi, int kwrap, const void* w, const float* scale, const float* bias,
+                           const void* residual, int ldr, void* out, int ldo, int out_mode, int N, int H, int W, int Cin,
+                           int Cout, int R, int S, int stride, int pad, int dil, int relu, int dtype, void* ws, size_t ws_bytes,
+                           void* stream);
+
 /* mega_copy_segments with an f32 -> bf16 conversion on the way (source blocks f32, destination blocks bf16; row_bytes =
  * SOURCE bytes per row, a multiple of 32; 16-byte aligned on both sides): a concatenation of f32 row blocks delivered as the
  * rounded copy the bf16 projections read (roi_box_feature_extractors.py:812-814 pools with an f32 activation stream). */

@@ -76,6 +76,10 @@ SIGNATURES = {
     "mega_roi_align_fwd_planes": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] + [c_int] * 3 + [c_void_p]),
     "mega_conv2d_nhwc_sp": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                     c_int] + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]),
+    "mega_split_f32_to_planes_dt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mega_roi_align_fwd_planes_dt": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] + [c_int] * 4 + [c_void_p]),
+    "mega_conv2d_nhwc_sp_dt": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                       c_int] + [c_int] * 12 + [c_void_p, c_size_t, c_void_p]),
     "mega_last_error_string": (ctypes.c_char_p, []),
 }
 

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void copy_cast_segments_kernel(CopyBatch b) {
 // f32 row [K] -> bf16 row [3K] = [hi | lo | hi], hi = bf16(v), lo = bf16(v - hi): with the weight rows laid out
 // [Wh | Wh | Wl] a plain bf16 GEMM over 3K computes hi.Wh + lo.Wh + hi.Wl = v.W to ~2^-16 (f32 accumulation of exact
 // bf16 products; only the lo.Wl term, 2^-18, is dropped) at the bf16 MFMA rate.  8 elements per thread.
-template <int PLANES>
+template <int PLANES, typename HT = bf16_t>
 __global__ __launch_bounds__(256) void split3_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows,
                                                               int K8) {
   const size_t total = (size_t)rows * K8;
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(256) void split3_f32_bf16_kernel(const float* __res
     u32x4_t hi, lo;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const unsigned h = pack_bf16x2(v[2 * d], v[2 * d + 1]);
+      const unsigned h = Half16<HT>::pack2(v[2 * d], v[2 * d + 1]);
       hi[d] = h;
-      lo[d] = pack_bf16x2(v[2 * d] - __uint_as_float(h << 16), v[2 * d + 1] - __uint_as_float(h & 0xffff0000u));
+      lo[d] = Half16<HT>::pack2(v[2 * d] - Half16<HT>::lo(h), v[2 * d + 1] - Half16<HT>::hi(h));
     }
     u32x4_t* row = reinterpret_cast<u32x4_t*>(dst + r * (size_t)(K8 * 8 * PLANES));
     row[c] = hi;
@@ -160,16 +160,24 @@ extern "C" int mega_split_f32_to_bf16x3(const float* src, void* dst, int rows, i
 
 // dst[r][0:K] = hi, dst[r][K:2K] = lo of src[r][0:K]: the split-precision PLANES form of an f32 activation (hi = bf16(x),
 // lo = bf16(x - hi)) that mega_conv2d_nhwc_sp reads as its input / residual and writes as its output.
-extern "C" int mega_split_f32_to_planes(const float* src, void* dst, int rows, int K, void* stream) {
+extern "C" int mega_split_f32_to_planes_dt(const float* src, void* dst, int rows, int K, int dtype, void* stream) {
   mega_clear_error();
   if (rows == 0) return MEGA_OK;
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
   if (!src || !dst || rows < 0 || K <= 0 || K % 8 || (reinterpret_cast<size_t>(src) & 15) || (reinterpret_cast<size_t>(dst) & 15))
     return MEGA_ERR_ARG;
   const size_t total = (size_t)rows * (K / 8);
   size_t nb = (total + 255) / 256;
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(split3_f32_bf16_kernel<2>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K / 8);
+  if (dtype == MEGA_F16)
+    hipLaunchKernelGGL((split3_f32_bf16_kernel<2, f16_t>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K / 8);
+  else
+    hipLaunchKernelGGL((split3_f32_bf16_kernel<2, bf16_t>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K / 8);
   return mega_check_launch();
+}
+
+extern "C" int mega_split_f32_to_planes(const float* src, void* dst, int rows, int K, void* stream) {
+  return mega_split_f32_to_planes_dt(src, dst, rows, K, MEGA_BF16, stream);
 }
 
 // dst[i] = bf16(src[i]) for n contiguous elements (both 16-byte aligned).  The aggregation head keeps its activation

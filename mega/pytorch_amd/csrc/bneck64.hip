@@ -208,8 +208,11 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_kernel(Bneck64Params p) {
           const int py = R / BK_PX, pxx = R - py * BK_PX;
           const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
           const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-          const bf16_t va = in ? bk_relu1<HT>(c1a[r] * s1a + b1a) : (bf16_t)0;
-          const bf16_t vb = in ? bk_relu1<HT>(c1b[r] * s1b + b1b) : (bf16_t)0;
+          // (converted unconditionally, then selected: the f16 conversion's register barrier -- common.h f16_src -- would
+          //  otherwise keep it under a divergent branch per element instead of a v_cndmask)
+          const bf16_t ra = bk_relu1<HT>(c1a[r] * s1a + b1a), rb = bk_relu1<HT>(c1b[r] * s1b + b1b);
+          const bf16_t va = in ? ra : (bf16_t)0;
+          const bf16_t vb = in ? rb : (bf16_t)0;
           unsigned char* base = t1l + R * 128;
           const int sw = (pxx >> 1) & 7;
           *reinterpret_cast<bf16_t*>(base + (((lo >> 3) ^ sw) * 16) + (lo & 7) * 2) = va;
@@ -449,8 +452,11 @@ __global__ __launch_bounds__(BK_NT, 2) void bneck64_ds_kernel(Bneck64DsParams p)
           const int py = R / BK_PX, pxx = R - py * BK_PX;
           const int yy = y0 - 1 + py, xx = x0 - 1 + pxx;
           const bool in = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-          const bf16_t va = in ? bk_relu1<HT>(c1a[r] * s1a + b1a) : (bf16_t)0;
-          const bf16_t vb = in ? bk_relu1<HT>(c1b[r] * s1b + b1b) : (bf16_t)0;
+          // (converted unconditionally, then selected: the f16 conversion's register barrier -- common.h f16_src -- would
+          //  otherwise keep it under a divergent branch per element instead of a v_cndmask)
+          const bf16_t ra = bk_relu1<HT>(c1a[r] * s1a + b1a), rb = bk_relu1<HT>(c1b[r] * s1b + b1b);
+          const bf16_t va = in ? ra : (bf16_t)0;
+          const bf16_t vb = in ? rb : (bf16_t)0;
           unsigned char* base = t1l + R * 128;
           const int sw = (pxx >> 1) & 7;
           *reinterpret_cast<bf16_t*>(base + (((lo >> 3) ^ sw) * 16) + (lo & 7) * 2) = va;

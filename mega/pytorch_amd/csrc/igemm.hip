@@ -624,11 +624,15 @@ extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scal
 // Cin % 64 == 0, Cout % 8 == 0, every tensor below 2 GiB.  ws: split-K workspace as for mega_conv2d_nhwc_ws (f32 output, no
 // residual).  Replaces, in the split-precision parity mode, the same reference layers as mega_conv2d_nhwc
 // (backbone/resnet.py:324-344, rpn/rpn.py:99-106, roi_box_feature_extractors.py:894,:907).
-extern "C" int mega_conv2d_nhwc_sp(const void* in, int ldi, int kwrap, const void* w, const float* scale, const float* bias,
-                                   const void* residual, int ldr, void* out, int ldo, int out_mode, int N, int H, int W,
-                                   int Cin, int Cout, int R, int S, int stride, int pad, int dil, int relu, void* ws,
-                                   size_t ws_bytes, void* stream) {
+// dtype (MEGA_BF16 / MEGA_F16): the 16-bit type of the planes and weights.  MEGA_F16: IEEE-half pairs -- the two-pass form of
+// the fp16 mode (conv_mode "h2": ldi = 2C, Cin = 2C, kwrap = 0, w = [W | W] per tap with W rounded to fp16 ONCE: x_hi.W + x_lo.W,
+// i.e. exact activations against single-rounded weights at twice the matrix-core work).
+extern "C" int mega_conv2d_nhwc_sp_dt(const void* in, int ldi, int kwrap, const void* w, const float* scale, const float* bias,
+                                      const void* residual, int ldr, void* out, int ldo, int out_mode, int N, int H, int W,
+                                      int Cin, int Cout, int R, int S, int stride, int pad, int dil, int relu, int dtype,
+                                      void* ws, size_t ws_bytes, void* stream) {
   mega_clear_error();
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
   if (!in || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
       dil <= 0 || pad < 0 || out_mode < 0 || out_mode > 2 || ldi <= 0 || kwrap < 0 || Cin % 64 != 0)
     return MEGA_ERR_ARG;
@@ -665,7 +669,15 @@ extern "C" int mega_conv2d_nhwc_sp(const void* in, int ldi, int kwrap, const voi
   // one block per CU: the row count that wastes the fewest CU-rounds (the rule of choose_tile)
   const long t256 = (long)cdiv(p.M, 256) * cdiv(Cout, 256) * p.ksplit, t192 = (long)cdiv(p.M, 192) * cdiv(Cout, 256) * p.ksplit;
   const long c256 = cdiv((int)t256, 256) * 256L * 8, c192 = cdiv((int)t192, 256) * 192L * 9;
-  int rc = mega_igemm8_launch(p, c192 < c256 ? 192 : 256, out_mode == 2, MEGA_BF16, st);
-  if (rc == MEGA_OK && p.ksplit > 1) rc = launch_finalize<bf16_t, float>(p, st);
+  int rc = mega_igemm8_launch(p, c192 < c256 ? 192 : 256, out_mode == 2, dtype, st);
+  if (rc == MEGA_OK && p.ksplit > 1) rc = launch_finalize<bf16_t, float>(p, st);      // (no residual in split-K launches: type-free)
   return rc;
+}
+
+extern "C" int mega_conv2d_nhwc_sp(const void* in, int ldi, int kwrap, const void* w, const float* scale, const float* bias,
+                                   const void* residual, int ldr, void* out, int ldo, int out_mode, int N, int H, int W,
+                                   int Cin, int Cout, int R, int S, int stride, int pad, int dil, int relu, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  return mega_conv2d_nhwc_sp_dt(in, ldi, kwrap, w, scale, bias, residual, ldr, out, ldo, out_mode, N, H, W, Cin, Cout, R, S, stride,
+                                pad, dil, relu, MEGA_BF16, ws, ws_bytes, stream);
 }

@@ -89,7 +89,6 @@ __device__ __forceinline__ int fast_div(int n, unsigned mg, unsigned sh) {   // 
 // HT: the 16-bit operand type (bf16_t, or f16_t = IEEE half: round 6) of in / w / residual; OT = HT or float.
 template <typename OT, int MF1, int CLS = 0, int ABL = 0, int SP = 0, typename HT = bf16_t>
 __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
-  static_assert(!SP || std::is_same<HT, bf16_t>::value, "split-precision planes are bf16 pairs");
   static_assert(sizeof(OT) == 4 || std::is_same<OT, HT>::value, "16-bit outputs have the operands' type");
   constexpr int BM = 128 + 64 * MF1;
   constexpr int BN = 256;
@@ -560,14 +559,14 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
                 asm volatile("" : "+v"(l4));
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                  v[2 * d] += __uint_as_float(h4[d] << 16) + __uint_as_float(l4[d] << 16);
-                  v[2 * d + 1] += __uint_as_float(h4[d] & 0xffff0000u) + __uint_as_float(l4[d] & 0xffff0000u);
+                  v[2 * d] += Half16<HT>::lo(h4[d]) + Half16<HT>::lo(l4[d]);
+                  v[2 * d + 1] += Half16<HT>::hi(h4[d]) + Half16<HT>::hi(l4[d]);
                 }
               } else {
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                  v[2 * d] += __uint_as_float(h4[d] << 16) + __uint_as_float(h4[2 + d] << 16);
-                  v[2 * d + 1] += __uint_as_float(h4[d] & 0xffff0000u) + __uint_as_float(h4[2 + d] & 0xffff0000u);
+                  v[2 * d] += Half16<HT>::lo(h4[d]) + Half16<HT>::lo(h4[2 + d]);
+                  v[2 * d + 1] += Half16<HT>::hi(h4[d]) + Half16<HT>::hi(h4[2 + d]);
                 }
               }
             }
@@ -578,9 +577,9 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
 #pragma unroll
               for (int d = 0; d < 4; ++d) {
                 const float x0 = RELU ? fmaxf(v[2 * d], 0.f) : act(v[2 * d]), x1 = RELU ? fmaxf(v[2 * d + 1], 0.f) : act(v[2 * d + 1]);
-                const unsigned h = pack_bf16x2(x0, x1);
+                const unsigned h = Half16<HT>::pack2(x0, x1);
                 o[d] = h;
-                ol[d] = pack_bf16x2(x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u));
+                ol[d] = Half16<HT>::pack2(x0 - Half16<HT>::lo(h), x1 - Half16<HT>::hi(h));
               }
               __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, ooff, 0, 0);
               __builtin_amdgcn_raw_buffer_store_b128(ol, rs_out, ooff + (unsigned)p.Cout * 2u, 0, 0);
@@ -774,8 +773,23 @@ int mega_igemm8_supports(const ConvParams& p) {
 }
 
 int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, int half_dtype, hipStream_t st) {
-  if (half_dtype == MEGA_F16) {        // IEEE half operands (same tiles, same launch classes; no split-precision planes)
-    if (p.sp) return MEGA_ERR_ARG;
+  if (half_dtype == MEGA_F16 && p.sp) {  // fp16 [hi | lo] planes (conv_mode "h2"): the SP kernels on IEEE-half pairs
+    const size_t oplanes = p.split_out ? 2 : 1, osz = out_f32 ? 4 : 2;
+    const bool ok = p.ldi >= (p.kwrap > 0 ? p.kwrap : p.Cin) && p.ldi % 64 == 0 && (p.kwrap == 0 || (p.kwrap % 64 == 0 && p.kwrap < p.Cin && p.Cin - p.kwrap <= p.kwrap)) &&
+                    p.Cout % 8 == 0 && !(p.split_out && out_f32) && p.ldo % (out_f32 ? 4 : 8) == 0 && p.ldo >= (int)oplanes * p.Cout &&
+                    (!p.res || (p.ldr % 8 == 0 && p.ldr >= 2 * p.Cout)) &&
+                    ((size_t)(p.M - 1) * p.ldo + oplanes * p.Cout) * osz < 0x7FF00000ull &&
+                    (!p.res || ((size_t)(p.M - 1) * p.ldr + 2 * (size_t)p.Cout) * 2 < 0x7FF00000ull) &&
+                    (p.ksplit == 1 || (!p.split_out && !p.res));
+    if (!ok) return MEGA_ERR_ARG;
+    const bool streamf = mega_igemm8_streaming(p.R * p.S, p.K) && p.ksplit == 1;
+    if (bm == 256 && streamf) return out_f32 ? launch8<float, 2, 1, 0, 1, f16_t>(p, st) : launch8<f16_t, 2, 1, 0, 1, f16_t>(p, st);
+    if (bm == 192 && streamf) return out_f32 ? launch8<float, 1, 1, 0, 1, f16_t>(p, st) : launch8<f16_t, 1, 1, 0, 1, f16_t>(p, st);
+    if (bm == 256) return out_f32 ? launch8<float, 2, 0, 0, 1, f16_t>(p, st) : launch8<f16_t, 2, 0, 0, 1, f16_t>(p, st);
+    if (bm == 192) return out_f32 ? launch8<float, 1, 0, 0, 1, f16_t>(p, st) : launch8<f16_t, 1, 0, 0, 1, f16_t>(p, st);
+    return MEGA_ERR_ARG;
+  }
+  if (half_dtype == MEGA_F16) {        // IEEE half operands (same tiles, same launch classes)
     const bool streamf = mega_igemm8_streaming(p.R * p.S, p.K) && p.ksplit == 1;
     if (bm == 256 && streamf) return out_f32 ? launch8<float, 2, 1, 0, 0, f16_t>(p, st) : launch8<f16_t, 2, 1, 0, 0, f16_t>(p, st);
     if (bm == 192 && streamf) return out_f32 ? launch8<float, 1, 1, 0, 0, f16_t>(p, st) : launch8<f16_t, 1, 1, 0, 0, f16_t>(p, st);

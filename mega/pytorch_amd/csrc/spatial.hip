@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const T* __restrict__ in,
 // PLANES (f32 input only): the pooled values leave as split-precision planes -- row k of `out` is bf16 [hi | lo] of the
 // [PH PW C] f32 values (hi = bf16(v), lo = bf16(v - hi)): the operand mega_conv2d_nhwc_sp's fc0 reads, written here instead
 // of an f32 tensor that a second pass would have to read back and split (3 + 3 GB per 40-frame batch at C = 2048).
-template <typename T, bool XCD_SLICED, bool PLANES = false>
+// PT: the 16-bit type of the planes (bf16_t, or f16_t for the fp16 two-pass mode)
+template <typename T, bool XCD_SLICED, bool PLANES = false, typename PT = bf16_t>
 __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __restrict__ feat,
                                                                  const float* __restrict__ rois, T* __restrict__ out,
                                                                  int K, int C, int H, int W, float spatial_scale,
@@ -299,9 +300,9 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_vec_kernel(const T* __rest
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[e] / count;
-      const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
-      const unsigned l0 = pack_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
-      const unsigned l1 = pack_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+      const unsigned h0 = Half16<PT>::pack2(v[0], v[1]), h1 = Half16<PT>::pack2(v[2], v[3]);
+      const unsigned l0 = Half16<PT>::pack2(v[0] - Half16<PT>::lo(h0), v[1] - Half16<PT>::hi(h0));
+      const unsigned l1 = Half16<PT>::pack2(v[2] - Half16<PT>::lo(h1), v[3] - Half16<PT>::hi(h1));
       const size_t plane = (size_t)PH * PW * C;                       // elements per plane of one ROI row
       unsigned short* row = reinterpret_cast<unsigned short*>(out) + (size_t)k * 2 * plane +
                             (size_t)(bin - k * PH * PW) * C + (size_t)cv * 4;
@@ -768,7 +769,8 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const void* __restric
           const int r = pix / SP_TX, c = pix - r * SP_TX;
           const int oy = oy0 + r, ox = ox0 + c;
           const bool ok = pix < SP_NPIX && (unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo;
-          *reinterpret_cast<unsigned short*>(smem + pix * OUT_PS + ch * 2) = ok ? (unsigned short)(Half16<HT>::cvt(fmaxf(acc[b][j][q] * sc + bi, 0.f)) & 0x7fffu) : (unsigned short)0;   // +0, never -0: the pool below orders bit patterns
+          const unsigned short hv = (unsigned short)(Half16<HT>::cvt(fmaxf(acc[b][j][q] * sc + bi, 0.f)) & 0x7fffu);   // +0, never -0: the pool below orders bit patterns
+          *reinterpret_cast<unsigned short*>(smem + pix * OUT_PS + ch * 2) = ok ? hv : (unsigned short)0;
         }
       }
     }
@@ -1002,10 +1004,12 @@ extern "C" int mega_stem_pool_bf16(const void* in, int u8, const void* w_n176_bf
 // mega_roi_align_fwd for f32 NHWC features with the result as split-precision planes: out bf16 [K][2 PH PW C] =
 // [hi | lo] of the f32 pooled row [PH PW C] (the same arithmetic, term by term, as the f32 kernel -- ROIAlign_cuda.cu:64-122 --
 // then hi = bf16(v), lo = bf16(v - hi)).  C % 4 == 0.  The A operand of the split-precision fc0 (mega_conv2d_nhwc_sp).
-extern "C" int mega_roi_align_fwd_planes(const float* feat, const float* rois, void* out, int K, int C, int H, int W,
-                                         float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, void* stream) {
+extern "C" int mega_roi_align_fwd_planes_dt(const float* feat, const float* rois, void* out, int K, int C, int H, int W,
+                                            float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, int dtype,
+                                            void* stream) {
   mega_clear_error();
   if (K == 0) return MEGA_OK;
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
   if (!feat || !rois || !out || K < 0 || C <= 0 || C % 4 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0) return MEGA_ERR_ARG;
   const int CV = C / 4;
   const long long total = (long long)K * pooled_h * pooled_w * CV;
@@ -1014,11 +1018,24 @@ extern "C" int mega_roi_align_fwd_planes(const float* feat, const float* rois, v
   if (nb > 131072) nb = 131072;
   dim3 vgrid((unsigned)(sliced ? nb * 8 : nb));
   hipStream_t st = (hipStream_t)stream;
-  if (sliced)
+  if (dtype == MEGA_F16) {
+    if (sliced)
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, true, true, f16_t>), vgrid, dim3(256), 0, st, feat, rois, (float*)out, K, C,
+                         H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+    else
+      hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, false, true, f16_t>), vgrid, dim3(256), 0, st, feat, rois, (float*)out, K,
+                         C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
+  } else if (sliced)
     hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, true, true>), vgrid, dim3(256), 0, st, feat, rois, (float*)out, K, C, H,
                        W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
   else
     hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, false, true>), vgrid, dim3(256), 0, st, feat, rois, (float*)out, K, C, H,
                        W, spatial_scale, pooled_h, pooled_w, sampling_ratio);
   return mega_check_launch();
+}
+
+extern "C" int mega_roi_align_fwd_planes(const float* feat, const float* rois, void* out, int K, int C, int H, int W,
+                                         float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, void* stream) {
+  return mega_roi_align_fwd_planes_dt(feat, rois, out, K, C, H, W, spatial_scale, pooled_h, pooled_w, sampling_ratio, MEGA_BF16,
+                                      stream);
 }

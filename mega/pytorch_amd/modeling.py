@@ -72,6 +72,10 @@ def conv_mode(cfg):
               accumulation (x.W to ~2^-16); the stem, the narrow RPN outputs and ROIAlign stay exact f32.  The parity mode
               at matrix-core rates.
       "bf16"  cfg.DTYPE bfloat16 (what bench.py times)
+      "h2"    cfg.DTYPE float16 + cfg.F16_CONV "x2" (round 6): the two-pass form -- activations as float16 [hi | lo] planes
+              (x to ~2^-22), every conv / fc0 ONE fp16 GEMM over K x 2 against weights [W | W] rounded to fp16 once:
+              exact activations x single-rounded weights at twice the fp16 mode's matrix-core work; stem, the narrow RPN
+              outputs and ROIAlign exact f32 as in "x3"; the head is the bf16 head
       "f16"   cfg.DTYPE float16 (round 6): the same kernels instantiated for IEEE half operands -- identical MFMA rate and
               bytes, 11 significant bits instead of 8 (1/8 of the rounding noise); activations are bounded by 65 504
       "wide"  cfg.DTYPE bfloat16 + cfg.RESIDUAL_STREAM "planes": bf16 convolutions, but the residual trunk of layer1-3 /
@@ -81,7 +85,7 @@ def conv_mode(cfg):
     if compute_dtype(cfg) == torch.float32:
         return "x3" if str(getattr(cfg, "F32_CONV", "exact")) == "bf16x3" else "f32"
     if compute_dtype(cfg) == torch.float16:
-        return "f16"
+        return "h2" if str(getattr(cfg, "F16_CONV", "single")) == "x2" else "f16"
     return "wide" if str(getattr(cfg, "RESIDUAL_STREAM", "bfloat16")) == "planes" else "bf16"
 
 
@@ -142,6 +146,24 @@ def _pack_conv(conv, dtype):
     return conv.weight.detach().permute(0, 2, 3, 1).contiguous().to(dtype)
 
 
+_PLANES3 = ("x3", "h2")          # conv modes whose EVERY conv reads / writes planes (three per bottleneck)
+
+
+def _spk(mode):
+    """conv_mode -> the x3 argument of ops.conv2d_sp: True ([hi | lo | hi] . [Wh | Wh | Wl], bf16), "h2" ([hi | lo] . [W | W],
+    float16), False (the hi plane against plain bf16 weights: mode "wide")"""
+    return {"x3": True, "h2": "h2"}.get(mode, False)
+
+
+def _plane_dtype(mode):
+    return torch.float16 if mode == "h2" else torch.bfloat16
+
+
+def _pack_conv_h2(conv, dtype=None):
+    """OIHW parameter -> the two-pass fp16 operand [Cout,R,S,2C] = [W | W] per tap (ops.conv2d_sp(x3="h2"))."""
+    return ops.split_conv_weight_h2(conv.weight.detach().float().permute(0, 2, 3, 1).contiguous())
+
+
 def _pack_conv_x3(conv, dtype=None):
     """OIHW parameter -> split-precision operand [Cout,R,S,3C] = [Wh | Wh | Wl] per tap (ops.conv2d_sp(x3=True))."""
     return ops.split_conv_weight_x3(conv.weight.detach().float().permute(0, 2, 3, 1).contiguous())
@@ -197,7 +219,7 @@ class Bottleneck(_Packed):
 
     def _pack(self, dtype, device):
         pk = {}
-        pack = _pack_conv_x3 if dtype == "x3" else _pack_conv
+        pack = {"x3": _pack_conv_x3, "h2": _pack_conv_h2}.get(dtype, _pack_conv)
         for i in (1, 2, 3):
             s, b = getattr(self, "bn%d" % i).folded()
             pk["w%d" % i] = pack(getattr(self, "conv%d" % i), dtype).to(device)
@@ -213,16 +235,16 @@ class Bottleneck(_Packed):
     def run_sp(self, x, out_mode="planes"):
         """The block on split-precision planes (conv_mode "x3" / "wide").  x: ops.Planes, or -- wide mode, the stem's
         output -- a plain bf16 tensor.  -> Planes, or out_mode "f32" / "bf16": a plain tensor (the last block of res5)."""
-        x3 = self.sp_mode == "x3"
-        pk = self._packed("x3" if x3 else torch.bfloat16, x.device)
+        x3 = _spk(self.sp_mode)
+        pk = self._packed(self.sp_mode if x3 else torch.bfloat16, x.device)
         identity = x
         if self.downsample is not None:
             identity = ops.conv2d_sp(x, pk["wd"], pk["sd"], pk["bd"], stride=self.down_stride, out_mode="planes", x3=x3)
         elif not isinstance(x, ops.Planes):
             raise ValueError("an identity block needs its input as planes")
         if x3:
-            t = ops.conv2d_sp(x, pk["w1"], pk["s1"], pk["b1"], stride=self.stride, relu=True)
-            t = ops.conv2d_sp(t, pk["w2"], pk["s2"], pk["b2"], pad=self.dilation, dil=self.dilation, relu=True)
+            t = ops.conv2d_sp(x, pk["w1"], pk["s1"], pk["b1"], stride=self.stride, relu=True, x3=x3)
+            t = ops.conv2d_sp(t, pk["w2"], pk["s2"], pk["b2"], pad=self.dilation, dil=self.dilation, relu=True, x3=x3)
         else:       # bf16 inside the block: conv1 reads the hi plane, conv2 is the plain launch
             t = ops.conv2d_sp(x, pk["w1"], pk["s1"], pk["b1"], stride=self.stride, relu=True, out_mode="bf16", x3=False)
             t = ops.conv2d_nhwc(t, pk["w2"], pk["s2"], pk["b2"], pad=self.dilation, dil=self.dilation, relu=True)
@@ -331,7 +353,7 @@ class ResNet(nn.Module):
             self.add_module(name, _make_stage(in_ch, mid, out, n, first_stride=int(i > 0) + 1))
             self.stages.append(name)
             in_ch = out
-        if self.mode in ("x3", "wide"):
+        if self.mode in ("x3", "wide", "h2"):
             for m in self.modules():
                 if isinstance(m, Bottleneck):
                     m.sp_mode = self.mode
@@ -342,18 +364,20 @@ class ResNet(nn.Module):
         conv_mode "x3" / "wide": C4 as an f32 tensor (hi + lo of the planes run_nhwc returns)."""
         y = self.run_nhwc(x, u8_norm)
         if isinstance(y, ops.Planes):      # (the seam's tensor: f32 = hi + lo in mode "x3", the bf16 hi plane in mode "wide")
-            y = y.float() if self.mode == "x3" else y.hi().contiguous()
+            y = y.float() if self.mode in _PLANES3 else y.hi().contiguous()
         return [_nchw_view(y)]
 
     def run_nhwc(self, x, u8_norm=None):
         """forward() without the NCHW view: -> C4 as a contiguous NHWC tensor, or as ops.Planes (conv_mode "x3" / "wide")"""
+        if u8_norm is not None and self.mode == "h2":       # (the two-pass mode's stem is the exact-f32 one: preprocess first)
+            x, u8_norm = ops.preprocess_frames(x.contiguous(), u8_norm[0], u8_norm[1]), None
         if u8_norm is not None:
             assert self.dtype in _HALF and x.dtype == torch.uint8
             y = self.stem.run_u8(x.contiguous(), u8_norm[0], u8_norm[1], self.dtype)
         else:
-            y = self.stem.run(x.float().contiguous(), self.dtype)
-        if self.mode == "x3":
-            y = ops.split_planes(y)       # the stem (exact f32 direct conv + max-pool) hands over its f32 map as planes
+            y = self.stem.run(x.float().contiguous(), torch.float32 if self.mode == "h2" else self.dtype)
+        if self.mode in _PLANES3:
+            y = ops.split_planes(y, _plane_dtype(self.mode))   # the stem (exact f32 direct conv + max-pool) hands over its f32 map as planes
         for name in self.stages:
             blocks = list(getattr(self, name))
             n = y.shape[0]
@@ -460,8 +484,8 @@ class RPNHead(_Packed):
     def _pack(self, dtype, device):
         w2 = torch.cat([self.cls_logits.weight.detach(), self.bbox_pred.weight.detach()], dim=0)
         b2 = torch.cat([self.cls_logits.bias.detach(), self.bbox_pred.bias.detach()], dim=0)
-        if dtype == "x3":      # split-precision 3x3 conv -> f32; the narrow 1x1 outputs stay exact f32
-            return {"w1": _pack_conv_x3(self.conv).to(device), "b1": self.conv.bias.detach().float().to(device).contiguous(),
+        if dtype in _PLANES3:   # split-precision 3x3 conv -> f32; the narrow 1x1 outputs stay exact f32
+            return {"w1": (_pack_conv_x3 if dtype == "x3" else _pack_conv_h2)(self.conv).to(device), "b1": self.conv.bias.detach().float().to(device).contiguous(),
                     "w2": w2.permute(0, 2, 3, 1).contiguous().float().to(device), "b2": b2.float().to(device).contiguous()}
         return {"w1": _pack_conv(self.conv, dtype).to(device), "b1": self.conv.bias.detach().float().to(device).contiguous(),
                 "w2": w2.permute(0, 2, 3, 1).contiguous().to(dtype).to(device), "b2": b2.float().to(device).contiguous()}
@@ -471,8 +495,8 @@ class RPNHead(_Packed):
     def run(self, feat_nhwc):
         """-> [B, H*W, 5A] f32 (channel a = objectness of anchor a, A + 4a + j = delta j)."""
         if isinstance(feat_nhwc, ops.Planes):
-            x3 = self.sp_mode == "x3"
-            pk = self._packed("x3" if x3 else torch.bfloat16, feat_nhwc.device)
+            x3 = _spk(self.sp_mode)
+            pk = self._packed(self.sp_mode if x3 else torch.bfloat16, feat_nhwc.device)
             t = ops.conv2d_sp(feat_nhwc, pk["w1"], None, pk["b1"], pad=1, relu=True, out_mode="f32" if x3 else "bf16", x3=x3)
             o = ops.conv2d_nhwc(t, pk["w2"], None, pk["b2"], out_dtype=torch.float32)
             B, H, W, C = o.shape
@@ -508,7 +532,7 @@ class RPNWithRefModule(nn.Module):
         self.post_nms_top_n = {"key": c.POST_NMS_TOP_N_TEST, "ref": cfg.MODEL.VID.RPN.REF_POST_NMS_TOP_N}
         self.nms_thresh, self.min_size = c.NMS_THRESH, c.MIN_SIZE
         self.strict_gt = bool(getattr(cfg, "NMS_STRICT_GT", True))
-        if conv_mode(cfg) in ("x3", "wide"):
+        if conv_mode(cfg) in ("x3", "wide", "h2"):
             self.head.sp_mode = conv_mode(cfg)
         self.keep_index = False       # tests: frame records also carry the kept proposals' flat anchor indices
 
@@ -614,7 +638,7 @@ class MEGAFeatureExtractor(_Packed):
         # cfg.F32_HEAD_LINEAR: "auto" (with F32_CONV "bf16x3": the head's Wq / Wk / Wv projections and stage FCs run in
         # split precision like the frame stage; the attention core, position logits and predictor stay exact f32) | "exact"
         self.head_x3 = self.mode == "x3" and str(getattr(cfg, "F32_HEAD_LINEAR", "auto")) != "exact"
-        if self.mode in ("x3", "wide"):
+        if self.mode in ("x3", "wide", "h2"):
             for m_ in self.head.modules():
                 if isinstance(m_, Bottleneck):
                     m_.sp_mode = self.mode
@@ -638,7 +662,7 @@ class MEGAFeatureExtractor(_Packed):
         r2 = self.resolution ** 2
         w0 = w0.view(w0.shape[0], self.pooled_c, r2).permute(0, 2, 1).reshape(w0.shape[0], -1)
         # (conv_mode "x3" reads fc0 as pk["fc0_x3"] only: no resident f32 copy of the 411 MB matrix beside it -- ADVICE r05)
-        pk["fc_w"] = [None if self.mode == "x3" else w0.contiguous().to(dtype).to(device)] + [
+        pk["fc_w"] = [None if self.mode in _PLANES3 else w0.contiguous().to(dtype).to(device)] + [
             self.l_fcs[i].weight.detach().to(dtype).to(device).contiguous() for i in range(1, self.stage)]
         pk["fc_b"] = [self.l_fcs[i].bias.detach().float().to(device).contiguous() for i in range(self.stage)]
         if self.stream != dtype:      # f32 activation stream in bf16 mode: the stage FCs read and write it at ~2^-16 --
@@ -650,10 +674,11 @@ class MEGAFeatureExtractor(_Packed):
         if hx3:
             for i in range(1, self.stage):
                 pk["fc_w"][i] = ops.X3Weight(self.l_fcs[i].weight, device)
-        if self.mode == "x3":      # split-precision fc0 (and reduce conv) operands
-            pk["fc0_x3"] = ops.split_conv_weight_x3(w0.float().contiguous().view(w0.shape[0], 1, 1, -1)).view(w0.shape[0], -1).to(device)
+        if self.mode in _PLANES3:  # split-precision fc0 (and reduce conv) operands
+            splitw = ops.split_conv_weight_x3 if self.mode == "x3" else ops.split_conv_weight_h2
+            pk["fc0_x3"] = splitw(w0.float().contiguous().view(w0.shape[0], 1, 1, -1)).view(w0.shape[0], -1).to(device)
             if self.conv is not None:
-                pk["rc_w_x3"] = _pack_conv_x3(self.conv).to(device)
+                pk["rc_w_x3"] = (_pack_conv_x3 if self.mode == "x3" else _pack_conv_h2)(self.conv).to(device)
         return pk
 
     # ---- per-frame stage (independent per frame; the multi-GPU sharding unit)
@@ -665,18 +690,19 @@ class MEGAFeatureExtractor(_Packed):
     def res5_features(self, feat_nhwc):
         """the proposal-independent half of box_features: res5 (+1x1 reduce) on the full C4 maps"""
         pk = self._packed(self.dtype, feat_nhwc.device)
-        if self.mode in ("x3", "wide") and not isinstance(feat_nhwc, ops.Planes):
+        if self.mode in ("x3", "wide", "h2") and not isinstance(feat_nhwc, ops.Planes):
             # the reference call signature (forward(x, proposals): x = the backbone's C4 TENSOR, f32 = hi + lo in mode "x3",
             # the bf16 hi plane in mode "wide"): back to planes, so that res5's blocks -- which run on planes in these modes --
             # end in a plain map for ROIAlign (ADVICE r05: the tensor branch handed a Planes object to the reduce conv)
-            feat_nhwc = ops.split_planes(feat_nhwc.float().contiguous()) if self.mode == "x3" else feat_nhwc.contiguous()
+            feat_nhwc = (ops.split_planes(feat_nhwc.float().contiguous(), _plane_dtype(self.mode)) if self.mode in _PLANES3
+                         else feat_nhwc.contiguous())
         if isinstance(feat_nhwc, ops.Planes) or (self.mode == "wide" and self.head.layer4[0].sp_mode is not None):
-            plain = "f32" if self.mode == "x3" else "bf16"
+            plain = "f32" if self.mode in _PLANES3 else "bf16"
             if self.conv is None:
                 return self.head.run(feat_nhwc, out_mode=plain)
             x = self.head.run(feat_nhwc, out_mode="planes")
-            return ops.conv2d_sp(x, pk["rc_w_x3"] if self.mode == "x3" else pk["rc_w"], None, pk["rc_b"], relu=True,
-                                 out_mode=plain, x3=self.mode == "x3")
+            return ops.conv2d_sp(x, pk["rc_w_x3"] if self.mode in _PLANES3 else pk["rc_w"], None, pk["rc_b"], relu=True,
+                                 out_mode=plain, x3=_spk(self.mode))
         x = self.head.run(feat_nhwc)
         if self.conv is not None:
             x = ops.conv2d_nhwc(x, pk["rc_w"], None, pk["rc_b"], relu=True)
@@ -685,7 +711,7 @@ class MEGAFeatureExtractor(_Packed):
     def pooled_fc(self, x5, rois5):
         """ROIAlign on the res5 maps -> fc0 + ReLU"""
         pk = self._packed(self.dtype, x5.device)
-        if self.mode == "x3":
+        if self.mode in _PLANES3:
             # f32 ROIAlign (exact term order) writing planes -> split-precision fc0, in row chunks: a chunk's planes tensor
             # ([rows, 2 x 49 C] bf16) stays below the kernels' 2 GiB operand limit.  Rows are independent (split-K depends
             # on K alone), so the chunking does not change a row's bits.
@@ -694,7 +720,7 @@ class MEGAFeatureExtractor(_Packed):
             out = torch.empty((K, self.feat_dim), dtype=torch.float32, device=x5.device)
             for o in range(0, K, per):
                 pooled = ops.roi_align_planes(x5, rois5[o:o + per].contiguous(), self.scale, (self.resolution, self.resolution),
-                                              self.sampling_ratio)
+                                              self.sampling_ratio, _plane_dtype(self.mode))
                 out[o:o + per] = ops.linear_sp(pooled, pk["fc0_x3"], pk["fc_b"][0], relu=True)
             return out
         pooled = ops.roi_align(x5, rois5, self.scale, (self.resolution, self.resolution), self.sampling_ratio)

@@ -355,8 +355,8 @@ def roi_align(feat, rois, spatial_scale, pooled, sampling_ratio, in_nhwc=True, o
     return out
 
 
-def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio):
-    """roi_align on f32 NHWC features, the pooled rows as split-precision planes: -> Planes [K, ph*pw*C] (t = bf16
+def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio, dtype=torch.bfloat16):
+    """roi_align on f32 NHWC features, the pooled rows as split-precision planes: -> Planes [K, ph*pw*C] (t = bf16 / f16
     [K, 2*ph*pw*C]); equals split_planes(roi_align(...).view(K, -1)) bit for bit, without the f32 tensor in between."""
     _gpu(feat, rois)
     lib = _lib.load()
@@ -365,12 +365,12 @@ def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio):
     K = rois.shape[0]
     assert feat.dtype == torch.float32 and feat.is_contiguous() and rois.dtype == torch.float32 and rois.is_contiguous()
     assert rois.shape[1] == 5 and C % 4 == 0
-    out = torch.empty((K, 2 * ph * pw * C), dtype=torch.bfloat16, device=feat.device)
+    out = torch.empty((K, 2 * ph * pw * C), dtype=dtype, device=feat.device)
     _tok = _pb("roi_align", 0.0, out.numel() * 2 + feat.numel() * 4)
-    rc = lib.mega_roi_align_fwd_planes(_ptr(feat), _ptr(rois), _ptr(out), K, C, H, W, float(spatial_scale), ph, pw,
-                                       int(sampling_ratio), _stream())
+    rc = lib.mega_roi_align_fwd_planes_dt(_ptr(feat), _ptr(rois), _ptr(out), K, C, H, W, float(spatial_scale), ph, pw,
+                                          int(sampling_ratio), _DT[dtype], _stream())
     _pe(_tok)
-    _lib.check(rc, "mega_roi_align_fwd_planes")
+    _lib.check(rc, "mega_roi_align_fwd_planes_dt")
     return Planes(out, ph * pw * C)
 
 
@@ -845,8 +845,12 @@ class Planes(object):
     __slots__ = ("t", "C")
 
     def __init__(self, t, C):
-        assert t.dtype == torch.bfloat16 and t.shape[-1] == 2 * C and t.is_contiguous()
+        assert t.dtype in _HALF and t.shape[-1] == 2 * C and t.is_contiguous()     # (float16 pairs: the fp16 two-pass mode)
         self.t, self.C = t, C
+
+    @property
+    def dtype(self):
+        return self.t.dtype
 
     @property
     def shape(self):
@@ -864,18 +868,25 @@ class Planes(object):
         return self.t[..., :self.C]
 
 
-def split_planes(x):
-    """f32 [..., C] (contiguous, C % 8 == 0) -> Planes (one launch)."""
+def split_planes(x, dtype=torch.bfloat16):
+    """f32 [..., C] (contiguous, C % 8 == 0) -> Planes of `dtype` pairs (one launch)."""
     _gpu(x)
     lib = _lib.load()
     C = x.shape[-1]
-    assert x.dtype == torch.float32 and x.is_contiguous() and C % 8 == 0
-    out = torch.empty(tuple(x.shape[:-1]) + (2 * C,), dtype=torch.bfloat16, device=x.device)
+    assert x.dtype == torch.float32 and x.is_contiguous() and C % 8 == 0 and dtype in _HALF
+    out = torch.empty(tuple(x.shape[:-1]) + (2 * C,), dtype=dtype, device=x.device)
     _tok = _pb("assemble", 0.0, x.numel() * 8.0)
-    rc = lib.mega_split_f32_to_planes(_ptr(x), _ptr(out), x.numel() // C, C, _stream())
+    rc = lib.mega_split_f32_to_planes_dt(_ptr(x), _ptr(out), x.numel() // C, C, _DT[dtype], _stream())
     _pe(_tok)
-    _lib.check(rc, "mega_split_f32_to_planes")
+    _lib.check(rc, "mega_split_f32_to_planes_dt")
     return Planes(out, C)
+
+
+def split_conv_weight_h2(w_ohwi):
+    """f32 conv weight [Cout,R,S,C] (OHWI) -> float16 [Cout,R,S,2C] = [W | W] per tap, W rounded to fp16 once: the operand of
+    conv2d_sp(x3="h2") -- against fp16 [hi | lo] planes the K = 2C contraction is x_hi.W + x_lo.W (the two-pass fp16 mode)."""
+    w = w_ohwi.float().to(torch.float16)
+    return torch.cat([w, w], dim=-1).contiguous()
 
 
 def split_conv_weight_x3(w_ohwi):
@@ -895,28 +906,33 @@ def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1
     (bf16 compute over a wide residual stream).  residual: Planes [N,Ho,Wo,Cout] (hi + lo added in f32).
     out_mode: "planes" -> Planes, "f32" -> f32 tensor, "bf16" -> bf16 tensor  [N,Ho,Wo,Cout]."""
     assert residual is None or isinstance(residual, Planes)
+    # x3 == "h2": the two-pass fp16 form -- float16 planes read as [hi | lo] (K = 2C, no wrap) against w = split_conv_weight_h2(W)
+    h2 = isinstance(x3, str) and x3 == "h2"
+    kmul = 2 if h2 else (3 if x3 else 1)
+    pdt = torch.float16 if h2 else torch.bfloat16
     if not isinstance(x, Planes):      # a plain bf16 tensor as the input (pixel stride C): x3=False only
         assert x.dtype == torch.bfloat16 and x.is_contiguous() and not x3
         xt, ldi = x, x.shape[-1]
     else:
         xt, ldi = x.t, 2 * x.C
+    assert xt.dtype == pdt and (residual is None or residual.t.dtype == pdt)
     _gpu(xt, w, scale, bias, None if residual is None else residual.t)
     lib = _lib.load()
     N, H, W, C = x.shape
     Cout, R, S, Cw = w.shape
-    assert Cw == (3 * C if x3 else C) and w.dtype == torch.bfloat16 and w.is_contiguous() and C % 64 == 0 and Cout % 8 == 0
+    assert Cw == kmul * C and w.dtype == pdt and w.is_contiguous() and C % 64 == 0 and Cout % 8 == 0
     Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
     mode = {"bf16": 0, "planes": 1, "f32": 2}[out_mode]
     ldo = 0
     if out is not None:      # caller's [N*Ho*Wo, ldo >= Cout] buffer (plain output modes): row stride = its width
         assert mode != 1 and out.dim() == 2 and out.shape[0] == N * Ho * Wo and out.shape[1] >= Cout and out.is_contiguous()
-        assert out.dtype == (torch.float32 if mode == 2 else torch.bfloat16)
+        assert out.dtype == (torch.float32 if mode == 2 else pdt)
         ldo = out.shape[1]
     elif mode == 1:
-        out = torch.empty((N, Ho, Wo, 2 * Cout), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((N, Ho, Wo, 2 * Cout), dtype=pdt, device=x.device)
     else:
-        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32 if mode == 2 else torch.bfloat16, device=x.device)
+        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32 if mode == 2 else pdt, device=x.device)
     if residual is not None:
         assert residual.shape == (N, Ho, Wo, Cout)
     for v in (scale, bias):
@@ -928,16 +944,16 @@ def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1
     M = N * Ho * Wo
     _tok = None
     if _PROF is not None:
-        _tok = _pb("igemm8_sp_" + ("x3" if x3 else "hi"), 2.0 * M * Cout * K,
+        _tok = _pb("igemm8_sp_" + ("h2" if h2 else ("x3" if x3 else "hi")), 2.0 * M * Cout * K,
                    xt.numel() * (2.0 if x3 or xt is x else 1.0) + w.numel() * 2.0 + out.numel() * out.element_size()
                    + (0 if residual is None else residual.t.numel() * 2.0), detail="%dx%dx%d (%dx%d)" % (M, Cout, K, R, S))
     nb = lib.mega_conv2d_nhwc_workspace_bytes(M, Cout, K) if mode == 2 and residual is None else 0
     ws = _ws(nb, x.device) if nb else None
-    rc = lib.mega_conv2d_nhwc_sp(_ptr(xt), ldi, 2 * C if x3 else 0, _ptr(w), _ptr(scale), _ptr(bias),
-                                 None if residual is None else _ptr(residual.t), 0, _ptr(out), ldo, mode, N, H, W, Cw, Cout,
-                                 R, S, stride, pad, dil, int(relu), _ptr(ws), nb, _stream())
+    rc = lib.mega_conv2d_nhwc_sp_dt(_ptr(xt), ldi, 2 * C if kmul == 3 else 0, _ptr(w), _ptr(scale), _ptr(bias),
+                                    None if residual is None else _ptr(residual.t), 0, _ptr(out), ldo, mode, N, H, W, Cw, Cout,
+                                    R, S, stride, pad, dil, int(relu), _DT[pdt], _ptr(ws), nb, _stream())
     _pe(_tok)
-    _lib.check(rc, "mega_conv2d_nhwc_sp")
+    _lib.check(rc, "mega_conv2d_nhwc_sp_dt")
     return Planes(out, Cout) if mode == 1 else out
 
 
@@ -978,9 +994,12 @@ def linear_transposed_x3(w, x, ld):
 
 
 def linear_sp(x, w3, bias=None, relu=False):
-    """x: Planes [M,K]; w3 = split_conv_weight_x3 of [Nout,K] viewed [Nout,1,1,K] -> f32 [M,Nout] (x.W to ~2^-16)."""
+    """x: Planes [M,K]; w3 = split_conv_weight_x3 of [Nout,K] viewed [Nout,1,1,K] -> f32 [M,Nout] (x.W to ~2^-16); or, for
+    float16 planes, w3 = split_conv_weight_h2 of it ([Nout, 2K]: the two-pass fp16 form)."""
     M, K = x.shape
-    y = conv2d_sp(Planes(x.t.view(M, 1, 1, 2 * K), K), w3.view(w3.shape[0], 1, 1, 3 * K), None, bias, relu=relu, out_mode="f32")
+    h2 = x.t.dtype == torch.float16
+    y = conv2d_sp(Planes(x.t.view(M, 1, 1, 2 * K), K), w3.view(w3.shape[0], 1, 1, (2 if h2 else 3) * K), None, bias, relu=relu,
+                  out_mode="f32", x3="h2" if h2 else True)
     return y.view(M, w3.shape[0])
 
 

@@ -244,15 +244,20 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
 
 
 # ---- split-precision planes (conv_mode "x3" / "wide"): the twins compute on hi + lo (or hi) in f32 and re-split
-def _planes(x32):
+def _planes(x32, dtype=torch.bfloat16):
     from mega.pytorch_amd import ops
-    hi = x32.to(torch.bfloat16)
-    lo = (x32 - hi.float()).to(torch.bfloat16)
+    hi = x32.to(dtype)
+    lo = (x32 - hi.float()).to(dtype)
     return ops.Planes(torch.cat([hi, lo], dim=-1).contiguous(), x32.shape[-1])
 
 
-def split_planes(x):
-    return _planes(x.float())
+def split_planes(x, dtype=torch.bfloat16):
+    return _planes(x.float(), dtype)
+
+
+def split_conv_weight_h2(w_ohwi):
+    w = w_ohwi.float().to(torch.float16)
+    return torch.cat([w, w], dim=-1).contiguous()
 
 
 def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_mode="planes", x3=True,
@@ -263,31 +268,37 @@ def conv2d_sp(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1
         xin = x.float() if x3 else x.hi().float()
     else:
         C, xin = x.shape[-1], x.float()
-    w32 = (w[..., :C].float() + w[..., 2 * C:].float()) if x3 else w.float()      # [Wh | Wh | Wl] -> Wh + Wl
+    h2 = isinstance(x3, str) and x3 == "h2"
+    pdt = torch.float16 if h2 else torch.bfloat16
+    if h2:
+        w32 = w[..., :C].float()                                                    # [W | W] -> W (rounded to fp16 once)
+        assert w.shape[-1] == 2 * C
+    else:
+        w32 = (w[..., :C].float() + w[..., 2 * C:].float()) if x3 else w.float()    # [Wh | Wh | Wl] -> Wh + Wl
     assert w32.shape[-1] == C
     y = conv2d_nhwc(xin, w32, scale, bias, None if residual is None else residual.float(), stride, pad, dil, relu,
                     out_dtype=torch.float32)
     if out is not None:
         out[:, :y.shape[-1]] = y.reshape(out.shape[0], -1).to(out.dtype)
         return out
-    return _planes(y) if out_mode == "planes" else y.to(torch.float32 if out_mode == "f32" else torch.bfloat16)
+    return _planes(y, pdt) if out_mode == "planes" else y.to(torch.float32 if out_mode == "f32" else pdt)
 
 
 def linear_sp(x, w3, bias=None, relu=False):
     M, K = x.shape
-    w32 = w3[:, :K].float() + w3[:, 2 * K:].float()
+    w32 = w3[:, :K].float() + w3[:, 2 * K:].float() if w3.shape[1] == 3 * K else w3[:, :K].float()
     y = x.float() @ w32.t()
     if bias is not None:
         y = y + bias
     return F.relu(y) if relu else y
 
 
-def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio):
+def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio, dtype=torch.bfloat16):
     y = roi_align(feat, rois, spatial_scale, pooled, sampling_ratio)
-    return _planes(y.reshape(y.shape[0], -1).float())
+    return _planes(y.reshape(y.shape[0], -1).float(), dtype)
 
 
-ALL = ["split_planes", "conv2d_sp", "linear_sp", "roi_align_planes", "cast_bf16", "cast_half", "cat_rows_cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+ALL = ["split_planes", "split_conv_weight_h2", "conv2d_sp", "linear_sp", "roi_align_planes", "cast_bf16", "cast_half", "cat_rows_cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames", "position_logits_batched",
        "relation_attention_batched", "postprocess_batched"]
 

@@ -303,3 +303,61 @@ def test_f16_model_frame_stage_is_batch_invariant_and_close_to_f32(dev):
     f16 = m16.frame_stage_b(a16, [300, 300])["feats"]
     rel = float((f16 - f32).abs().mean() / f32.abs().mean())
     assert rel < 1.5e-3, "fc0 mean relative error %.3g" % rel
+
+
+# ------------------------------------------------------------------------------------------------ the two-pass form (conv_mode "h2")
+from test_kernels_gpu import SP_CASES, _sp_inputs  # noqa: E402
+
+
+@pytest.mark.parametrize("case", SP_CASES)
+def test_h2_conv2d_sp_vs_f64(dev, case):
+    """The two-pass fp16 conv (float16 [hi | lo] planes against [W | W], W rounded to fp16 ONCE, f32 accumulation) against the
+    f64 convolution of the same f32 activations with the SAME fp16-rounded weights: what is left is the planes' representation
+    (~2^-22 of a value, the lo plane's subnormal floor 6e-8 absolute) and f32 accumulation -- the exact-f32 kernels' level."""
+    ops = _ops()
+    N, H, W, C, Cout, R, stride, pad, dil, relu, use_res, out_mode = case
+    x, w, scale, bias, res = _sp_inputs(case)
+    w16 = w.to(H16)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w16.permute(0, 3, 1, 2).double(), stride=stride, padding=pad, dilation=dil)
+    ref = ref * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1)
+    if use_res:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    if relu:
+        ref = ref.clamp(min=0)
+    ref = ref.permute(0, 2, 3, 1)
+    xp = ops.split_planes(x.to(dev).contiguous(), H16)
+    assert xp.t.dtype == H16 and (xp.float().cpu() - x).abs().max() <= 2.0 ** -20 * x.abs().max() + 1e-7
+    rp = ops.split_planes(res.to(dev).contiguous(), H16) if use_res else None
+    wh2 = ops.split_conv_weight_h2(w).to(dev)
+    assert wh2.dtype == H16 and wh2.shape[-1] == 2 * C
+    y = ops.conv2d_sp(xp, wh2, scale.to(dev), bias.to(dev), residual=rp, stride=stride, pad=pad, dil=dil, relu=relu,
+                      out_mode=out_mode, x3="h2")
+    got = (y.float() if out_mode == "planes" else y).cpu().double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print("conv2d_sp h2 %s: max err / scale = %.3g" % (case, err))
+    assert got.shape == ref.shape and err < 2e-5, err
+
+
+def test_h2_linear_sp_split_k_and_roi_align_planes(dev):
+    """fc0's shape class (K >= 32768: three K ranges + finalize) through the fp16 SP kernels; the f32 ROIAlign writing fp16
+    [hi | lo] planes == split_planes(., float16) of its f32 output, bit for bit"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, K, Nout = 300, 49 * 1024, 1024
+    x = torch.randn((M, K), generator=g)
+    w = torch.randn((Nout, K), generator=g) / math.sqrt(K)
+    b = torch.randn((Nout,), generator=g) * 0.1
+    ref = (x.double() @ w.to(H16).double().t() + b.double()).clamp(min=0)
+    y = ops.linear_sp(ops.split_planes(x.to(dev), H16), ops.split_conv_weight_h2(w.view(Nout, 1, 1, K)).to(dev).view(Nout, 2 * K),
+                      b.to(dev), relu=True).cpu().double()
+    err = (y - ref).abs().max().item() / ref.abs().max().item()
+    print("linear_sp h2 split-K: max err / scale = %.3g" % err)
+    assert err < 2e-5
+    for (B, Hh, Ww, C, Kr) in ((2, 38, 63, 2048, 300), (1, 12, 17, 32, 9)):
+        g = torch.Generator().manual_seed(C + Kr)
+        feat = torch.randn((B, Hh, Ww, C), generator=g).to(dev)
+        rois = _random_rois(g, Kr, B, Ww * 16, Hh * 16).to(dev)
+        f32 = ops.roi_align(feat, rois, 1.0 / 16, (7, 7), 0)
+        want = ops.split_planes(f32.view(Kr, -1).contiguous(), H16)
+        got = ops.roi_align_planes(feat, rois, 1.0 / 16, (7, 7), 0, H16)
+        assert got.C == want.C and got.t.dtype == H16 and torch.equal(got.t.view(torch.int16), want.t.view(torch.int16))
