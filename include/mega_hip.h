@@ -58,7 +58,9 @@ int mega_conv2d_nhwc_tile(int M, int Cout, int K);
  * same MFMA instruction, so the choice never changes a result bit. */
 int mega_conv2d_nhwc_plan(int M, int Cout, int K, int in_dtype);
 /* The shape-complete form: which kernel mega_conv2d_nhwc[_ws] really dispatches THIS layer to (same predicates as the
- * launch path): kind 6 = conv3x3_c64_kernel (layer1's 3x3 64 -> 64 conv: 3x3, stride 1, pad 1, bf16 out, no residual,
+ * launch path): kind 2 = igemm2_kernel (round 6: 128 x 256 tiles at two blocks per CU -- the streaming class, 1x1 with K <= 512,
+ * by default), kind 4 = igemm4_kernel matrix class (round 6: the igemm8 tiles on 4 waves of 512 registers, 128 x 128 outputs per
+ * wave), 3 = igemm4 streaming class (only with MEGA_IGEMM4=2), kind 6 = conv3x3_c64_kernel (layer1's 3x3 64 -> 64 conv: 3x3, stride 1, pad 1, bf16 out, no residual,
  * enough tiles), 7 = igemm8 streaming class (1x1, K <= 512), 8 = igemm8 matrix class, 0 = igemm_kernel.  -1: bad shape. */
 int mega_conv2d_nhwc_plan_ex(int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil, int ldo,
                              int has_residual, int in_dtype, int out_dtype);

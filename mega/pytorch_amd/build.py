@@ -16,6 +16,9 @@ STAMP = os.path.join(HERE, "csrc", ".build_stamp")
 SOURCES = {
     "igemm.hip": [],
     "igemm8.hip": [],
+    "igemm4.hip": [],
+    "igemm2.hip": [],
+    "stream1x1.hip": [],
     "spatial.hip": [],
     "boxes.hip": ["-ffp-contract=off"],
     # MFMA results in VGPRs: the attention loop otherwise keeps its O accumulators in AGPRs and moves them to VGPRs and

@@ -444,6 +444,9 @@ inline void choose_tile(int M, int Cout, int K, int z, bool bf16, int& kind, int
   kind = 0;
   const char* force = getenv("MEGA_IGEMM_TILE");
   if (force && sscanf(force, "8:%d", &bm) == 1) { kind = 8; bn = 256; return; }
+  if (force && sscanf(force, "4:%d", &bm) == 1) { kind = 4; bn = 256; return; }
+  if (force && sscanf(force, "2:%d", &bm) == 1) { kind = 2; bm = 128; bn = 256; return; }
+  if (force && sscanf(force, "s:%d", &bm) == 1) { kind = 1; bm = 32; bn = 256; return; }
   if (force && sscanf(force, "%dx%d", &bm, &bn) == 2) return;
   const long b256 = (long)cdiv(M, 256) * cdiv(Cout, 256) * z;
   const long b128 = (long)cdiv(M, 128) * cdiv(Cout, 128) * z;
@@ -477,14 +480,51 @@ int dispatch_tile(const ConvParams& p, hipStream_t st) {
   if (kind == 8 && !(is_bf16 && mega_igemm8_supports(p))) {    // forced onto a shape it cannot take
     kind = 0; bm = 128; bn = 128;
   }
+  if constexpr (is_bf16 && sizeof(OT) == 2) {
+    // stream1x1 (persistent, wave-owned 32 x 256 tiles, weights resident in LDS): layer3's / layer2's conv3.  Measured SLOWER than
+    // the tile kernels (0.173 against 0.118 ms on layer3's conv3: its row-strided 8-byte epilogue accesses and 32-byte operand
+    // pieces bind the CU's address path, profiles/r06_streaming_class_experiments.txt) -- opt-in with MEGA_STREAM1X1=1;
+    // MEGA_IGEMM_TILE=s:32 forces it (shapes it does not take fall through)
+    static const int use_s = getenv("MEGA_STREAM1X1") ? atoi(getenv("MEGA_STREAM1X1")) : 0;
+    if ((kind == 1 || (kind == 8 && use_s && !getenv("MEGA_IGEMM_TILE"))) && mega_stream1x1_supports(p, 0))
+      return mega_stream1x1_launch(p, Half16<T>::CODE, st);
+  }
+  if (kind == 1) { kind = is_bf16 && mega_igemm8_supports(p) ? 8 : 0; bm = kind ? 256 : 128; bn = kind ? 256 : 128; }
   if constexpr (is_bf16) {
+    // igemm2 (4 waves, 128 x 256 tile, K-tile 32, TWO blocks per CU).  Measured (profiles/r06_streaming_class_experiments.txt):
+    // +6-10 % on layer2's conv3 (K = 128), +-1 % on layer3's conv3, slower on everything with a long K loop -- opt-in:
+    // MEGA_IGEMM2=1 the streaming class (1x1, K <= 512) with K <= 128, =2 the whole streaming class, =3 every igemm8 launch it
+    // supports; MEGA_IGEMM_TILE=2:128 forces it.  Default 0: the product path stays on igemm8.
+    static const int use2 = getenv("MEGA_IGEMM2") ? atoi(getenv("MEGA_IGEMM2")) : 0;
+    {
+      const bool streaming2 = mega_igemm8_streaming(p.R * p.S, p.K) && p.ksplit == 1;
+      if (kind == 2 || (kind == 8 && use2 && (use2 > 2 || (streaming2 && (use2 > 1 || p.K <= 128))) && !getenv("MEGA_IGEMM_TILE"))) {
+        if (mega_igemm2_supports(p, sizeof(OT) == 4)) return mega_igemm2_launch(p, sizeof(OT) == 4, Half16<T>::CODE, st);
+        if (kind == 2) kind = mega_igemm8_supports(p) ? 8 : 0;
+        if (kind == 0) { bm = 128; bn = 128; } else if (bm != 192) bm = 256;
+      }
+    }
+    // igemm4 (4 waves x 512 registers, 128 x 128 outputs per wave): the matrix-core-bound launch class -- 3x3 convs and every
+    // layer with more than 8 K-tiles -- when its epilogue serves the shape; MEGA_IGEMM4=0 keeps everything on igemm8,
+    // MEGA_IGEMM4=2 also sends the streaming class (1x1, K <= 512) over; MEGA_IGEMM_TILE=4:256 / 4:192 forces it
+    static const int use4 = getenv("MEGA_IGEMM4") ? atoi(getenv("MEGA_IGEMM4")) : 0;
+    const bool streaming = mega_igemm8_streaming(p.R * p.S, p.K) && p.ksplit == 1;
+    if (kind == 4 || (kind == 8 && use4 && (use4 > 1 || !streaming) && !getenv("MEGA_IGEMM_TILE"))) {
+      if (mega_igemm4_supports(p, sizeof(OT) == 4)) {
+        rc = mega_igemm4_launch(p, bm == 192 ? 192 : 256, sizeof(OT) == 4, Half16<T>::CODE, st);
+        if (rc == MEGA_OK && p.ksplit > 1) rc = launch_finalize<T, OT>(p, st);
+        return rc;
+      }
+      if (kind == 4) kind = mega_igemm8_supports(p) ? 8 : 0;
+      if (kind == 0) { bm = 128; bn = 128; }
+    }
     if (kind == 8) {
       rc = mega_igemm8_launch(p, bm, sizeof(OT) == 4, Half16<T>::CODE, st);
       if (rc == MEGA_OK && p.ksplit > 1) rc = launch_finalize<T, OT>(p, st);
       return rc;
     }
   }
-  if (kind == 8) rc = MEGA_ERR_ARG;
+  if (kind == 8 || kind == 4 || kind == 2) rc = MEGA_ERR_ARG;
   else if (bm == 256 && bn == 256) rc = launch<T, OT, 256, 256>(p, st);
   else if (bm == 256 && bn == 128) rc = launch<T, OT, 256, 128>(p, st);
   else if (bm == 128 && bn == 128) rc = launch<T, OT, 128, 128>(p, st);
@@ -504,8 +544,33 @@ static int plan_of(const ConvParams& p, bool bf16_in, bool f32_out) {
   if (bf16_in && !f32_out && !getenv("MEGA_IGEMM_TILE") && mega_conv64_supports(p, 0)) return 6 * 1000000 + 256 * 1000 + 64;
   int kind = 0, bm = 0, bn = 0;
   choose_tile(p.M, p.Cout, p.K, choose_ksplit(p.K), bf16_in, kind, bm, bn);
-  if (kind == 8 && !(bf16_in && mega_igemm8_supports(p))) { kind = 0; bm = 128; bn = 128; }
-  if (kind == 8 && mega_igemm8_streaming(p.R * p.S, p.K) && choose_ksplit(p.K) == 1) kind = 7;
+  if (kind == 1 || kind == 8) {      // stream1x1 first, then igemm2 (the launch path's own rule: dispatch_tile)
+    static const int use_s = getenv("MEGA_STREAM1X1") ? atoi(getenv("MEGA_STREAM1X1")) : 0;
+    ConvParams q = p;
+    q.ksplit = choose_ksplit(p.K);
+    if (bf16_in && !f32_out && (kind == 1 || (use_s && !getenv("MEGA_IGEMM_TILE"))) && mega_stream1x1_supports(q, 0)) return 1 * 1000000 + 32 * 1000 + 256;
+    if (kind == 1) { kind = 8; bm = 256; bn = 256; }
+  }
+  if (kind == 2 || kind == 8) {      // igemm2 first (the launch path's own rule: dispatch_tile)
+    static const int use2 = getenv("MEGA_IGEMM2") ? atoi(getenv("MEGA_IGEMM2")) : 0;
+    ConvParams q = p;
+    q.ksplit = choose_ksplit(p.K);
+    const bool streaming2 = mega_igemm8_streaming(p.R * p.S, p.K) && q.ksplit == 1;
+    if (bf16_in && (kind == 2 || (use2 && (use2 > 2 || (streaming2 && (use2 > 1 || p.K <= 128))) && !getenv("MEGA_IGEMM_TILE"))) && mega_igemm2_supports(q, f32_out))
+      return 2 * 1000000 + 128 * 1000 + 256;
+    if (kind == 2) { kind = 8; bm = 256; }
+  }
+  if ((kind == 8 || kind == 4) && !(bf16_in && mega_igemm8_supports(p))) { kind = 0; bm = 128; bn = 128; }
+  if (kind == 8 || kind == 4) {      // (the launch path's own rule: dispatch_tile)
+    static const int use4 = getenv("MEGA_IGEMM4") ? atoi(getenv("MEGA_IGEMM4")) : 0;
+    const bool streaming = mega_igemm8_streaming(p.R * p.S, p.K) && choose_ksplit(p.K) == 1;
+    ConvParams q = p;
+    q.ksplit = choose_ksplit(p.K);
+    const bool take4 = (kind == 4 || (use4 && (use4 > 1 || !streaming) && !getenv("MEGA_IGEMM_TILE"))) && mega_igemm4_supports(q, f32_out || q.ksplit > 1);
+    if (take4) kind = streaming ? 3 : 4;     // 4: igemm4 matrix class, 3: igemm4 streaming class
+    else kind = streaming ? 7 : 8;
+    if (bm != 192) bm = 256;
+  }
   return kind * 1000000 + bm * 1000 + bn;
 }
 

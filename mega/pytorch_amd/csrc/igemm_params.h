@@ -36,6 +36,17 @@ int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, int half_dtype,
 int mega_igemm8_supports(const ConvParams& p);
 // 1 when a launch of `taps` = R * S kernel taps and GEMM depth K belongs to igemm8's streaming class (1x1, K <= 512)
 int mega_igemm8_streaming(int taps, int K);
+// igemm4.hip: the same tiles on 4 waves of 512 registers (128 x 128 outputs per wave), for the shapes its buffer-addressed
+// epilogue serves (mega_igemm4_supports) -- the matrix-core-bound launch class by default (choose_tile, igemm.hip)
+int mega_igemm4_supports(const ConvParams& p, int out_f32);
+int mega_igemm4_launch(const ConvParams& p, int bm, int out_f32, int half_dtype, hipStream_t st);
+// igemm2.hip: 128 x 256 tiles, K-tile 32, 4 waves, two blocks per CU -- the streaming launch class (1x1, K <= 512) by default
+int mega_igemm2_supports(const ConvParams& p, int out_f32);
+int mega_igemm2_launch(const ConvParams& p, int out_f32, int half_dtype, hipStream_t st);
+// stream1x1.hip: persistent 1x1 / stride-1 conv with K = 128 / 256 (layer3's / layer2's conv3 + residual): weights resident in LDS,
+// a wave owns a 32 x 256 output tile, operands straight from global memory into MFMA fragments; bit-identical to the tile kernels
+int mega_stream1x1_supports(const ConvParams& p, int out_f32);
+int mega_stream1x1_launch(const ConvParams& p, int half_dtype, hipStream_t st);
 // conv64.hip: persistent 3x3 / 64 -> 64 channel kernel (layer1's conv2); bit-identical to the generic tiles
 int mega_conv64_supports(const ConvParams& p, int out_f32);
 int mega_conv64_launch(const ConvParams& p, int half_dtype, hipStream_t st);

@@ -131,8 +131,8 @@ def _igemm_family(lib, M, Cout, K, dtype, shape=None):
     # one family = one rocprofv3 symbol: igemm8_kernel<OT, ...> is instantiated per OUTPUT type, so a bf16 launch that writes
     # f32 (fc0's split-K partial sums, the RPN head's f32 logits) is a different symbol from the bf16-output launches of the
     # same tile ("_f32out")
-    f32out = shape is not None and dtype in _HALF and (shape[-1] == torch.float32 or (kind in (7, 8) and lib.mega_conv2d_nhwc_workspace_bytes(M, Cout, K) > 0))
-    return "igemm%s_%s_%dx%d%s" % ({8: "8", 7: "8s"}.get(kind, ""), {torch.bfloat16: "bf16", torch.float16: "f16"}.get(dtype, "f32"),
+    f32out = shape is not None and dtype in _HALF and (shape[-1] == torch.float32 or (kind in (2, 3, 4, 7, 8) and lib.mega_conv2d_nhwc_workspace_bytes(M, Cout, K) > 0))
+    return "igemm%s_%s_%dx%d%s" % ({8: "8", 7: "8s", 4: "4", 3: "4s", 2: "2", 1: "s"}.get(kind, ""), {torch.bfloat16: "bf16", torch.float16: "f16"}.get(dtype, "f32"),
                                    t // 1000, t % 1000, "_f32out" if f32out else "")
 
 

@@ -670,6 +670,39 @@ def test_igemm8_bit_equal_to_register_staged_tiles(dev):
                 case, force, (outs[0].float() - ref.float()).abs().max().item())
 
 
+def test_experimental_gemm_kernels_bit_equal_to_register_staged_tiles(dev):
+    """Round 6's opt-in GEMM kernels -- igemm4 (4 waves x 512 registers, 128 x 128 outputs per wave), igemm2 (128 x 256 tiles, K-tile
+    32, two blocks per CU) and stream1x1 (persistent, wave-owned 32 x 256 tiles, weights resident in LDS) -- are not dispatched by
+    default (measured at or below igemm8: profiles/r06_streaming_class_experiments.txt) but stay in the library behind
+    MEGA_IGEMM4 / MEGA_IGEMM2 / MEGA_STREAM1X1; they must give the SAME BITS as the register-staged tiles (same MFMA, same
+    ascending K order, same epilogue arithmetic).  Shapes a kernel does not take fall through to igemm8 inside the dispatcher."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        import sys
+        sys.path.insert(0, os.path.join(root, "tools", "gpu"))
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", "gpu", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    chk = load("igemm8_check")
+    cases = list(chk.CASES) + [
+        (9, 38, 63, 256, 1024, 1, 1, 0, 1, 1, True, False),       # layer3 conv3 (M = 21546: stream1x1 takes it, 10-row tail tile)
+        (9, 38, 63, 256, 1024, 1, 1, 0, 1, 2, False, False),      # LeakyReLU, no residual
+        (2, 75, 125, 128, 512, 1, 1, 0, 1, 1, True, False),       # layer2 conv3 (K = 128)
+        (8, 38, 63, 256, 2048, 1, 1, 0, 1, 0, True, False),       # eight N tiles
+    ]
+    for case in cases:
+        ref = chk.run(case, "128x128")[0]
+        for force in ("4:256", "4:192", "2:128", "s:32"):
+            outs = chk.run(case, force, reps=2)
+            assert torch.equal(outs[0], outs[1]), "%s %s: run-to-run difference" % (case, force)
+            assert torch.equal(outs[0], ref), "%s %s: differs from the 128x128 tile (max |d| %.3g)" % (
+                case, force, (outs[0].float() - ref.float()).abs().max().item())
+
+
 def test_multi_cat_equals_torch_cat(dev):
     """ops.multi_cat (mega_copy_segments: every concatenation of a call in one launch per copy width) == torch.cat,
     bit for bit: row blocks (16-byte rows), f32 boxes, and 2-byte-aligned V^T column blocks (75 keys = 150 bytes)
