@@ -371,6 +371,21 @@ typedef struct { const float* rois_q; const float* rois_k; void* out_bf16; int N
 int mega_position_logits_tiled_batched(const void* descs /* mega_pos_desc[n], host memory */, int n, const float* wg_t,
                                        const float* bg, const float* dim_mat, void* stream);
 
+/* Round 6: the head on IEEE-half operands (cfg.HEAD_DTYPE "float16": Q K^T, P V and the position term on
+ * v_mfma_f32_32x32x16_f16 / 16x16x32_f16 -- the bf16 rate and bytes, 11 significant bits instead of 8).  The three
+ * tile-ordered-logit entry points above with the 16-bit type as an argument: dtype = MEGA_BF16 (the calls above) or
+ * MEGA_F16; the logits / Q / K / V^T are that type.  mega_relation_attention and mega_relation_attention_batched take
+ * MEGA_F16 through their own dtype argument.  Replaces the same reference code as the bf16 forms:
+ * roi_box_feature_extractors.py:126-176 (position embedding), :567-646 (attention_module_multi_head). */
+int mega_position_logits_tiled_dt(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
+                                  const float* dim_mat, void* out16, int Nq, int Nk, int dtype, void* stream);
+int mega_position_logits_tiled_batched_dt(const void* descs /* mega_pos_desc[n], host memory */, int n, const float* wg_t,
+                                          const float* bg, const float* dim_mat, int dtype, void* stream);
+int mega_relation_attention_tiled_pos_dt(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
+                                         const void* pos_tiled16, const void* resid, int ldr, const float* bias_v,
+                                         void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype, void* ws,
+                                         size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,11 @@ SIGNATURES = {
                                         c_int, c_void_p, c_size_t, c_void_p]),
     "mega_relation_attention_batched": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "mega_position_logits_tiled_batched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mega_position_logits_tiled_dt": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
+    "mega_position_logits_tiled_batched_dt": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mega_relation_attention_tiled_pos_dt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                                     c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                     c_float, c_int, c_void_p, c_size_t, c_void_p]),
     "mega_conv2d_nhwc_tile": (c_int, [c_int] * 3),
     "mega_conv2d_nhwc_plan": (c_int, [c_int] * 4),
     "mega_conv2d_nhwc_plan_ex": (c_int, [c_int] * 14),

@@ -78,7 +78,7 @@ def _mega_cfg(r50):
     return CfgNode({
         "DTYPE": "float32",                      # defaults.py:541; "bfloat16" selects the bf16 MFMA path, "float16" the same
                                                  # kernels on IEEE-half operands (11 significant bits, values < 65 504)
-        "HEAD_DTYPE": "bfloat16",                # float16 mode only: operand type of the aggregation head (modeling.head_dtype)
+        "HEAD_DTYPE": "bfloat16",                # float16 mode only: operand type of the aggregation head, "bfloat16" | "float16" (modeling.head_dtype)
         # float16 mode only: "single" = one fp16 MFMA pass per product; "x2" = the two-pass form (modeling.conv_mode "h2"):
         # activations as float16 [hi | lo] planes against weights rounded to fp16 once, K x 2
         "F16_CONV": "single",

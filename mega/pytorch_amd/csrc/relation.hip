@@ -22,6 +22,7 @@
 //                       blockIdx.z (a call has only Nq/128 * 16 blocks for 256 CUs); partial (m, l, O) are then
 //                       merged by attn_combine_kernel.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -213,20 +214,36 @@ __global__ __launch_bounds__(256) void pos_logits_mfma_kernel(const float4* __re
 // logits in LDS in their final order and writes 32 runs of 512 contiguous bytes (16 B per lane) instead of 8-byte
 // pieces scattered over 16 head planes.  Each lane needs only the sine OR the cosine of its 16 arguments:
 // cos(x) = sin(x + 1/4 revolution), one transcendental per value instead of two.
+// HT = bf16_t / f16_t (round 6: the head on IEEE-half operands): the embedding, Wg and the stored logits are HT
+template <typename HT> struct PosMma;
+template <> struct PosMma<bf16_t> {
+  typedef bf16x8_t vec;
+  typedef __bf16 elem;
+  __device__ static __forceinline__ f32x4_t run(const vec& a, const vec& b, const f32x4_t& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct PosMma<f16_t> {
+  typedef f16x8_t vec;
+  typedef _Float16 elem;
+  __device__ static __forceinline__ f32x4_t run(const vec& a, const vec& b, const f32x4_t& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+template <typename HT>
 __device__ __forceinline__ void pos_logits_tiled_body(const float4* __restrict__ rois_q,
                                                       const float4* __restrict__ rois_k,
                                                       const float* __restrict__ wgt, const float* __restrict__ bg,
-                                                      const float* __restrict__ dim_mat, bf16_t* __restrict__ out_t,
+                                                      const float* __restrict__ dim_mat, unsigned short* __restrict__ out_t,
                                                       int Nq, int Nk) {
-  __shared__ __attribute__((aligned(16))) bf16_t stage[16 * 2 * 8 * 32];   // [head][key tile][q][tile order]
+  typedef typename PosMma<HT>::vec hvec;
+  typedef typename PosMma<HT>::elem helem;
+  __shared__ __attribute__((aligned(16))) unsigned short stage[16 * 2 * 8 * 32];   // [head][key tile][q][tile order]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 15, g = lane >> 4;
   const int q0 = blockIdx.y * 8, k00 = blockIdx.x * 64;
-  bf16x8_t bw[2];
+  hvec bw[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bw[s][e] = (__bf16)wgt[(32 * s + 8 * g + e) * 16 + row];
+    for (int e = 0; e < 8; ++e) bw[s][e] = (helem)wgt[(32 * s + 8 * g + e) * 16 + row];
   float crev[8];                                       // 100 / (2 pi dim[i]): log-ratio -> revolutions
 #pragma unroll
   for (int i = 0; i < 8; ++i) crev[i] = (100.0f * 0.15915494309189535f) / dim_mat[i];
@@ -261,16 +278,16 @@ __device__ __forceinline__ void pos_logits_tiled_body(const float4* __restrict__
     f32x4_t acc = {bias, bias, bias, bias};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8_t a;
+      hvec a;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] = (__bf16)sin_rev(fmaf(pm[s], crev[i], shift));
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw[s], acc, 0, 0, 0);
+      for (int i = 0; i < 8; ++i) a[i] = (helem)sin_rev(fmaf(pm[s], crev[i], shift));
+      acc = PosMma<HT>::run(a, bw[s], acc);
     }
     // D: head = row, keys kb + 4 g + r of the block's 64
     const int kf = kb + 4 * g, ktl = kf >> 5, kk = kf & 31;
     uint2 pk;
-    pk.x = (unsigned)f32_to_bf16(fast_log(fmaxf(acc[0], 0.f) + 1e-6f)) | ((unsigned)f32_to_bf16(fast_log(fmaxf(acc[1], 0.f) + 1e-6f)) << 16);
-    pk.y = (unsigned)f32_to_bf16(fast_log(fmaxf(acc[2], 0.f) + 1e-6f)) | ((unsigned)f32_to_bf16(fast_log(fmaxf(acc[3], 0.f) + 1e-6f)) << 16);
+    pk.x = Half16<HT>::pack2(fast_log(fmaxf(acc[0], 0.f) + 1e-6f), fast_log(fmaxf(acc[1], 0.f) + 1e-6f));
+    pk.y = Half16<HT>::pack2(fast_log(fmaxf(acc[2], 0.f) + 1e-6f), fast_log(fmaxf(acc[3], 0.f) + 1e-6f));
     *reinterpret_cast<uint2*>(&stage[((row * 2 + ktl) * 8 + ql) * 32 + ((kk >> 2) & 1) * 16 + (kk >> 3) * 4]) = pk;
   }
   __syncthreads();
@@ -283,26 +300,28 @@ __device__ __forceinline__ void pos_logits_tiled_body(const float4* __restrict__
   }
 }
 
+template <typename HT>
 __global__ __launch_bounds__(256) void pos_logits_tiled_kernel(const float4* __restrict__ rois_q,
                                                                const float4* __restrict__ rois_k,
                                                                const float* __restrict__ wgt,
                                                                const float* __restrict__ bg,
                                                                const float* __restrict__ dim_mat,
-                                                               bf16_t* __restrict__ out_t, int Nq, int Nk) {
-  pos_logits_tiled_body(rois_q, rois_k, wgt, bg, dim_mat, out_t, Nq, Nk);
+                                                               unsigned short* __restrict__ out_t, int Nq, int Nk) {
+  pos_logits_tiled_body<HT>(rois_q, rois_k, wgt, bg, dim_mat, out_t, Nq, Nk);
 }
 
 // the same for several (query boxes, key boxes) problems in one launch: blockIdx.z = problem
 constexpr int POS_MAXB = 20;          // problems per launch: the key frames of the bench's 20-key-frame step-batch in ONE launch
 struct PosBatch {
-  struct { const float4* rq; const float4* rk; bf16_t* out; int Nq, Nk; } p[POS_MAXB];
+  struct { const float4* rq; const float4* rk; unsigned short* out; int Nq, Nk; } p[POS_MAXB];
 };
+template <typename HT>
 __global__ __launch_bounds__(256) void pos_logits_tiled_batched_kernel(PosBatch b, const float* __restrict__ wgt,
                                                                        const float* __restrict__ bg,
                                                                        const float* __restrict__ dim_mat) {
   const auto& q = b.p[blockIdx.z];
   if ((int)blockIdx.x * 64 >= q.Nk || (int)blockIdx.y * 8 >= q.Nq) return;
-  pos_logits_tiled_body(q.rq, q.rk, wgt, bg, dim_mat, q.out, q.Nq, q.Nk);
+  pos_logits_tiled_body<HT>(q.rq, q.rk, wgt, bg, dim_mat, q.out, q.Nq, q.Nk);
 }
 
 // ----------------------------------------------------------------------------------------------- attention
@@ -314,6 +333,7 @@ template <> struct AttnCfg<bf16_t> {
   static constexpr int NPV = 2;      // P A-vectors per 32-key tile
   static constexpr int NLD = 1;      // 16-B loads per thread per tile (K and V each), 256 threads
 };
+template <> struct AttnCfg<f16_t> : AttnCfg<bf16_t> {};      // IEEE half (round 6): the bf16 geometry
 template <> struct AttnCfg<float> {
   static constexpr int KROW = 272;   // 256 B + 16
   static constexpr int VROW = 144;   // 128 B + 16
@@ -328,6 +348,27 @@ template <> struct Mma32<bf16_t> {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
                                                   0, 0, 0);
   }
+};
+template <> struct Mma32<f16_t> {
+  __device__ static __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+  }
+};
+// sum of a packed, ROUNDED pair of P values (one dot-product instruction against (1, 1)); see the softmax below
+template <typename T> struct PairSum;
+template <> struct PairSum<bf16_t> {
+  __device__ static __forceinline__ float run(unsigned pk, float acc) {
+    typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_v, pk), __builtin_bit_cast(bf16x2_v, 0x3f803f80u), acc, false);
+  }
+};
+template <> struct PairSum<f16_t> {
+  __device__ static __forceinline__ float run(unsigned pk, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, pk), __builtin_bit_cast(f16x2_t, 0x3c003c00u), acc, false);
+  }
+};
+template <> struct PairSum<float> {
+  __device__ static __forceinline__ float run(unsigned, float acc) { return acc; }
 };
 template <> struct Mma32<float> {
   __device__ static __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b) {
@@ -348,7 +389,7 @@ struct AttnParams {
   const void* K2;             // [Nk-N1][ldk]  keys N1 .. Nk-1 (second segment; unused when N1 == Nk)
   const void* Vt2;            // [G*64][ldv2]  keys N1 .. Nk-1; its columns may start at any 2-byte (bf16) / 4-byte (f32) address
   const float* pos;           // [G][Nq][ldp] additive logits or null
-  const bf16_t* pos_t;        // or: bf16 logits in tile order [G][ceil(Nk/32)][Nq][32] (see pos_logits_mfma_kernel)
+  const unsigned short* pos_t;   // or: 16-bit (T) logits in tile order [G][ceil(Nk/32)][Nq][32] (see pos_logits_mfma_kernel)
   const void* resid;          // [Nq][ldr] residual (feats_cur) or null
   const float* bias_v;        // [G*64] or null
   void* out;                  // [Nq][ldo]
@@ -526,7 +567,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
       if (POS_TILED) {
         const unsigned short* pb = reinterpret_cast<const unsigned short*>(&pr[0]);   // element 4 rq + e
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pe[e] = bf16_to_f32(pb[4 * rq + e]);
+        for (int e = 0; e < 4; ++e) pe[e] = Half16<typename std::conditional<sizeof(T) == 2, T, bf16_t>::type>::one(pb[4 * rq + e]);
       } else if (pos_row) {
         const float4 pw = *reinterpret_cast<const float4*>(pos_row + k0 + 8 * rq + 4 * h2);
         pe[0] = pw.x; pe[1] = pw.y; pe[2] = pw.z; pe[3] = pw.w;
@@ -564,13 +605,11 @@ __device__ __forceinline__ void attn_body(const AttnParams& p, const int split) 
       // out = sum p'_j v_j / sum p'_j is an exact weighted mean of the v_j with slightly perturbed weights.  With the sum
       // over the unrounded p_j the rounding errors times the COMMON part of the values (bias + the mean of the post-ReLU
       // features) did not cancel: 2.6e-4 of the 6.5e-4 median logit error of the bf16 head (tools/head_precision_cpu.py).
-      typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
-      const unsigned ones = 0x3f803f80u;       // (1.0, 1.0) in bf16: v_dot2c_f32_bf16 sums a rounded pair in one instruction
+      // (PairSum: v_dot2c_f32_bf16 / v_dot2_f32_f16 against (1.0, 1.0) sums a rounded pair in one instruction)
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
-        pk[d] = pack_bf16x2(s[2 * d], s[2 * d + 1]);
-        psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_v, pk[d]), __builtin_bit_cast(bf16x2_v, ones), psum,
-                                               false);
+        pk[d] = Half16<typename std::conditional<sizeof(T) == 2, T, bf16_t>::type>::pack2(s[2 * d], s[2 * d + 1]);
+        psum = PairSum<T>::run(pk[d], psum);
       }
     } else {
 #pragma unroll
@@ -792,24 +831,40 @@ extern "C" int mega_position_logits(const float* rois_q, const float* rois_k, co
   return mega_check_launch();
 }
 
-extern "C" int mega_position_logits_tiled(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
-                                          const float* dim_mat, void* out_bf16, int Nq, int Nk, void* stream) {
+static int position_logits_tiled_impl(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
+                                      const float* dim_mat, void* out_bf16, int Nq, int Nk, int dtype, void* stream) {
   mega_clear_error();
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
   if (Nq == 0 || Nk == 0) return MEGA_OK;
   if (!rois_q || !rois_k || !wg_t || !bg || !dim_mat || !out_bf16 || Nq < 0 || Nk < 0 ||
       (reinterpret_cast<size_t>(out_bf16) & 15))
     return MEGA_ERR_ARG;
   static const bool legacy = getenv("MEGA_POS_LEGACY") != nullptr;     // A/B switch (experiments)
-  if (legacy) {
+  if (dtype == MEGA_F16) {
+    dim3 grid(cdiv(Nk, 64), cdiv(Nq, 8));
+    hipLaunchKernelGGL(pos_logits_tiled_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
+                       (const float4*)rois_k, wg_t, bg, dim_mat, (unsigned short*)out_bf16, Nq, Nk);
+  } else if (legacy) {
     dim3 grid(cdiv(Nk, 256), Nq);
     hipLaunchKernelGGL(pos_logits_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
                        (const float4*)rois_k, wg_t, bg, dim_mat, (float*)nullptr, (bf16_t*)out_bf16, Nq, Nk, 0);
   } else {
     dim3 grid(cdiv(Nk, 64), cdiv(Nq, 8));
-    hipLaunchKernelGGL(pos_logits_tiled_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
-                       (const float4*)rois_k, wg_t, bg, dim_mat, (bf16_t*)out_bf16, Nq, Nk);
+    hipLaunchKernelGGL(pos_logits_tiled_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)rois_q,
+                       (const float4*)rois_k, wg_t, bg, dim_mat, (unsigned short*)out_bf16, Nq, Nk);
   }
   return mega_check_launch();
+}
+
+extern "C" int mega_position_logits_tiled(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
+                                          const float* dim_mat, void* out_bf16, int Nq, int Nk, void* stream) {
+  return position_logits_tiled_impl(rois_q, rois_k, wg_t, bg, dim_mat, out_bf16, Nq, Nk, MEGA_BF16, stream);
+}
+
+// round 6: the tile-ordered logits in the head's 16-bit operand type (dtype = MEGA_BF16 / MEGA_F16)
+extern "C" int mega_position_logits_tiled_dt(const float* rois_q, const float* rois_k, const float* wg_t, const float* bg,
+                                             const float* dim_mat, void* out16, int Nq, int Nk, int dtype, void* stream) {
+  return position_logits_tiled_impl(rois_q, rois_k, wg_t, bg, dim_mat, out16, Nq, Nk, dtype, stream);
 }
 
 // Number of key-range splits the attention core uses for (Nq, Nk) -- a function of the problem alone, so a problem
@@ -847,11 +902,11 @@ static int attn_fill(AttnParams& p, const void* q, int ldq, const void* k, int l
   else if (!k2 || !vt2 || ldv2 < Nk - nk1) return MEGA_ERR_ARG;
   p.N1 = nk1; p.K2 = k2; p.Vt2 = vt2; p.ldv2 = ldv2;
   p.io_f32 = (io_f32 != 0 && dtype != MEGA_F32) ? 1 : 0;   // (f32 mode: T is float already)
-  const int ve = dtype == MEGA_BF16 ? 8 : 4;
+  const int ve = dtype != MEGA_F32 ? 8 : 4;
   if (ldq % ve || ldk % ve || ldv % ve || (pos && (ldp % 32 || ldp < Nk))) return MEGA_ERR_ARG;
   if (ldv < (nk1 == Nk ? ((Nk + ve - 1) / ve) * ve : nk1)) return MEGA_ERR_ARG;
-  if (pos_tiled && (pos || dtype != MEGA_BF16 || (reinterpret_cast<size_t>(pos_tiled) & 15))) return MEGA_ERR_ARG;
-  p.pos_t = (const bf16_t*)pos_tiled;
+  if (pos_tiled && (pos || dtype == MEGA_F32 || (reinterpret_cast<size_t>(pos_tiled) & 15))) return MEGA_ERR_ARG;
+  p.pos_t = (const unsigned short*)pos_tiled;
   p.Q = q; p.ldq = ldq; p.K = k; p.ldk = ldk; p.Vt = vt; p.ldv = ldv; p.pos = pos; p.ldp = ldp;
   p.resid = resid; p.ldr = ldr; p.bias_v = bias_v; p.out = out; p.ldo = ldo; p.Nq = Nq; p.Nk = Nk; p.G = groups;
   p.scale = scale;
@@ -885,12 +940,15 @@ static int relation_attention_impl(const void* q, int ldq, const void* k, int ld
   dim3 grid(cdiv(Nq, 128), groups, nsplit);
   if (dtype == MEGA_BF16 && pos_tiled) hipLaunchKernelGGL((attn_kernel<bf16_t, true>), grid, dim3(256), 0, st, p);
   else if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, false>), grid, dim3(256), 0, st, p);
+  else if (dtype == MEGA_F16 && pos_tiled) hipLaunchKernelGGL((attn_kernel<f16_t, true>), grid, dim3(256), 0, st, p);
+  else if (dtype == MEGA_F16) hipLaunchKernelGGL((attn_kernel<f16_t, false>), grid, dim3(256), 0, st, p);
   else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_kernel<float, false>), grid, dim3(256), 0, st, p);
   else return MEGA_ERR_ARG;
   if (nsplit > 1) {
     const size_t total = (size_t)Nq * groups * 64;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_combine_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, p);
+    else if (dtype == MEGA_F16) hipLaunchKernelGGL((attn_combine_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_combine_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
   }
   return mega_check_launch();
@@ -953,6 +1011,8 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
   } while (0)
   if (dtype == MEGA_BF16 && tiled) MEGA_ATTN_LAUNCH(bf16_t, true);
   else if (dtype == MEGA_BF16) MEGA_ATTN_LAUNCH(bf16_t, false);
+  else if (dtype == MEGA_F16 && tiled) MEGA_ATTN_LAUNCH(f16_t, true);
+  else if (dtype == MEGA_F16) MEGA_ATTN_LAUNCH(f16_t, false);
   else if (dtype == MEGA_F32 && any_seg) hipLaunchKernelGGL((attn_batched_kernel<float, false, 2, true>), grid, dim3(256), 0, st, b);
   else if (dtype == MEGA_F32) hipLaunchKernelGGL((attn_batched_kernel<float, false, 2, false>), grid, dim3(256), 0, st, b);
 #undef MEGA_ATTN_LAUNCH      // (f32: 192 / 211 VGPRs, two blocks per CU either way; a 3-block bound would spill)
@@ -960,6 +1020,7 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
   if (any_split) {
     const int blocks = (int)((max_total + 255) / 256 > 4096 ? 4096 : (max_total + 255) / 256);
     if (dtype == MEGA_BF16) hipLaunchKernelGGL((attn_combine_batched_kernel<bf16_t>), dim3(blocks, n), dim3(256), 0, st, b);
+    else if (dtype == MEGA_F16) hipLaunchKernelGGL((attn_combine_batched_kernel<f16_t>), dim3(blocks, n), dim3(256), 0, st, b);
     else hipLaunchKernelGGL((attn_combine_batched_kernel<float>), dim3(blocks, n), dim3(256), 0, st, b);
   }
   return mega_check_launch();
@@ -967,9 +1028,10 @@ extern "C" int mega_relation_attention_batched(const void* descs, int n, int gro
 
 struct MegaPosDescC { const float* rois_q; const float* rois_k; void* out_bf16; int Nq, Nk; };
 
-extern "C" int mega_position_logits_tiled_batched(const void* descs, int n, const float* wg_t, const float* bg,
-                                                  const float* dim_mat, void* stream) {
+static int position_logits_tiled_batched_impl(const void* descs, int n, const float* wg_t, const float* bg,
+                                              const float* dim_mat, int dtype, void* stream) {
   mega_clear_error();
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
   if (n == 0) return MEGA_OK;
   if (!descs || n < 0 || n > POS_MAXB || !wg_t || !bg || !dim_mat) return MEGA_ERR_ARG;
   const MegaPosDescC* d = (const MegaPosDescC*)descs;
@@ -979,14 +1041,25 @@ extern "C" int mega_position_logits_tiled_batched(const void* descs, int n, cons
     if (!d[i].rois_q || !d[i].rois_k || !d[i].out_bf16 || d[i].Nq <= 0 || d[i].Nk <= 0 ||
         (reinterpret_cast<size_t>(d[i].out_bf16) & 15))
       return MEGA_ERR_ARG;
-    b.p[i].rq = (const float4*)d[i].rois_q; b.p[i].rk = (const float4*)d[i].rois_k; b.p[i].out = (bf16_t*)d[i].out_bf16;
+    b.p[i].rq = (const float4*)d[i].rois_q; b.p[i].rk = (const float4*)d[i].rois_k; b.p[i].out = (unsigned short*)d[i].out_bf16;
     b.p[i].Nq = d[i].Nq; b.p[i].Nk = d[i].Nk;
     max_q = d[i].Nq > max_q ? d[i].Nq : max_q;
     max_k = d[i].Nk > max_k ? d[i].Nk : max_k;
   }
   dim3 grid(cdiv(max_k, 64), cdiv(max_q, 8), n);
-  hipLaunchKernelGGL(pos_logits_tiled_batched_kernel, grid, dim3(256), 0, (hipStream_t)stream, b, wg_t, bg, dim_mat);
+  if (dtype == MEGA_F16) hipLaunchKernelGGL(pos_logits_tiled_batched_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, b, wg_t, bg, dim_mat);
+  else hipLaunchKernelGGL(pos_logits_tiled_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, b, wg_t, bg, dim_mat);
   return mega_check_launch();
+}
+
+extern "C" int mega_position_logits_tiled_batched(const void* descs, int n, const float* wg_t, const float* bg,
+                                                  const float* dim_mat, void* stream) {
+  return position_logits_tiled_batched_impl(descs, n, wg_t, bg, dim_mat, MEGA_BF16, stream);
+}
+
+extern "C" int mega_position_logits_tiled_batched_dt(const void* descs, int n, const float* wg_t, const float* bg,
+                                                     const float* dim_mat, int dtype, void* stream) {
+  return position_logits_tiled_batched_impl(descs, n, wg_t, bg, dim_mat, dtype, stream);
 }
 
 extern "C" int mega_relation_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldv,
@@ -1003,4 +1076,13 @@ extern "C" int mega_relation_attention_tiled_pos(const void* q, int ldq, const v
                                                  float scale, void* ws, size_t ws_bytes, void* stream) {
   return relation_attention_impl(q, ldq, k, ldk, vt, ldv, nullptr, 0, pos_tiled_bf16, resid, ldr, bias_v, out, ldo, Nq,
                                  Nk, groups, scale, MEGA_BF16, ws, ws_bytes, stream);
+}
+
+extern "C" int mega_relation_attention_tiled_pos_dt(const void* q, int ldq, const void* k, int ldk, const void* vt,
+                                                    int ldv, const void* pos_tiled16, const void* resid, int ldr,
+                                                    const float* bias_v, void* out, int ldo, int Nq, int Nk, int groups,
+                                                    float scale, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  if (dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
+  return relation_attention_impl(q, ldq, k, ldk, vt, ldv, nullptr, 0, pos_tiled16, resid, ldr, bias_v, out, ldo, Nq,
+                                 Nk, groups, scale, dtype, ws, ws_bytes, stream);
 }

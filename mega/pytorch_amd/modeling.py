@@ -52,12 +52,15 @@ def stream_dtype(cfg):
 
 
 def head_dtype(cfg):
-    """operand dtype of the aggregation head's matrix-core GEMMs / attention (Wq, Wk, Wv projections, Q K^T, P V).  The
-    compute dtype, except in float16 mode: there cfg.HEAD_DTYPE chooses -- "bfloat16" (default): the FRAME STAGE runs in
-    fp16 and the head is the bf16 head (f32 activation stream, bf16 rounded copies into the projections / Q K^T / P V;
-    its own error, 1.0-1.8e-4 of the logits, is not what limits the mode: tools/fp16_prediction_cpu.py, the head in fp16
-    moves the logit error from 5.5e-4 to 5.4e-4); "float16": fp16 operands in the head too (CPU twins only: relation.hip has
-    no fp16 instantiation)."""
+    """operand dtype of the aggregation head's matrix-core GEMMs / attention (Wq, Wk, Wv projections, Q K^T, P V, the position
+    term).  The compute dtype, except in float16 mode: there cfg.HEAD_DTYPE chooses -- "bfloat16" (default): the FRAME STAGE
+    runs in fp16 and the head is the bf16 head (f32 activation stream, bf16 rounded copies into the projections / Q K^T / P V;
+    its own error, 1.0-1.8e-4 of the logits, is not what limits the fp16 frame stage: 5.5e-4 -> 5.4e-4 with the head in fp16);
+    "float16" (round 6): the head's kernels instantiated for IEEE-half operands (relation.hip: v_mfma_f32_32x32x16_f16 /
+    16x16x32_f16, fp16 tile-ordered position logits) -- the bf16 head's rate and bytes at an eighth of its rounding noise.
+    Its use is BEHIND ANOTHER MODE'S FRAME STAGE (engine.ClipEngine(frame_model=...)): split-precision frame stage + fp16 head
+    holds the parity mode's bounds (logit error median 1.3-2.5e-5, p99 <= 1.5e-4, 100 % of the proposals and detections:
+    tests/test_e2e_gpu.py::test_r101_600x1000_f16_head_vs_oracle) at the bf16 head's speed."""
     d = compute_dtype(cfg)
     if d == torch.float16:
         return _DTYPES[str(getattr(cfg, "HEAD_DTYPE", "bfloat16"))]

@@ -500,14 +500,15 @@ def position_logits(rois_q, rois_k, wg_t, bg, dim_mat, precise=True, tiled=False
     lib = _lib.load()
     Nq, Nk = rois_q.shape[0], rois_k.shape[0]
     if tiled:
-        assert not precise and tiled in (True, torch.bfloat16), "the tile-ordered position logits are bf16"
+        tdt = torch.bfloat16 if tiled is True else tiled      # the head's 16-bit operand type (bf16, or f16: round 6)
+        assert not precise and tdt in _HALF, "the tile-ordered position logits are bf16 / f16"
         kt = (Nk + 31) // 32
-        out = torch.empty((16, kt, Nq, 32), dtype=torch.bfloat16, device=rois_q.device)
+        out = torch.empty((16, kt, Nq, 32), dtype=tdt, device=rois_q.device)
         _tok = _pb("pos_logits", 2.0 * Nq * Nk * 1024, out.numel() * 2.0)
-        rc = lib.mega_position_logits_tiled(_ptr(rois_q.contiguous()), _ptr(rois_k.contiguous()), _ptr(wg_t), _ptr(bg),
-                                            _ptr(dim_mat), _ptr(out), Nq, Nk, _stream())
+        rc = lib.mega_position_logits_tiled_dt(_ptr(rois_q.contiguous()), _ptr(rois_k.contiguous()), _ptr(wg_t), _ptr(bg),
+                                               _ptr(dim_mat), _ptr(out), Nq, Nk, _DT[tdt], _stream())
         _pe(_tok)
-        _lib.check(rc, "mega_position_logits_tiled")
+        _lib.check(rc, "mega_position_logits_tiled_dt")
         return out
     ldp = (Nk + 31) // 32 * 32
     out = torch.empty((16, Nq, ldp), dtype=torch.float32, device=rois_q.device)
@@ -531,15 +532,15 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     out = torch.empty((Nq, groups * 64), dtype=q.dtype, device=q.device)
     nb = lib.mega_relation_attention_workspace_bytes(Nq, Nk, groups)
     ws = _ws(nb, q.device) if nb else None
-    _tok = _pb("attention_" + ("bf16" if q.dtype == torch.bfloat16 else "f32"), 4.0 * Nq * Nk * 64 * groups, (q.numel() + k.numel() + vt.numel() + out.numel()) * q.element_size() + (0 if pos is None else pos.numel() * pos.element_size()))
-    if pos is not None and pos.dtype == torch.bfloat16:       # tile-ordered bf16 logits (position_logits(tiled=True))
-        assert q.dtype == torch.bfloat16 and pos.is_contiguous() and tuple(pos.shape) == (groups, (Nk + 31) // 32, Nq, 32)
-        rc = lib.mega_relation_attention_tiled_pos(_ptr(q), q.shape[1], _ptr(k), k.shape[1], _ptr(vt), vt.shape[1],
-                                                   _ptr(pos), _ptr(resid), 0 if resid is None else resid.shape[1],
-                                                   _ptr(bias_v), _ptr(out), groups * 64, Nq, Nk, groups,
-                                                   1.0 / math.sqrt(64.0), _ptr(ws), nb, _stream())
+    _tok = _pb("attention_" + _ATT_NAME.get(q.dtype, "f32"), 4.0 * Nq * Nk * 64 * groups, (q.numel() + k.numel() + vt.numel() + out.numel()) * q.element_size() + (0 if pos is None else pos.numel() * pos.element_size()))
+    if pos is not None and pos.dtype in _HALF:       # tile-ordered 16-bit logits (position_logits(tiled=dtype))
+        assert q.dtype == pos.dtype and pos.is_contiguous() and tuple(pos.shape) == (groups, (Nk + 31) // 32, Nq, 32)
+        rc = lib.mega_relation_attention_tiled_pos_dt(_ptr(q), q.shape[1], _ptr(k), k.shape[1], _ptr(vt), vt.shape[1],
+                                                      _ptr(pos), _ptr(resid), 0 if resid is None else resid.shape[1],
+                                                      _ptr(bias_v), _ptr(out), groups * 64, Nq, Nk, groups,
+                                                      1.0 / math.sqrt(64.0), _DT[q.dtype], _ptr(ws), nb, _stream())
         _pe(_tok)
-        _lib.check(rc, "mega_relation_attention_tiled_pos")
+        _lib.check(rc, "mega_relation_attention_tiled_pos_dt")
         return out
     rc = lib.mega_relation_attention(_ptr(q), q.shape[1], _ptr(k), k.shape[1], _ptr(vt), vt.shape[1], _ptr(pos),
                                      0 if pos is None else pos.shape[2], _ptr(resid),
@@ -550,6 +551,7 @@ def relation_attention(q, k, vt, Nk, pos=None, resid=None, bias_v=None, groups=1
     return out
 
 
+_ATT_NAME = {torch.bfloat16: "bf16", torch.float16: "f16"}      # attention kernel family names (bench.py's per-family roofline)
 _MAX_BATCHED = 20    # problems per batched position-logit / attention launch (POS_MAXB / ATTN_MAXB in relation.hip)
 
 
@@ -577,14 +579,15 @@ def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, t
     ONE launch per 20 problems, the f32 forms fall back to one call per problem."""
     if not tiled:
         return [position_logits(a, b, wg_t, bg, dim_mat, precise=precise, tiled=False) for a, b in zip(rois_qs, rois_ks)]
-    assert tiled in (True, torch.bfloat16), "the tile-ordered position logits are bf16"
+    tdt = torch.bfloat16 if tiled is True else tiled
+    assert tdt in _HALF, "the tile-ordered position logits are bf16 / f16"
     _gpu(wg_t, bg, dim_mat, *rois_qs, *rois_ks)
     lib = _lib.load()
     outs, keep = [], []
     for a, b in zip(rois_qs, rois_ks):
         a, b = a.contiguous(), b.contiguous()
         keep.append((a, b))
-        outs.append(torch.empty((16, (b.shape[0] + 31) // 32, a.shape[0], 32), dtype=torch.bfloat16, device=a.device))
+        outs.append(torch.empty((16, (b.shape[0] + 31) // 32, a.shape[0], 32), dtype=tdt, device=a.device))
     per = _even_chunks(len(outs), _MAX_BATCHED)
     for o in range(0, len(outs), per):
         n = min(per, len(outs) - o)
@@ -595,9 +598,9 @@ def position_logits_batched(rois_qs, rois_ks, wg_t, bg, dim_mat, precise=True, t
             arr[i].Nq, arr[i].Nk = a.shape[0], b.shape[0]
         _tok = _pb("pos_logits", sum(2.0 * arr[i].Nq * arr[i].Nk * 1024 for i in range(n)),
                    sum(outs[o + i].numel() * 2.0 for i in range(n)))
-        rc = lib.mega_position_logits_tiled_batched(ctypes.addressof(arr), n, _ptr(wg_t), _ptr(bg), _ptr(dim_mat), _stream())
+        rc = lib.mega_position_logits_tiled_batched_dt(ctypes.addressof(arr), n, _ptr(wg_t), _ptr(bg), _ptr(dim_mat), _DT[tdt], _stream())
         _pe(_tok)
-        _lib.check(rc, "mega_position_logits_tiled_batched")
+        _lib.check(rc, "mega_position_logits_tiled_batched_dt")
     return outs
 
 
@@ -662,8 +665,8 @@ def relation_attention_batched(items, groups=16):
             d.resid, d.ldr = _ptr(resid), 0 if resid is None else resid.stride(0)
             d.io_f32 = io_f32
             d.bias_v = _ptr(it.get("bias_v"))
-            if pos is not None and pos.dtype == torch.bfloat16:
-                assert pos.is_contiguous() and tuple(pos.shape) == (groups, (Nk + 31) // 32, Nq, 32)
+            if pos is not None and pos.dtype in _HALF:
+                assert pos.dtype == dt and pos.is_contiguous() and tuple(pos.shape) == (groups, (Nk + 31) // 32, Nq, 32)
                 d.pos_tiled = pos.data_ptr()
             elif pos is not None:
                 d.pos, d.ldp = pos.data_ptr(), pos.shape[2]
@@ -672,7 +675,7 @@ def relation_attention_batched(items, groups=16):
             fl += 4.0 * Nq * Nk * 64 * groups
             by += (q.numel() + k.numel() + vt.numel()) * q.element_size() + outs[o + i].numel() * outs[o + i].element_size() + \
                 (0 if pos is None else pos.numel() * pos.element_size())
-        _tok = _pb("attention_" + ("bf16" if dt == torch.bfloat16 else "f32"), fl, by)
+        _tok = _pb("attention_" + _ATT_NAME.get(dt, "f32"), fl, by)
         rc = lib.mega_relation_attention_batched(ctypes.addressof(arr), n, groups, 1.0 / math.sqrt(64.0), _DT[dt], _stream())
         _pe(_tok)
         _lib.check(rc, "mega_relation_attention_batched")

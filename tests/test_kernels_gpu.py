@@ -562,7 +562,7 @@ def test_relation_attention_tiled_pos(dev, shape):
 # The exact shapes of the benchmarked configuration (MEGA R-101, 600x1000, 20-frame frame-stage batches):
 # SURVEY.md Appendix A attention call list, the first FC of the box head, the RPN conv through its natural dispatch.
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(675, 3750, True), (1875, 750, False), (300, 750, True)])
 def test_relation_attention_hot_shapes(dev, dtype, shape):
     """local stage 0 (675 x 3750 with the position term: 1875 window rows + 1875 memory rows), the global stage over
@@ -591,7 +591,10 @@ def test_relation_attention_hot_shapes(dev, dtype, shape):
     out = relation_attention_forward(wts, x.to(dev), r.to(dev), bq.to(dev) if use_pos else None,
                                      bk.to(dev) if use_pos else None, residual=True)
     err = _relerr(out.float().cpu(), ref)
-    assert err < (2e-4 if dtype == torch.float32 else 3e-2), "attention %s %s relerr %.3g" % (shape, dtype, err)
+    # (float16, round 6: the same kernels on IEEE-half operands -- 11 significant bits: an eighth of the bf16 bound)
+    bound = {torch.float32: 2e-4, torch.bfloat16: 3e-2, torch.float16: 4e-3}[dtype]
+    print("attention %s %s relerr %.3g" % (shape, dtype, err))
+    assert err < bound, "attention %s %s relerr %.3g" % (shape, dtype, err)
     # the engine's form of the same call: the second half of the keys arrives as cached memory projections
     if use_pos and Nk == 3750:
         h = Nk // 2
@@ -600,7 +603,7 @@ def test_relation_attention_hot_shapes(dev, dtype, shape):
         out2 = relation_attention_forward(wts, x.to(dev), r[:h].to(dev), bq.to(dev), bk.to(dev), residual=True,
                                           mem_kv=(k1, vt1[:, :Nk - h].contiguous()))
         err2 = _relerr(out2.float().cpu(), ref)
-        assert err2 < (2e-4 if dtype == torch.float32 else 3e-2), "attention with cached memory K/V: relerr %.3g" % err2
+        assert err2 < bound, "attention with cached memory K/V: relerr %.3g" % err2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
