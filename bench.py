@@ -335,6 +335,74 @@ F16X2_PARITY = ("against the f32 oracle, R-101 600x1000, 28 key frames incl. the
                 "profiles/r06_fp16_prediction.txt)")
 
 
+def leg_roofline(runner, clip, T, gfor, pos, spb, mode):
+    """The headline's `roofline` block for a parity-mode leg (VERDICT r05 item 6 iii): one instrumented step-batch of the leg's
+    own engine -- kernel by kernel, no graph replays, one stream, a HIP event pair around every launch (ops.Profiler) -- after
+    one untimed eager batch; dominant symbol = the matrix-core GEMM family with the largest share of GPU time.  FLOPs are the
+    MATRIX-CORE work of a launch (a split-precision launch contracts 3 K, a two-pass fp16 launch 2 K); `traffic` = HBM bytes
+    per launch of that symbol from the newest committed PMC summary of the mode (null when there is none)."""
+    from mega.pytorch_amd import ops
+    try:
+        if pos + 2 * spb + 13 >= T:
+            return None
+        ug, us, ov = runner.use_graphs, runner.use_static, runner.overlap
+        runner.use_graphs, runner.use_static, runner.overlap = False, False, False
+        runner.run(clip, T, gfor, first=pos, last=pos + spb)
+        torch.cuda.synchronize()
+        p = ops.Profiler()
+        ops.set_profiler(p)
+        runner.run(clip, T, gfor, first=pos + spb, last=pos + 2 * spb)
+        summ = p.summary()
+        ops.set_profiler(None)
+        runner.use_graphs, runner.use_static, runner.overlap = ug, us, ov
+        tot_ms = sum(v["ms"] for v in summ.values())
+        mm = {k: v for k, v in summ.items() if k.startswith("igemm") and not k.startswith("igemm8s_") and v["ms"] > 0}
+        if not mm or tot_ms <= 0:
+            return None
+        dom = max(mm, key=lambda k: mm[k]["ms"])
+        d = mm[dom]
+        peak = 157.3 if mode == "float32" else 2500.0
+        ach = d["flops"] / (d["ms"] * 1e9)
+        allg = {k: v for k, v in summ.items() if k.startswith("igemm")}
+        sym = {"igemm8_sp_x3": "igemm8_kernel<*, *, *, 0, 1, unsigned short> (split-precision planes, 3 K contraction)",
+               "igemm8_sp_h2": "igemm8_kernel<*, *, *, 0, 1, _Float16> (fp16 [hi | lo] planes, 2 K contraction)",
+               "igemm8_sp_hi": "igemm8_kernel<*, *, *, 0, 1, unsigned short> (hi plane only)"}.get(dom, dom)
+        traffic = src = None
+        tagf = {"bf16x3": "r06_x3", "float32": "r06_f32", "float16": "r06_f16", "f16x2": "r06_f16x2"}.get(mode)
+        for cand in ([tagf] if tagf else []) + (["r05_x3"] if mode == "bf16x3" else []):
+            pmc = os.path.join(ROOT, "profiles", cand + "_pmc_summary.json")
+            if os.path.exists(pmc):
+                ks = json.load(open(pmc))["kernels"]
+                want = "igemm8_kernel" if dom.startswith("igemm8") else "igemm_kernel"
+
+                def is_sp(name):       # igemm8_kernel<OT, MF1, CLS, ABL, SP[, HT]>
+                    a = [x.strip() for x in name[name.index("<") + 1:name.rindex(">")].split(",")] if "<" in name else []
+                    return len(a) >= 5 and a[4] == "1"
+                rows = [v for name, v in ks.items() if name.startswith(want) and (not dom.startswith("igemm8") or is_sp(name) == dom.startswith("igemm8_sp"))]
+                if rows:
+                    k = max(rows, key=lambda v: v.get("launches", 0) * v.get("hbm_bytes_per_launch_corrected", 0))
+                    traffic, src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/%s_pmc_summary.json (the symbol of this family with the most HBM bytes)" % cand
+                    break
+        return {"bound": "mfma", "kernel": sym, "family": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
+                "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2), "flops_per_launch": round(d["flops"] / d["launches"], 0),
+                "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 0),
+                "recomputed_from": {"launches": d["launches"], "sum_gflop": round(d["flops"] / 1e9, 2), "sum_us": round(1e3 * d["ms"], 1),
+                                    "key_frames": spb, "how": "achieved = sum_gflop / sum_us (HIP events around every launch of this "
+                                                              "family in one instrumented step-batch of this leg's engine)"},
+                "share_of_gpu_time": round(d["ms"] / tot_ms, 3),
+                "all_igemm_variants": {"achieved": round(sum(v["flops"] for v in allg.values()) / (sum(v["ms"] for v in allg.values()) * 1e9), 2),
+                                       "share_of_gpu_time": round(sum(v["ms"] for v in allg.values()) / tot_ms, 3)},
+                "kernel_families_ms_per_key_frame": {k: round(v["ms"] / spb, 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
+    except Exception as e:  # noqa: BLE001  (an extra must never cost the leg)
+        try:
+            ops.set_profiler(None)
+        except Exception:  # noqa: BLE001
+            pass
+        log("leg roofline skipped: %r" % (e,))
+        return None
+
+
 def f32_parity_leg(args, device, clip, gfor, T, spb, mode="float32", head_mode=None):
     """mode "bf16x3": the split-precision parity mode (cfg.F32_CONV = "bf16x3": the frame stage's convs / fc0 as bf16
     matrix-core GEMMs over [hi | lo | hi] . [Wh | Wh | Wl], f32 accumulation; aggregation head exact f32) -- pinned by
@@ -388,6 +456,7 @@ def f32_parity_leg(args, device, clip, gfor, T, spb, mode="float32", head_mode=N
     el = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     fps = spb / el
     x3 = mode == "bf16x3"
+    leg_roof = leg_roofline(runner, clip, T, gfor, pos, spb, mode) if not args.no_roofline else None
     if mode in ("float16", "f16x2"):
         out = {"dtype": ("f16 (frame stage on IEEE-half operands: v_mfma_f32_32x32x16_f16, 11 significant bits at the bf16 MFMA rate "
                          "and bytes; f32 accumulation; the head is the bf16 head on an f32 activation stream)") if mode == "float16" else
@@ -402,6 +471,7 @@ def f32_parity_leg(args, device, clip, gfor, T, spb, mode="float32", head_mode=N
                "parity": F16_PARITY if mode == "float16" else F16X2_PARITY}
         if mode == "f16x2":
             out["frac_of_2500TF_at_2x_flops"] = round(2 * ALGO_GFLOP_PER_FRAME * 1e9 * fps / 2500e12, 4) if args.arch == "R-101" else None
+        out["roofline"] = leg_roof
         del runner, model, frame_model
         torch.cuda.empty_cache()
         return out
@@ -427,6 +497,7 @@ def f32_parity_leg(args, device, clip, gfor, T, spb, mode="float32", head_mode=N
                      if x3 else
                      ("logits within 1e-3 of the reference / oracle, identical detections (tests/test_e2e_gpu.py: "
                       "test_r101_600x1000_f32_vs_oracle, test_f32_long_clip_vs_reference_fixture)")}
+    out["roofline"] = leg_roof
     del runner, model, frame_model
     torch.cuda.empty_cache()
     return out

@@ -5,7 +5,7 @@
 # 4. rocprofv3 kernel stats of the bench   5. rocprofv3 PMC passes, ONE counter per pass, kernel trace only
 #    (MI355X_MICROARCH.md HBM section): FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE
 #    -> reduce with tools/pmc_summary.py (per kernel family: HBM bytes per launch, MFMA-busy fraction)
-tag=${1:-r05}
+tag=${1:-r06}
 quick=${2:-}
 out=gpurun_out/$tag
 mkdir -p $out
@@ -24,8 +24,16 @@ pmcargs="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ${EXTRA_PMC:-}; do
   (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/$out/pmc_$c -o pmc -- python $root/bench.py $pmcargs > $root/$out/pmc_$c.json 2> $root/$out/pmc_$c.err); ls -la $out/pmc_$c | tail -1
 done
+# round 6: the other modes as the PROFILED configuration (kernel stats + the same four PMC passes): the split-precision parity
+# mode, the fp16 mode, the fp16 two-pass mode  ->  <mode>_prof/, <mode>_pmc_<counter>/ (reduced with tools/pmc_summary.py)
+for mode in bf16x3 float16 f16x2; do
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/${mode}_prof -o bench -- python $root/bench.py --dtype $mode --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-h2d-leg --min-seconds 1 > $root/$out/${mode}_bench_under_rocprof.json 2> $root/$out/${mode}_prof.err); ls $out/${mode}_prof | head -2
+  for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+    (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/$out/${mode}_pmc_$c -o pmc -- python $root/bench.py --dtype $mode $pmcargs > $root/$out/${mode}_pmc_$c.json 2> $root/$out/${mode}_pmc_$c.err); ls -la $out/${mode}_pmc_$c | tail -1
+  done
+done
 # keep only what the reducers need (the kernel-trace CSVs are large)
-rm -f $out/pmc_*/pmc_kernel_trace.csv $out/prof/bench_kernel_trace.csv
+rm -f $out/pmc_*/pmc_kernel_trace.csv $out/prof/bench_kernel_trace.csv $out/*_pmc_*/pmc_kernel_trace.csv $out/*_prof/bench_kernel_trace.csv
 # the RCCL collectives of the sharded aggregation on ONE GPU (world 1, every key frame owned by rank 0)
 leg="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-f32-leg --no-h2d-leg"
 MEGA_FORCE_SHARDED=1 timeout 300 python bench.py $leg > $out/bench_n1_forced_sharded.json 2> $out/bench_n1_forced_sharded.err
@@ -33,6 +41,12 @@ timeout 300 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-roofli
 # round 5's modes as the main configuration (kernel families of each in the line)
 timeout 300 python bench.py --steps 20 --warmup 5 --dtype bf16x3 --no-cpu-baseline --no-f32-leg --no-h2d-leg --min-seconds 2 > $out/bench_n1_bf16x3.json 2> $out/bench_n1_bf16x3.err
 timeout 300 python bench.py --steps 20 --warmup 5 --dtype wide --no-cpu-baseline --no-f32-leg --no-h2d-leg --min-seconds 2 > $out/bench_n1_wide_trunk.json 2> $out/bench_n1_wide_trunk.err
+# round 6's modes as the main configuration
+timeout 300 python bench.py --steps 20 --warmup 5 --dtype float16 --no-cpu-baseline --no-f32-leg --no-h2d-leg --min-seconds 2 > $out/bench_n1_float16.json 2> $out/bench_n1_float16.err
+timeout 300 python bench.py --steps 20 --warmup 5 --dtype f16x2 --no-cpu-baseline --no-f32-leg --no-h2d-leg --min-seconds 2 > $out/bench_n1_f16x2.json 2> $out/bench_n1_f16x2.err
+# round 6's opt-in GEMM kernels end to end (same box): igemm2 on the K <= 128 streaming layers, on the whole streaming class
+MEGA_IGEMM2=1 timeout 300 python bench.py $leg > $out/bench_n1_igemm2_k128.json 2> $out/bench_n1_igemm2_k128.err
+MEGA_IGEMM2=2 timeout 300 python bench.py $leg > $out/bench_n1_igemm2_streaming.json 2> $out/bench_n1_igemm2_streaming.err
 # A/B legs on the same box: the round-3 head (bf16 activation stream), the unfused layer1 blocks, two batches per block
 timeout 300 python bench.py $leg --head-stream bfloat16 > $out/bench_n1_bf16_head_stream.json 2> $out/bench_n1_bf16_head_stream.err
 MEGA_FUSE_BOTTLENECK=0 timeout 300 python bench.py $leg > $out/bench_n1_unfused_layer1.json 2> $out/bench_n1_unfused_layer1.err
@@ -46,4 +60,4 @@ timeout 120 python tools/gpu/bneck_bench.py > $out/bneck_bench.txt 2>&1; tail -5
 # the other BASELINE configurations
 for c in 1 2 5; do timeout 300 python tools/bench_configs.py --config $c > $out/config$c.json 2> $out/config$c.err; cut -c1-160 $out/config$c.json; done
 timeout 300 python tools/bench_configs.py --config 1 --dtype float32 --no-cpu-baseline > $out/config1_f32.json 2> $out/config1_f32.err; cut -c1-160 $out/config1_f32.json
-grep -E "ATTRIBUTION|^H |^F bf16|^B bf16|^W wide|^X bf16x3|^bf16x3 |CALIBRATED|calibrated f32|config [125]|cfg[15] |R-101 600x1000|roi_align bf16|bf16 key frame|graph aggregation:|common-mode|conv2d_sp x3|linear_sp" $out/pytest_gpu.log | cut -c1-460 > $out/pytest_prints.txt
+grep -E "ATTRIBUTION|^H |^F bf16|^B bf16|^W wide|^X bf16x3|^bf16x3 |^f16 |^f16x2 |^X3H |^F16H |^H2H |^attention |CALIBRATED|calibrated f32|config [125]|cfg[15] |R-101 600x1000|roi_align bf16|bf16 key frame|graph aggregation:|common-mode|conv2d_sp x3|linear_sp" $out/pytest_gpu.log | cut -c1-460 > $out/pytest_prints.txt
