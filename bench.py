@@ -335,6 +335,20 @@ F16X2_PARITY = ("against the f32 oracle, R-101 600x1000, 28 key frames incl. the
                 "profiles/r06_fp16_prediction.txt)")
 
 
+def igemm_symbol(famname):
+    """profiler family -> the rocprofv3 symbol of its launches"""
+    if famname.startswith("igemm8_sp"):
+        return "igemm8_kernel<*, *, *, 0, 1> (split-precision planes)"
+    parts = famname.split("_")
+    t_ = parts[2].split("x")
+    f32o = famname.endswith("_f32out")
+    et = {"bf16": "unsigned short", "f16": "_Float16"}.get(parts[1], "float")
+    if parts[0] in ("igemm8", "igemm8s"):      # <OT, MF1, CLS, ABL, SP, HT> (HT: the 16-bit operand type, round 6)
+        return "igemm8_kernel<%s, %d, %d, 0, 0, %s>" % ("float" if f32o else et, 2 if t_[0] == "256" else 1,
+                                                        1 if parts[0] == "igemm8s" else 0, et)
+    return "igemm_kernel<%s, %s, %s, %s>" % (et, "float" if (f32o or parts[1] == "f32") else et, t_[0], t_[1])
+
+
 def leg_roofline(runner, clip, T, gfor, pos, spb, mode):
     """The headline's `roofline` block for a parity-mode leg (VERDICT r05 item 6 iii): one instrumented step-batch of the leg's
     own engine -- kernel by kernel, no graph replays, one stream, a HIP event pair around every launch (ops.Profiler) -- after
@@ -366,7 +380,7 @@ def leg_roofline(runner, clip, T, gfor, pos, spb, mode):
         allg = {k: v for k, v in summ.items() if k.startswith("igemm")}
         sym = {"igemm8_sp_x3": "igemm8_kernel<*, *, *, 0, 1, unsigned short> (split-precision planes, 3 K contraction)",
                "igemm8_sp_h2": "igemm8_kernel<*, *, *, 0, 1, _Float16> (fp16 [hi | lo] planes, 2 K contraction)",
-               "igemm8_sp_hi": "igemm8_kernel<*, *, *, 0, 1, unsigned short> (hi plane only)"}.get(dom, dom)
+               "igemm8_sp_hi": "igemm8_kernel<*, *, *, 0, 1, unsigned short> (hi plane only)"}.get(dom) or igemm_symbol(dom)
         traffic = src = None
         tagf = {"bf16x3": "r06_x3", "float32": "r06_f32", "float16": "r06_f16", "f16x2": "r06_f16x2"}.get(mode)
         for cand in ([tagf] if tagf else []) + (["r05_x3"] if mode == "bf16x3" else []):
@@ -378,10 +392,14 @@ def leg_roofline(runner, clip, T, gfor, pos, spb, mode):
                 def is_sp(name):       # igemm8_kernel<OT, MF1, CLS, ABL, SP[, HT]>
                     a = [x.strip() for x in name[name.index("<") + 1:name.rindex(">")].split(",")] if "<" in name else []
                     return len(a) >= 5 and a[4] == "1"
-                rows = [v for name, v in ks.items() if name.startswith(want) and (not dom.startswith("igemm8") or is_sp(name) == dom.startswith("igemm8_sp"))]
+                if dom.startswith("igemm8_sp"):
+                    rows = [v for name, v in ks.items() if name.startswith(want) and is_sp(name)]
+                else:       # a plain family is ONE symbol: its own row
+                    w_ = sym.replace("unsigned short", "bf16").replace(" ", "")
+                    rows = [v for name, v in ks.items() if name.replace(" ", "").startswith(w_)]
                 if rows:
                     k = max(rows, key=lambda v: v.get("launches", 0) * v.get("hbm_bytes_per_launch_corrected", 0))
-                    traffic, src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/%s_pmc_summary.json (the symbol of this family with the most HBM bytes)" % cand
+                    traffic, src = round(k["hbm_bytes_per_launch_corrected"]), "profiles/%s_pmc_summary.json%s" % (cand, " (the symbol of this family with the most HBM bytes)" if dom.startswith("igemm8_sp") else "")
                     break
         return {"bound": "mfma", "kernel": sym, "family": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
@@ -747,18 +765,7 @@ def main():
         mm = {k: v for k, v in igemms.items() if not k.startswith("igemm8s_")}
         peak = 2500.0 if args.dtype in HALF_MODES + ("bf16x3",) else 157.3
 
-        def symbol_of(famname):
-            """profiler family -> the rocprofv3 symbol of its launches"""
-            if famname.startswith("igemm8_sp"):
-                return "igemm8_kernel<*, *, *, 0, 1> (split-precision planes)"
-            parts = famname.split("_")
-            t_ = parts[2].split("x")
-            f32o = famname.endswith("_f32out")
-            et = {"bf16": "unsigned short", "f16": "_Float16"}.get(parts[1], "float")
-            if parts[0] in ("igemm8", "igemm8s"):      # <OT, MF1, CLS, ABL, SP, HT> (HT: the 16-bit operand type, round 6)
-                return "igemm8_kernel<%s, %d, %d, 0, 0, %s>" % ("float" if f32o else et, 2 if t_[0] == "256" else 1,
-                                                                1 if parts[0] == "igemm8s" else 0, et)
-            return "igemm_kernel<%s, %s, %s, %s>" % (et, "float" if (f32o or parts[1] == "f32") else et, t_[0], t_[1])
+        symbol_of = igemm_symbol
         for k, v in sorted(mm.items(), key=lambda kv: -kv[1]["ms"]):
             a_ = v["flops"] / (v["ms"] * 1e9) if v["ms"] > 0 else 0.0
             roofline_mfma.append({"kernel": symbol_of(k), "family": k, "bound": "mfma", "achieved": round(a_, 2), "peak": peak,
@@ -779,7 +786,7 @@ def main():
         traffic, traffic_src = None, None
         sym = symbol_of(dom)
         for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
-            pmc = os.path.join(ROOT, "profiles", rnd + ("_f16" if args.dtype == "float16" else "") + "_pmc_summary.json")
+            pmc = os.path.join(ROOT, "profiles", rnd + {"float16": "_f16", "f16x2": "_f16x2", "bf16x3": "_x3"}.get(args.dtype, "") + "_pmc_summary.json")
             if os.path.exists(pmc):
                 ks = json.load(open(pmc))["kernels"]
                 want_ = sym.replace("unsigned short", "bf16").replace(" ", "")      # (tools/pmc_summary.py's short names)

@@ -14,11 +14,34 @@ import json
 import sys
 
 
+_DEMANGLED = {}
+
+
+def _demangle(name):
+    """c++filt on one mangled symbol, cached.  The binutils of this image predate the `DF16_` (_Float16) builtin-type code, so it
+    is handed the symbol with `Dh` (IEEE half: also a builtin type, hence no substitution index moves) and `half` is renamed back."""
+    if name not in _DEMANGLED:
+        import subprocess
+        out = name
+        try:
+            r = subprocess.run(["c++filt", name.replace("DF16_", "Dh")], stdout=subprocess.PIPE, universal_newlines=True, timeout=10)
+            got = r.stdout.strip()
+            if got and not got.startswith("_Z"):
+                import re
+                out = re.sub(r"\bhalf\b", "_Float16", got)
+        except Exception:  # noqa: BLE001
+            pass
+        _DEMANGLED[name] = out
+    return _DEMANGLED[name]
+
+
 def short(k):
     """rocprofv3 kernel name -> short family name.  The anonymous-namespace prefix is stripped BEFORE the argument
     list is cut off (every kernel of this library lives in `(anonymous namespace)`: cutting at the first "(" used to
     collapse all of them into one empty name).  The split-K first FC of the box head is its own template
     instantiation (igemm.hip), hence its own row."""
+    if k.startswith("_Z"):      # rocprofv3 leaves names with _Float16 arguments mangled (round 6: the fp16 instantiations)
+        k = _demangle(k)
     k = k.replace("(anonymous namespace)::", "").replace("void ", "").replace("unsigned short", "bf16")
     k = k.replace("__hip_bfloat16", "bf16")
     name = k.split("(")[0].strip()
