@@ -242,6 +242,16 @@ int mega_fgfa_warp_aggregate(const void* feats, const float* flow, void* out, fl
 int mega_fgfa_warp_aggregate_ring(const void* feats, const float* flow, void* out, float* weights_out, int T, int H,
                                   int W, int Cf, int Ce, const int* order, int dtype, void* stream);
 
+/* FlowNetS input in one kernel (round 6): the T image pairs cat([cur, frame_t]) of generalized_rcnn_fgfa.py:196-198 (the
+ * "/ 255" lives in the first conv's weights), average-pooled 2 x 2 with ceil_mode (backbone/flownet.py:52,:56), written as
+ * the operand of flow_conv1 with its seven horizontal taps gathered into the channel dimension:
+ *   out[t][3 + h][w][s * 8 + c] = pool(pair)[t][h][w - 3 + s][c]  (c < 6; zeros for c = 6, 7, channels 56..63, taps outside
+ *   the row and the three rows above / below), dtype MEGA_BF16 / MEGA_F16, [T][ceil(H/2) + 6][ceil(W/2)][64]:
+ * flow_conv1 (7 x 7, stride 2, pad 3, 6 -> 64) then IS a 7 x 1 conv, stride 2, pad 0, over 64 channels (K = 448 instead of
+ * the 49 x 64 of a channel-padded operand).  ring: f32 [T][3][H][W]; cur: the key frame(s), or NULL = ring slot order[0]. */
+int mega_fgfa_pair_taps(const float* ring, long long ring_stride, const float* cur, long long cur_stride, const int* order,
+                        void* out, int T, int H, int W, int dtype, void* stream);
+
 /* DFF feature propagation: out[H][W][C] = bilinear warp (same grid convention as above) of the
  * key frame's NHWC feature map by flow [2][H][W], times the per-element scale map [H][W][C].  Replaces
  * GeneralizedRCNNDFF.get_grid / resample and the scale multiply (detector/generalized_rcnn_dff.py:41-60,:132-135). */

@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmega_hip.so")
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+c_longlong = ctypes.c_longlong
 
 _ERR = {1: "bad argument", 2: "kernel launch failure", 3: "workspace too small"}
 
@@ -63,6 +64,7 @@ SIGNATURES = {
     "mega_conv2d_nhwc_plan_ex": (c_int, [c_int] * 14),
     "mega_preprocess_frames": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_float] * 3 + [c_int, c_void_p]),
     "mega_dff_warp_scale": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "mega_fgfa_pair_taps": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "mega_resize_bilinear_u8": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                                       c_int, c_void_p]),
     "mega_fgfa_warp_aggregate": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),

@@ -331,6 +331,70 @@ __global__ __launch_bounds__(256) void dff_warp_scale_kernel(const T* __restrict
   }
 }
 
+
+// ---- FlowNetS input (round 6): image pairs -> the first conv's operand in ONE kernel.
+// generalized_rcnn_fgfa.py:196-198 builds cat([cur, ref], 1) / 255 for the T window frames and flownet.py:52,:56 average-pools
+// it 2 x 2 before the 7 x 7 / stride-2 `flow_conv1` (6 -> 64 channels).  As separate steps on this path that was a 302 MB f32
+// concatenation, a permute + cast, a pad to 8 channels, the pool, a pad to the GEMM's 64-channel K vector (403 MB) and a conv
+// whose K = 49 x 64 carries 10.7x the real 49 x 6 products: ~1.5 ms of a 5.6 ms key frame.  Here one kernel reads the f32 NCHW
+// frames once and writes, per pooled pixel (t, h, w), the SEVEN horizontal taps of the conv as one 128-byte row:
+//   out[t][3 + h][w][s * 8 + c] = pool(pair)[t][h][w - 3 + s][c]   (c < 6: cur's 3 then the frame's 3 channels; 0 elsewhere),
+// with three zero rows above and below, so that flow_conv1 is a 7 x 1 convolution (stride 2, pad 0) over 64 channels: K = 448.
+// Arithmetic = the steps it replaces: each f32 pixel rounded to the 16-bit type, the in-bounds taps of a 2 x 2 window summed in
+// f32 in (dy, dx) order and divided by their count (nn.AvgPool2d(2, 2, ceil_mode=True)), rounded once.
+template <typename HT>
+__global__ __launch_bounds__(256) void pair_taps_kernel(const float* __restrict__ ring, long long ring_stride,
+                                                        const float* __restrict__ cur, long long cur_stride,
+                                                        const int* __restrict__ order, HT* __restrict__ out, int H, int W,
+                                                        int Hp, int Wp) {
+  constexpr int SEG = 250;
+  __shared__ uint4 px[SEG + 6];
+  const int w0 = blockIdx.x * SEG, row = blockIdx.y, t = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int npx = min(SEG, Wp - w0);
+  uint4* orow = reinterpret_cast<uint4*>(out + (((size_t)t * (Hp + 6) + row) * Wp + w0) * 64);
+  const int h = row - 3;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  if (h < 0 || h >= Hp) {                                // the conv's vertical padding
+    for (int i = tid; i < npx * 8; i += 256) orow[i] = zero;
+    return;
+  }
+  const float* cb = cur ? cur + (size_t)t * cur_stride : ring + (size_t)order[0] * ring_stride;
+  const float* rb = ring + (size_t)t * ring_stride;
+  if (tid < SEG + 6) {
+    const int w = w0 - 3 + tid;
+    uint4 v = zero;
+    if (w >= 0 && w < Wp) {
+      float a[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const float* plane = (c < 3 ? cb + (size_t)c * H * W : rb + (size_t)(c - 3) * H * W);
+        float acc = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int hi = 2 * h + dy;
+          if (hi >= H) continue;
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int wi = 2 * w + dx;
+            if (wi >= W) continue;
+            acc += Half16<HT>::one(Half16<HT>::cvt(plane[(size_t)hi * W + wi]));
+            ++cnt;
+          }
+        }
+        a[c] = acc / (float)cnt;
+      }
+      v = make_uint4(Half16<HT>::pack2(a[0], a[1]), Half16<HT>::pack2(a[2], a[3]), Half16<HT>::pack2(a[4], a[5]), 0u);
+    }
+    px[tid] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < npx * 8; i += 256) {             // 16-byte chunk s of pixel p: tap s (chunk 7: the K pad)
+    const int p_ = i >> 3, s_ = i & 7;
+    orow[i] = s_ < 7 ? px[p_ + s_] : zero;
+  }
+}
 }  // namespace
 
 extern "C" int mega_dff_warp_scale(const void* feats, const float* flow, const void* scale, void* out, int H, int W,
@@ -405,5 +469,25 @@ static int fgfa_impl(const void* feats, const float* flow, void* out, float* wei
   } else {
     return MEGA_ERR_ARG;
   }
+  return mega_check_launch();
+}
+
+/* see pair_taps_kernel.  ring: f32 [T][3][H][W] (ring_stride elements between frames); cur: the key frame(s), f32 [.][3][H][W]
+ * with cur_stride elements between the T pairs' key frames (0: one key frame for all), or NULL: the key frame is ring slot
+ * order[0] (device int).  out: [T][ceil(H/2) + 6][ceil(W/2)][64] of the 16-bit dtype. */
+extern "C" int mega_fgfa_pair_taps(const float* ring, long long ring_stride, const float* cur, long long cur_stride,
+                                   const int* order, void* out, int T, int H, int W, int dtype, void* stream) {
+  mega_clear_error();
+  if (!ring || !out || (!cur && !order) || T <= 0 || H <= 0 || W <= 0 || T > 65535) return MEGA_ERR_ARG;
+  const int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
+  if (Hp + 6 > 65535 || (reinterpret_cast<size_t>(out) & 15)) return MEGA_ERR_ARG;
+  const dim3 grid((unsigned)((Wp + 249) / 250), (unsigned)(Hp + 6), (unsigned)T);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MEGA_BF16)
+    hipLaunchKernelGGL((pair_taps_kernel<bf16_t>), grid, dim3(256), 0, st, ring, ring_stride, cur, cur_stride, order, (bf16_t*)out, H, W, Hp, Wp);
+  else if (dtype == MEGA_F16)
+    hipLaunchKernelGGL((pair_taps_kernel<f16_t>), grid, dim3(256), 0, st, ring, ring_stride, cur, cur_stride, order, (f16_t*)out, H, W, Hp, Wp);
+  else
+    return MEGA_ERR_ARG;
   return mega_check_launch();
 }

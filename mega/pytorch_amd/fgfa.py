@@ -109,6 +109,14 @@ class FlowNetS(_Packed):
             pk["ones"] = torch.ones((1024,), dtype=torch.float32, device=device)
         pk["x2.5"] = torch.full((2,), 2.5, dtype=torch.float32, device=device)
         pk["m"] = m
+        if dtype in (torch.bfloat16, torch.float16):
+            # flow_conv1 over ops.fgfa_pair_taps' operand: a 7 x 1 conv whose 64 input channels are the seven horizontal taps
+            # x (6 image channels + 2 zeros) + 8 zeros: w[o][r][0][s * 8 + c] = W[o][c][r][s] / 255  (K = 448, not 49 x 64)
+            w1 = self.flow_conv1.weight.detach().float() / 255.0                     # [64,6,7,7] (o, c, r, s)
+            wt = torch.zeros((64, 7, 1, 64), dtype=torch.float32)
+            for s_ in range(7):
+                wt[:, :, 0, s_ * 8:s_ * 8 + 6] = w1[:, :, :, s_].permute(0, 2, 1)   # [o, r, c]
+            pk["flow_conv1_taps"] = wt.to(dtype).to(device).contiguous()
         return pk
 
     def _conv(self, pk, name, x, act=2):
@@ -133,6 +141,30 @@ class FlowNetS(_Packed):
         # pair to 64 channels first wrote and re-read 1.6 GB per key frame for the same values
         x = _padc(ops.avgpool2x2_ceil(_padc(pair_nhwc, 8 if dt == torch.bfloat16 else 4)), m)
         r1 = self._conv(pk, "flow_conv1", x)
+        return self._trunk(pk, r1, m)
+
+    def run_pairs(self, refs, cur=None, order=None, dtype=torch.bfloat16):
+        """The same network fed from the f32 NCHW frames (16-bit compute dtypes): refs [T,3,H,W], the key frame `cur`
+        ([1,3,H,W] or one per pair) or ring slot order[0] -- the pair assembly, cast, pool and flow_conv1's horizontal taps are
+        ONE kernel (ops.fgfa_pair_taps) and flow_conv1 a 7 x 1 conv over K = 448 (round 6: the concatenation, permute, two
+        channel pads and a conv over K = 3136 it replaces were a quarter of config 5's key frame)."""
+        pk = self._packed(dtype, refs.device)
+        x = ops.fgfa_pair_taps(refs, cur, order, dtype)
+        w, b, s, p = pk["flow_conv1"]
+        r1 = ops.conv2d_nhwc(x, pk["flow_conv1_taps"], None, b, stride=2, pad=0, relu=2)
+        return self._trunk(pk, r1, _mult(dtype))
+
+    def pairs(self, refs, cur, dtype, order=None):
+        """flow of the pairs (cur | refs[t]): the one-kernel input stage for the 16-bit dtypes, the generic path otherwise"""
+        if dtype in (torch.bfloat16, torch.float16):
+            return self.run_pairs(refs, cur, order, dtype)
+        T = refs.shape[0]
+        if cur is None:
+            cur = refs.index_select(0, order[0:1].long())
+        pair = torch.cat([cur.expand(T, -1, -1, -1) if cur.shape[0] == 1 else cur, refs], dim=1)
+        return self.run(pair.permute(0, 2, 3, 1).contiguous().to(dtype))
+
+    def _trunk(self, pk, r1, m):
         r2 = self._conv(pk, "conv2", r1)
         r3 = self._conv(pk, "conv3", r2)
         r4 = self._conv(pk, "conv3_1", r3)
@@ -324,8 +356,7 @@ class GeneralizedRCNNFGFA(nn.Module):
         all_features = torch.cat(list(self.features), dim=0)                   # [T,h,w,3072] NHWC
         cur_image = self.images[self.key_frame_location]
         T = all_images.shape[0]
-        pair = torch.cat([cur_image.expand(T, -1, -1, -1), all_images], dim=1)  # :196-198 (the /255 lives in conv1)
-        flow = self.flownet.run(pair.permute(0, 2, 3, 1).contiguous().to(self.dtype))
+        flow = self.flownet.pairs(all_images, cur_image, self.dtype)             # :196-198 (the /255 lives in conv1)
         nfeat = self.backbone.out_channels
         agg = ops.fgfa_warp_aggregate(all_features.contiguous(), flow, nfeat, self.key_frame_location)   # [h,w,1024]
         feats = (_nchw_view(agg.unsqueeze(0)),)
@@ -411,8 +442,7 @@ class GeneralizedRCNNDFF(nn.Module):
             self.key_feats = _nhwc(self.backbone(cur)[0]).contiguous()
         if self.key_feats is None:
             raise RuntimeError("the first frame of a video must be a key frame")
-        pair = torch.cat([cur, self.key_images], dim=1)                         # :132 (the /255 lives in conv1)
-        flow, scale = self.flownet.run(pair.permute(0, 2, 3, 1).contiguous().to(self.dtype))
+        flow, scale = self.flownet.pairs(self.key_images, cur, self.dtype)       # :132 cat([cur, key]) (the /255 lives in conv1)
         agg = ops.dff_warp_scale(self.key_feats[0], flow[0].contiguous(), scale[0].contiguous())
         feats = (_nchw_view(agg.unsqueeze(0)),)
         proposals, _ = self.rpn(to_image_list(cur), feats, None)
@@ -481,9 +511,7 @@ class FgfaClipEngine(object):
         m = self.m
         W, H = size
         T = self.T
-        cur = self.img_ring.index_select(0, self.order[0:1])
-        pair = torch.cat([cur.expand(T, -1, -1, -1), self.img_ring], dim=1)
-        flow = m.flownet.run(pair.permute(0, 2, 3, 1).contiguous().to(m.dtype))
+        flow = m.flownet.pairs(self.img_ring, None, m.dtype, order=self.order)     # the key frame = ring slot order[0]
         nfeat = m.backbone.out_channels
         agg = ops.fgfa_warp_aggregate(self.feat_ring, flow, nfeat, 0, order=self.order)
         feats = (_nchw_view(agg.unsqueeze(0)),)

@@ -1074,6 +1074,31 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
     return (out, wts) if want_weights else out
 
 
+def fgfa_pair_taps(refs, cur=None, order=None, dtype=torch.bfloat16):
+    """FlowNetS's first-conv operand from the f32 NCHW frames in one kernel (mega_fgfa_pair_taps): refs [T,3,H,W] f32, the
+    key frame `cur` [1,3,H,W] (one for all pairs) or [T,3,H,W] (one per pair), or cur=None with `order` (i32 on the device):
+    the key frame is refs[order[0]] (the engine's image ring).  -> `dtype` [T, ceil(H/2) + 6, ceil(W/2), 64]:
+    out[t, 3 + h, w, s * 8 + c] = avgpool2x2_ceil(cat([cur, refs[t]]))[h, w - 3 + s, c], zeros elsewhere."""
+    _gpu(refs, cur, order)
+    lib = _lib.load()
+    T, C, H, W = refs.shape
+    assert C == 3 and refs.dtype == torch.float32 and refs.stride(1) == H * W and refs.stride(2) == W and refs.stride(3) == 1
+    assert dtype in _HALF and (cur is not None or order is not None)
+    cs = 0
+    if cur is not None:
+        assert cur.dtype == torch.float32 and cur.shape[1:] == (3, H, W) and cur.shape[0] in (1, T)
+        assert cur.stride(1) == H * W and cur.stride(2) == W and cur.stride(3) == 1
+        cs = cur.stride(0) if cur.shape[0] == T else 0
+    else:
+        assert order.dtype == torch.int32 and order.is_contiguous()
+    out = torch.empty((T, (H + 1) // 2 + 6, (W + 1) // 2, 64), dtype=dtype, device=refs.device)
+    _tok = _pb("fgfa_pair_taps", 0.0, refs.numel() * 4.0 + out.numel() * 2.0)
+    rc = lib.mega_fgfa_pair_taps(_ptr(refs), refs.stride(0), _ptr(cur), cs, _ptr(order), _ptr(out), T, H, W, _DT[dtype], _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_fgfa_pair_taps")
+    return out
+
+
 def avgpool2x2_ceil(x):
     """nn.AvgPool2d(2, 2, ceil_mode=True) on NHWC."""
     _gpu(x)

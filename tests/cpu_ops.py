@@ -233,6 +233,30 @@ def avgpool2x2_ceil(x):
     return F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1).contiguous().to(x.dtype)
 
 
+def fgfa_pair_taps(refs, cur=None, order=None, dtype=torch.bfloat16):
+    """the arithmetic of pair_taps_kernel: every f32 pixel rounded to `dtype`, the in-bounds taps of a 2 x 2 window summed in
+    f32 in (dy, dx) order and divided by their count, rounded once; the seven horizontal taps of a pooled pixel in 8-channel
+    groups of its 64-channel row, three zero rows above and below"""
+    T, _, H, W = refs.shape
+    if cur is None:
+        cur = refs[int(order[0]):int(order[0]) + 1]
+    pair = torch.cat([cur.expand(T, -1, -1, -1), refs], dim=1).to(dtype).float()       # [T,6,H,W]
+    Hp, Wp = (H + 1) // 2, (W + 1) // 2
+    acc = torch.zeros((T, 6, Hp, Wp))
+    cnt = torch.zeros((1, 1, Hp, Wp))
+    for dy in range(2):
+        for dx in range(2):
+            v = pair[:, :, dy::2, dx::2]
+            acc[:, :, :v.shape[2], :v.shape[3]] = acc[:, :, :v.shape[2], :v.shape[3]] + v
+            cnt[:, :, :v.shape[2], :v.shape[3]] += 1
+    pooled = (acc / cnt).to(dtype)                                                     # [T,6,Hp,Wp]
+    out = torch.zeros((T, Hp + 6, Wp, 64), dtype=dtype)
+    for s in range(7):
+        lo, hi = max(0, 3 - s), min(Wp, Wp + 3 - s)                                    # w with 0 <= w - 3 + s < Wp
+        out[:, 3:3 + Hp, lo:hi, s * 8:s * 8 + 6] = pooled[:, :, :, lo - 3 + s:hi - 3 + s].permute(0, 2, 3, 1)
+    return out
+
+
 def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
     if order is not None:          # ring form: window position t lives in slot order[1 + t], the key frame in order[0]
         slots = order[1:].long()
@@ -298,7 +322,7 @@ def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio, dtype=to
     return _planes(y.reshape(y.shape[0], -1).float(), dtype)
 
 
-ALL = ["split_planes", "split_conv_weight_h2", "conv2d_sp", "linear_sp", "roi_align_planes", "cast_bf16", "cast_half", "cat_rows_cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
+ALL = ["split_planes", "split_conv_weight_h2", "conv2d_sp", "linear_sp", "roi_align_planes", "cast_bf16", "cast_half", "cat_rows_cast_bf16", "split_bf16x3", "split_weight_bf16x3", "multi_cat", "copy_blocks", "pack_stem_weight_bf16", "dff_warp_scale", "resize_bilinear_u8", "avgpool2x2_ceil", "fgfa_pair_taps", "fgfa_warp_aggregate", "conv2d_nhwc", "linear", "linear_transposed", "stem", "maxpool3x3s2", "roi_align", "nms", "rpn_select",
        "postprocess", "position_logits", "relation_attention", "preprocess_frames", "position_logits_batched",
        "relation_attention_batched", "postprocess_batched"]
 

@@ -157,6 +157,33 @@ def test_fgfa_detector_matches_oracle(monkeypatch):
         assert (det.get_field("scores") - ws).abs().max() < 1e-5
 
 
+def test_flownet_pair_taps_path_on_cpu_twins(monkeypatch):
+    """FlowNetS.pairs in a 16-bit dtype (round 6: ops.fgfa_pair_taps + flow_conv1 as a 7 x 1 conv over the gathered taps) on
+    the CPU twins against the generic path on the explicitly built pair tensor: the packing of the taps weights, the operand
+    layout (three zero rows, seven taps x 8 channels) and the conv geometry give the same flow (f32 twins: round-off only),
+    with the key frame given directly and as a ring slot."""
+    import mega.pytorch_amd.fgfa  # noqa: F401
+    from mega.pytorch_amd import config, modeling, synth
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    cfg = config.get_cfg("R-50", "fgfa")
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.DTYPE = "bfloat16"
+    model = modeling.build_detection_model(cfg)
+    model.load_state_dict(synth.make_fgfa_state_dict(seed=3))
+    fn = model.flownet
+    g = torch.Generator().manual_seed(2)
+    refs = torch.rand((3, 3, 70, 90), generator=g) * 255.0 - 110.0
+    cur = refs[1:2].clone()
+    pair = torch.cat([cur.expand(3, -1, -1, -1), refs], dim=1)
+    with torch.no_grad():
+        old = fn.run(pair.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)).float()
+        new = fn.pairs(refs, cur, torch.bfloat16).float()
+        ring = fn.pairs(refs, None, torch.bfloat16, order=torch.tensor([1, 0, 1, 2], dtype=torch.int32)).float()
+    assert new.shape == old.shape and torch.equal(new, ring)
+    assert (new - old).abs().max().item() <= 0.02 * max(old.abs().max().item(), 1e-6)
+
+
 def test_fgfa_clip_engine_equals_model_on_cpu_twins(monkeypatch):
     """fgfa.FgfaClipEngine's host logic -- features of upcoming frames in look-ahead batches, the window in rings with a
     rotating slot table, the cold-start fill, the end-of-video clamp, restart on a second video -- against

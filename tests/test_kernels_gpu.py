@@ -403,6 +403,33 @@ def test_avgpool2x2_ceil(dev, dtype, shape):
     assert (got - ref).abs().max() < (1e-6 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 37, 51), (21, 60, 100), (2, 8, 1002)])
+def test_fgfa_pair_taps(dev, dtype, shape):
+    """mega_fgfa_pair_taps (round 6): cat([cur, ref]) -> 16-bit -> AvgPool2d(2, 2, ceil_mode) -> the seven horizontal taps of
+    flow_conv1 as one 64-channel row, three zero rows above / below -- BIT-equal to the arithmetic of the steps it replaces
+    (tests/cpu_ops.py's twin: each f32 pixel rounded, the in-bounds taps summed in f32 in (dy, dx) order, divided by their count,
+    rounded once), for the three ways the key frame is given: one for all pairs, one per pair, a ring slot (order[0]); odd
+    sizes (ceil-mode edges) and a row longer than one 250-pixel segment."""
+    import cpu_ops
+    ops = _ops()
+    T, H, W = shape
+    g = torch.Generator().manual_seed(T + H + W)
+    refs = (torch.rand((T, 3, H, W), generator=g) * 255.0 - 110.0)
+    cur1 = (torch.rand((1, 3, H, W), generator=g) * 255.0 - 110.0)
+    curT = (torch.rand((T, 3, H, W), generator=g) * 255.0 - 110.0)
+    order = torch.tensor([T - 1] + list(range(T)), dtype=torch.int32)
+    for cur, od in ((cur1, None), (curT, None), (None, order)):
+        if cur is not None and cur.shape[0] == T:        # one key frame per pair: the twin pair by pair
+            want = torch.cat([cpu_ops.fgfa_pair_taps(refs[t:t + 1], cur[t:t + 1], None, dtype) for t in range(T)], 0)
+        else:
+            want = cpu_ops.fgfa_pair_taps(refs, cur, od, dtype)
+        got = ops.fgfa_pair_taps(refs.to(dev), None if cur is None else cur.to(dev), None if od is None else od.to(dev), dtype).cpu()
+        assert got.shape == want.shape == (T, (H + 1) // 2 + 6, (W + 1) // 2, 64)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), "pair taps differ from the twin (max |d| %.3g)" % (
+            (got.float() - want.float()).abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_dff_warp_scale(dev, dtype):
     """warp(key feats, flow) * scale vs F.grid_sample(bilinear, border) (generalized_rcnn_dff.py:41-60,:134-135)."""
