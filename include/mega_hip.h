@@ -396,6 +396,37 @@ int mega_relation_attention_tiled_pos_dt(const void* q, int ldq, const void* k, 
                                          void* out, int ldo, int Nq, int Nk, int groups, float scale, int dtype, void* ws,
                                          size_t ws_bytes, void* stream);
 
+/* Round 6, FGFA / DFF (BASELINE configs[4]): FlowNetS's refinement levels, mega_core/modeling/backbone/flownet.py:40-52,:94-111.
+ *
+ * mega_conv2d_nhwc_ws with the split count chosen by the CALLER (small-M, long-K layers whose tiles would not fill the chip:
+ * FlowNetS's coarse levels on 21 pairs, the FGFA box head's fc6 on 300 rows -- roi_box_feature_extractors.py:55-118).
+ * ksplit >= 1 K ranges (clamped so that every range holds a K-tile), f32 partial sums in a workspace of
+ * mega_conv2d_nhwc_ks_workspace_bytes(M, Cout, K, in_dtype, ksplit) bytes, added in a fixed order by a second kernel.
+ * The result depends on ksplit (summation order), never on M. */
+size_t mega_conv2d_nhwc_ks_workspace_bytes(int M, int Cout, int K, int in_dtype, int ksplit);
+int mega_conv2d_nhwc_ks(const void* in, const void* w, const float* scale, const float* bias, const void* residual,
+                        void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil,
+                        int relu, int ldo, int ldr, int in_dtype, int out_dtype, int ksplit, void* ws, size_t ws_bytes,
+                        void* stream);
+/* nn.ConvTranspose2d(Cin, C, 4, stride=2) + bias + activation + crop_like + its slice of the torch.cat (flownet.py:9-13,:40-52,
+ * :94-111), as ONE sub-pixel GEMM: the four output phases (a, b) of a stride-2 transposed conv are a 2 x 2 / pad 1 convolution
+ * with 4 C output columns (a, b, co); GEMM row (t, m, n), column (a, b, co) is written to
+ *   out[t][2 m + a - crop][2 n + b - crop][coff + co]   of an NHWC tensor [N][out_H][out_W][ldo] (dropped outside it).
+ * in [N][H][W][Cin]; w4 [4 C][2][2][Cin] with w4[(a*2 + b)*C + co][r][s][ci] = Wt[ci][co][a + 2 (1 - r)][b + 2 (1 - s)]
+ * (Wt = the ConvTranspose2d weight [Cin][C][4][4]); bias4 f32 [4 C] (the bias once per phase) or NULL; relu as
+ * mega_conv2d_nhwc; dtype = operand AND output type (MEGA_BF16 / MEGA_F16: Cin % 64 == 0; MEGA_F32: Cin % 32 == 0);
+ * C, ldo, coff multiples of the 16-byte vector.  ksplit / ws as mega_conv2d_nhwc_ks with M = N (H+1) (W+1), Cout = 4 C,
+ * K = 4 Cin.  A quarter of the matrix work of the zero-stuffed form, no zero-stuffing / crop / cat copies. */
+int mega_conv2d_nhwc_subpixel(const void* in, const void* w4, const float* bias4, void* out, int N, int H, int W, int Cin,
+                              int C, int relu, int out_H, int out_W, int crop, int ldo, int coff, int dtype, int ksplit,
+                              void* ws, size_t ws_bytes, void* stream);
+/* The rest of a refinement level's concatenation in one pass (flownet.py:94-111): out[..., 0:Cs] = skip,
+ * out[..., Cs+C : Cs+C+2] = crop(ConvTranspose2d(2, 2, 4, stride=2)(flow)) computed in f32 from the f32 weights
+ * w_up [2][2][4][4] / b_up [2], out[..., Cs+C+2 : ldo] = 0.  skip [N][H2][W2][Cs], flow [N][h][w][2], out [N][H2][W2][ldo] of
+ * `dtype`; crop: rows / columns of the full (2h+2) x (2w+2) map dropped at the top / left. */
+int mega_flow_level_assemble(const void* skip, const void* flow, const float* w_up, const float* b_up, void* out, int N,
+                             int H2, int W2, int Cs, int C, int ldo, int h, int w, int crop, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,10 @@ SIGNATURES = {
     "mega_roi_align_fwd_planes_dt": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float] + [c_int] * 4 + [c_void_p]),
     "mega_conv2d_nhwc_sp_dt": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                        c_int] + [c_int] * 12 + [c_void_p, c_size_t, c_void_p]),
+    "mega_conv2d_nhwc_ks_workspace_bytes": (c_size_t, [c_int] * 5),
+    "mega_conv2d_nhwc_ks": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p, c_size_t, c_void_p]),
+    "mega_conv2d_nhwc_subpixel": (c_int, [c_void_p] * 4 + [c_int] * 13 + [c_void_p, c_size_t, c_void_p]),
+    "mega_flow_level_assemble": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
     "mega_last_error_string": (ctypes.c_char_p, []),
 }
 

@@ -491,3 +491,83 @@ extern "C" int mega_fgfa_pair_taps(const float* ring, long long ring_stride, con
     return MEGA_ERR_ARG;
   return mega_check_launch();
 }
+
+// ---- FlowNetS refinement level (flownet.py:94-111): concatN = cat([skip, crop(leaky(deconvN(x))), crop(upsample_flowN(flow))], 1)
+// zero-padded to the GEMM's K vector.  The deconvolution's sub-pixel conv (mega_conv2d_nhwc_subpixel) writes its slice of the
+// concatenation itself; this kernel writes the rest in one pass: the skip connection's channels [0, Cs), the 2-channel
+// ConvTranspose2d(2, 2, 4, stride 2) of the coarse flow at [Cs + C, Cs + C + 2) -- 16 FMAs per pixel in f32 on the f32 weights:
+// out pixel (Y, X) = (y + crop, x + crop) of the full map sees coarse pixels (Y / 2 - dy, X / 2 - dx) through taps
+// (Y % 2 + 2 dy, X % 2 + 2 dx) -- and zeros up to the pixel stride.  Replaces a GEMM on 64-padded channels over a zero-stuffed
+// map, two crops, a cat and a pad (five launches, ~0.15 ms per level of the 21-pair key frame).
+template <typename T>
+__global__ __launch_bounds__(256) void flow_level_assemble_kernel(const T* __restrict__ skip, const T* __restrict__ flow,
+                                                                  const float* __restrict__ wup, const float* __restrict__ bup,
+                                                                  T* __restrict__ out, int N, int H2, int W2, int Cs, int C, int ldo,
+                                                                  int h, int w, int crop) {
+  constexpr int VE = Elem<T>::VE;
+  const int vs = Cs / VE, vt = (ldo - Cs - C) / VE, vpp = vs + vt;
+  const long long total = (long long)N * H2 * W2 * vpp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long px = i / vpp;
+    const int v = (int)(i - px * vpp);
+    T* o = out + px * ldo;
+    if (v < vs) {
+      *reinterpret_cast<uint4*>(o + v * VE) = *reinterpret_cast<const uint4*>(skip + px * Cs + v * VE);
+      continue;
+    }
+    uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    if (v == vs) {
+      const int x = (int)(px % W2), y = (int)((px / W2) % H2), t = (int)(px / ((long long)W2 * H2));
+      const int Y = y + crop, X = x + crop, a = Y & 1, b = X & 1, m = Y >> 1, n = X >> 1;
+      float u0 = bup[0], u1 = bup[1];
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int mi = m - dy, ni = n - dx;
+          if ((unsigned)mi >= (unsigned)h || (unsigned)ni >= (unsigned)w) continue;
+          const T* f = flow + ((long long)(t * h + mi) * w + ni) * 2;
+          const float f0 = Elem<T>::ld(f), f1 = Elem<T>::ld(f + 1);
+          const int tap = (a + 2 * dy) * 4 + (b + 2 * dx);          // w[ci][co][kh][kw]
+          u0 = fmaf(f0, wup[0 * 32 + 0 * 16 + tap], u0);
+          u0 = fmaf(f1, wup[1 * 32 + 0 * 16 + tap], u0);
+          u1 = fmaf(f0, wup[0 * 32 + 1 * 16 + tap], u1);
+          u1 = fmaf(f1, wup[1 * 32 + 1 * 16 + tap], u1);
+        }
+      T* ze = reinterpret_cast<T*>(&z);
+      T e0, e1;
+      Elem<T>::st(&e0, u0);
+      Elem<T>::st(&e1, u1);
+      ze[0] = e0; ze[1] = e1;
+    }
+    *reinterpret_cast<uint4*>(o + Cs + C + (v - vs) * VE) = z;
+  }
+}
+
+/* see flow_level_assemble_kernel.  skip [N][H2][W2][Cs], flow [N][h][w][2], out [N][H2][W2][ldo] of `dtype` (MEGA_F32 / BF16 /
+ * F16); w_up f32 [2][2][4][4] (ConvTranspose2d weight, [in][out][kh][kw]), b_up f32 [2]; Cs, C, ldo multiples of the 16-byte
+ * vector, ldo >= Cs + C + 2; crop: rows / columns of the full (2h + 2) x (2w + 2) map dropped at the top / left. */
+extern "C" int mega_flow_level_assemble(const void* skip, const void* flow, const float* w_up, const float* b_up, void* out,
+                                        int N, int H2, int W2, int Cs, int C, int ldo, int h, int w, int crop, int dtype,
+                                        void* stream) {
+  mega_clear_error();
+  if (!skip || !flow || !w_up || !b_up || !out || N <= 0 || H2 <= 0 || W2 <= 0 || h <= 0 || w <= 0 || crop < 0) return MEGA_ERR_ARG;
+  const int ve = dtype == MEGA_F32 ? 4 : 8;
+  if ((dtype != MEGA_F32 && dtype != MEGA_BF16 && dtype != MEGA_F16) || Cs <= 0 || C <= 0 || Cs % ve || C % ve || ldo % ve ||
+      ldo < Cs + C + 2 || H2 + crop > 2 * h + 2 || W2 + crop > 2 * w + 2)
+    return MEGA_ERR_ARG;
+  if ((reinterpret_cast<size_t>(out) & 15) || (reinterpret_cast<size_t>(skip) & 15)) return MEGA_ERR_ARG;
+  const long long total = (long long)N * H2 * W2 * ((Cs + (ldo - Cs - C)) / ve);
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MEGA_BF16)
+    hipLaunchKernelGGL((flow_level_assemble_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)skip, (const bf16_t*)flow,
+                       w_up, b_up, (bf16_t*)out, N, H2, W2, Cs, C, ldo, h, w, crop);
+  else if (dtype == MEGA_F16)
+    hipLaunchKernelGGL((flow_level_assemble_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, (const f16_t*)skip, (const f16_t*)flow,
+                       w_up, b_up, (f16_t*)out, N, H2, W2, Cs, C, ldo, h, w, crop);
+  else
+    hipLaunchKernelGGL((flow_level_assemble_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)skip, (const float*)flow,
+                       w_up, b_up, (float*)out, N, H2, W2, Cs, C, ldo, h, w, crop);
+  return mega_check_launch();
+}

@@ -52,7 +52,7 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, typename OT, int BM, int BN>
+template <typename T, typename OT, int BM, int BN, bool PS = false>
 __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igemm_kernel(ConvParams p) {
   constexpr int KE = KTB / (int)sizeof(T);   // K elements per tile
   constexpr int VE = 16 / (int)sizeof(T);    // elements per 16-B vector
@@ -242,13 +242,15 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
   //      keeps the counts exact, the residual rows are a rolling (two-slab) prefetch and the stores drain behind the
   //      next slab's staging (barriers wait for LDS traffic only).
   constexpr bool RES_FAST = 64 * VPR / NTHREADS <= 4;  // (256-wide tiles: 8-16 residual vectors per slab in flight twice would spill)
+  // PS (sub-pixel output, igemm_params.h): the launcher only admits shapes this path serves
+  const size_t out_elems = PS ? (size_t)p.N * p.ps_H * p.ps_W * p.ldo : (size_t)(p.M - 1) * p.ldo + p.Cout;
   const bool fast = vec_ok && p.ksplit == 1 && n0 + BN <= p.Cout &&
-                    ((size_t)(p.M - 1) * p.ldo + p.Cout) * sizeof(OT) < 0x7FF00000ull &&
+                    out_elems * sizeof(OT) < 0x7FF00000ull &&
                     (res == nullptr || (RES_FAST && ((size_t)(p.M - 1) * p.ldr + p.Cout) * sizeof(T) < 0x7FF00000ull));
   if (fast) {
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        p.out, 0, (int)(((size_t)(p.M - 1) * p.ldo + p.Cout) * sizeof(OT)), 0x00020000);
+        p.out, 0, (int)(out_elems * sizeof(OT)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.res ? p.res : p.out), 0, res ? (int)(((size_t)(p.M - 1) * p.ldr + p.Cout) * sizeof(T)) : 0,
         0x00020000);
@@ -258,6 +260,20 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
     const int row0 = tid / VPR, cvo = (tid % VPR) * OVE, ncol = n0 + cvo;
     auto slab_m = [&](int i, int it) {      // (row0 < RSTEP, RSTEP divides 32: per-thread part + compile-time part)
       return (m0 + row0) + (((it * RSTEP) >> 5) * WTM + i * 32 + ((it * RSTEP) & 31));
+    };
+    // byte offset of the 16-byte output vector of GEMM row m (this thread's columns ncol ..): plain rows, or the sub-pixel
+    // scatter of a transposed conv's phases (a vector never straddles two phases: ps_C % OVE == 0)
+    const int ps_q = PS ? ncol / p.ps_C : 0;
+    const int ps_col = PS ? p.ps_coff + (ncol - ps_q * p.ps_C) : 0;
+    auto out_off = [&](int m) -> unsigned {
+      if constexpr (PS) {
+        const int t = m / HoWo, rem = m - t * HoWo, mh = rem / p.Wo, mw = rem - mh * p.Wo;
+        const int y = 2 * mh + (ps_q >> 1) - p.ps_crop, x = 2 * mw + (ps_q & 1) - p.ps_crop;
+        const bool ok = m < p.M && (unsigned)y < (unsigned)p.ps_H && (unsigned)x < (unsigned)p.ps_W;
+        return ok ? (unsigned)(((t * p.ps_H + y) * p.ps_W + x) * p.ldo + ps_col) * (unsigned)sizeof(OT) : 0xFFFFFFFFu;
+      } else {
+        return (unsigned)(m * p.ldo + ncol) * (unsigned)sizeof(OT);
+      }
     };
     // RL = 1: ReLU on the ROUNDED value (bf16: one v_pk_max_i16 per pair on the packed bits; f32: v_max) -- equal to
     // the generic x > 0 ? x : x * slope bit for bit except that negative inputs give +0 instead of -0 (see igemm8.hip)
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
 #pragma unroll
             for (int t = 0; t < 4; ++t) o[t] = __float_as_uint(RELU ? fmaxf(v[t], 0.f) : act(v[t]));
           }
-          __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (unsigned)(slab_m(i, it) * p.ldo + ncol) * (unsigned)sizeof(OT), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, out_off(slab_m(i, it)), 0, 0);
         }
         if (HAS_RES && i + PD < TM) ldres(i + PD, rr[i % PD]);   // slab i + PD into the registers slab i just freed
       }
@@ -334,6 +350,7 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
     }
     return;
   }
+  if (PS && p.ksplit == 1) return;            // (the sub-pixel launcher refuses what the fast path does not serve)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (i > 0) __syncthreads();               // the previous slab has been read out
@@ -395,13 +412,13 @@ __global__ __launch_bounds__(NTHREADS, (BM * BN <= 128 * 128 ? 2 : 1)) void igem
   }
 }
 
-template <typename T, typename OT, int BM, int BN>
+template <typename T, typename OT, int BM, int BN, bool PS = false>
 int launch(const ConvParams& p, hipStream_t st) {
   const int ntm = cdiv(p.M, BM), ntn = cdiv(p.Cout, BN);
   const size_t smem = 2 * (BM + BN) * LDS_STRIDE;
   // set on every launch: a per-process flag would miss the second device of a multi-GPU process (cheap host call)
-  (void)hipFuncSetAttribute((const void*)igemm_kernel<T, OT, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL((igemm_kernel<T, OT, BM, BN>), dim3(ntm * ntn, 1, p.ksplit), dim3(NTHREADS), smem, st, p);
+  (void)hipFuncSetAttribute((const void*)igemm_kernel<T, OT, BM, BN, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((igemm_kernel<T, OT, BM, BN, PS>), dim3(ntm * ntn, 1, p.ksplit), dim3(NTHREADS), smem, st, p);
   return mega_check_launch();
 }
 
@@ -417,6 +434,13 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(ConvParams p) {
     v = v * (p.scale ? p.scale[n] : 1.f) + (p.bias ? p.bias[n] : 0.f);
     if (p.res) v += Elem<T>::ld((const T*)p.res + (size_t)m * p.ldr + n);
     v = v > 0.f ? v : v * neg_slope;
+    if (p.ps) {                                   // sub-pixel output (igemm_params.h)
+      const int HoWo = p.Ho * p.Wo, t = m / HoWo, rem = m - t * HoWo, mh = rem / p.Wo, mw = rem - mh * p.Wo;
+      const int q = n / p.ps_C, y = 2 * mh + (q >> 1) - p.ps_crop, x = 2 * mw + (q & 1) - p.ps_crop;
+      if ((unsigned)y < (unsigned)p.ps_H && (unsigned)x < (unsigned)p.ps_W)
+        Elem<OT>::st((OT*)p.out + ((size_t)(t * p.ps_H + y) * p.ps_W + x) * p.ldo + p.ps_coff + (n - q * p.ps_C), v);
+      continue;
+    }
     Elem<OT>::st((OT*)p.out + (size_t)m * p.ldo + n, v);
   }
 }
@@ -607,10 +631,48 @@ extern "C" size_t mega_conv2d_nhwc_workspace_bytes(int M, int Cout, int K) {
   return z > 1 ? (size_t)z * M * Cout * sizeof(float) : 0;
 }
 
+// the largest split count <= want whose every K range holds at least one K-tile (the kernels assume nkt >= 1)
+static int clamp_ksplit(int K, int in_dtype, int want) {
+  const int nkt = K / (in_dtype == MEGA_F32 ? 32 : 64);
+  int z = want < 1 ? 1 : (want > nkt ? nkt : want);
+  while (z > 1 && (z - 1) * cdiv(nkt, z) >= nkt) --z;
+  return z < 1 ? 1 : z;
+}
+
+extern "C" size_t mega_conv2d_nhwc_ks_workspace_bytes(int M, int Cout, int K, int in_dtype, int ksplit) {
+  const int z = clamp_ksplit(K, in_dtype, ksplit);
+  return z > 1 ? (size_t)z * M * Cout * sizeof(float) : 0;
+}
+
+static int conv2d_impl(const void* in, const void* w, const float* scale, const float* bias,
+                       const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
+                       int R, int S, int stride, int pad, int dil, int relu, int ldo, int ldr,
+                       int in_dtype, int out_dtype, void* ws, size_t ws_bytes, int ksplit, void* stream);
+
 extern "C" int mega_conv2d_nhwc_ws(const void* in, const void* w, const float* scale, const float* bias,
                                    const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
                                    int R, int S, int stride, int pad, int dil, int relu, int ldo, int ldr,
                                    int in_dtype, int out_dtype, void* ws, size_t ws_bytes, void* stream) {
+  return conv2d_impl(in, w, scale, bias, residual, out, N, H, W, Cin, Cout, R, S, stride, pad, dil, relu, ldo, ldr, in_dtype,
+                     out_dtype, ws, ws_bytes, 0, stream);
+}
+
+// mega_conv2d_nhwc_ws with the split count chosen by the CALLER (small-M, long-K layers whose tiles would not fill the chip:
+// FlowNetS's coarse levels, the FGFA box head's fc6 on 300 rows).  ksplit >= 1 K ranges (clamped so that every range holds a
+// K-tile); workspace of mega_conv2d_nhwc_ks_workspace_bytes.  The result depends on ksplit (summation order), not on M.
+extern "C" int mega_conv2d_nhwc_ks(const void* in, const void* w, const float* scale, const float* bias,
+                                   const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
+                                   int R, int S, int stride, int pad, int dil, int relu, int ldo, int ldr,
+                                   int in_dtype, int out_dtype, int ksplit, void* ws, size_t ws_bytes, void* stream) {
+  if (ksplit < 1) return MEGA_ERR_ARG;
+  return conv2d_impl(in, w, scale, bias, residual, out, N, H, W, Cin, Cout, R, S, stride, pad, dil, relu, ldo, ldr, in_dtype,
+                     out_dtype, ws, ws_bytes, ksplit, stream);
+}
+
+static int conv2d_impl(const void* in, const void* w, const float* scale, const float* bias,
+                       const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
+                       int R, int S, int stride, int pad, int dil, int relu, int ldo, int ldr,
+                       int in_dtype, int out_dtype, void* ws, size_t ws_bytes, int ksplit, void* stream) {
   mega_clear_error();
   if (!in || !w || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
       dil <= 0 || pad < 0)
@@ -629,9 +691,11 @@ extern "C" int mega_conv2d_nhwc_ws(const void* in, const void* w, const float* s
   p.relu = relu;
   p.ksplit = 1;
   p.partial = nullptr;
-  if (ws) {   // with a workspace the K range of long-K layers is split (mega_conv2d_nhwc_workspace_bytes)
-    const int z = choose_ksplit(p.K);
+  if (ksplit > 0 && in_dtype != MEGA_F32 && in_dtype != MEGA_BF16 && in_dtype != MEGA_F16) return MEGA_ERR_ARG;
+  if (ksplit > 0 || ws) {   // with a workspace the K range of long-K layers is split (mega_conv2d_nhwc_workspace_bytes)
+    const int z = ksplit > 0 ? clamp_ksplit(p.K, in_dtype, ksplit) : choose_ksplit(p.K);
     if (z > 1) {
+      if (!ws) return MEGA_ERR_ARG;
       if (ws_bytes < (size_t)z * p.M * Cout * sizeof(float)) return MEGA_ERR_ARG;
       p.ksplit = z;
       p.partial = (float*)ws;
@@ -675,6 +739,61 @@ extern "C" int mega_conv2d_nhwc(const void* in, const void* w, const float* scal
                                 int in_dtype, int out_dtype, void* stream) {
   return mega_conv2d_nhwc_ws(in, w, scale, bias, residual, out, N, H, W, Cin, Cout, R, S, stride, pad, dil, relu, ldo,
                              ldr, in_dtype, out_dtype, nullptr, 0, stream);
+}
+
+// ConvTranspose2d(Cin -> C, kernel 4, stride 2, no padding) + bias + activation, cropped, written into a channel slice of an
+// NHWC tensor -- FlowNetS's refinement deconvolutions (mega_core/modeling/backbone/flownet.py:40-52 deconv5..deconv2 and
+// :94-111: crop_like + torch.cat) without the zero-stuffed input (4x the matrix work) and without the crop / cat copies.
+// Output pixel (2 m + a, 2 n + b) of the full (2H + 2) x (2W + 2) map only sees input pixels (m - dy, n - dx), dy, dx in {0, 1},
+// through kernel taps (a + 2 dy, b + 2 dx): the four phases (a, b) are ONE 2 x 2 / pad 1 convolution over the input with
+// 4 C output columns ordered (a, b, co),  w4[(a*2 + b)*C + co][r][s][ci] = Wt[ci][co][a + 2 (1 - r)][b + 2 (1 - s)]
+// (ops.pack_deconv4x4s2), whose epilogue scatters row (t, m, n), column (a, b, co) to
+//   out[t][2 m + a - crop][2 n + b - crop][coff + co]      (dropped outside [0, out_H) x [0, out_W); ldo = pixel stride).
+// bias4 f32 [4 C] (the bias repeated per phase) or NULL; relu as mega_conv2d_nhwc; dtype = operand AND output type
+// (MEGA_BF16 / MEGA_F16: Cin % 64 == 0; MEGA_F32: Cin % 32 == 0); C, ldo, coff multiples of the 16-byte vector (8 / 4
+// elements).  ksplit > 1: split-K as mega_conv2d_nhwc_ks (workspace mega_conv2d_nhwc_ks_workspace_bytes(N (H+1) (W+1), 4 C,
+// 4 Cin, dtype, ksplit)).
+extern "C" int mega_conv2d_nhwc_subpixel(const void* in, const void* w4, const float* bias4, void* out, int N, int H, int W,
+                                         int Cin, int C, int relu, int out_H, int out_W, int crop, int ldo, int coff, int dtype,
+                                         int ksplit, void* ws, size_t ws_bytes, void* stream) {
+  mega_clear_error();
+  if (!in || !w4 || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || C <= 0 || out_H <= 0 || out_W <= 0 || crop < 0 ||
+      ksplit < 1 || coff < 0)
+    return MEGA_ERR_ARG;
+  if (dtype != MEGA_F32 && dtype != MEGA_BF16 && dtype != MEGA_F16) return MEGA_ERR_ARG;
+  const size_t esz = dtype == MEGA_F32 ? 4 : 2;
+  const int ove = (int)(16 / esz);
+  if (Cin % (dtype == MEGA_F32 ? 32 : 64) != 0 || C % ove != 0 || ldo % ove != 0 || coff % ove != 0 || coff + C > ldo) return MEGA_ERR_ARG;
+  ConvParams p = {};
+  p.in = in; p.w = w4; p.scale = nullptr; p.bias = bias4; p.res = nullptr; p.out = out;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = 4 * C; p.R = 2; p.S = 2; p.stride = 1; p.pad = 1; p.dil = 1;
+  p.Ho = H + 1; p.Wo = W + 1;
+  p.M = N * p.Ho * p.Wo;
+  p.K = 4 * Cin;
+  p.ldo = ldo; p.ldr = ldo; p.relu = relu;
+  p.ps = 1; p.ps_H = out_H; p.ps_W = out_W; p.ps_C = C; p.ps_crop = crop; p.ps_coff = coff;
+  const size_t ib = (size_t)N * H * W * Cin * esz, wb = (size_t)p.Cout * p.K * esz;
+  if (ib >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull || (size_t)N * out_H * out_W * ldo * esz >= 0x7FF00000ull) return MEGA_ERR_ARG;
+  p.in_bytes = (unsigned)ib;
+  p.w_bytes = (unsigned)wb;
+  p.ksplit = clamp_ksplit(p.K, dtype, ksplit);
+  p.partial = nullptr;
+  if (p.ksplit > 1) {
+    if (!ws || ws_bytes < (size_t)p.ksplit * p.M * p.Cout * sizeof(float)) return MEGA_ERR_ARG;
+    p.partial = (float*)ws;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long b128 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 128) * p.ksplit, b12864 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 64) * p.ksplit;
+  const int tile = b128 >= 384 ? 0 : (b12864 >= 384 ? 1 : 2);     // (choose_tile's rule for the register-staged tiles)
+  auto go = [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    int rc = tile == 0 ? launch<T, T, 128, 128, true>(p, st) : (tile == 1 ? launch<T, T, 128, 64, true>(p, st) : launch<T, T, 64, 64, true>(p, st));
+    if (rc == MEGA_OK && p.ksplit > 1) rc = launch_finalize<T, T>(p, st);
+    return rc;
+  };
+  if (dtype == MEGA_BF16) return go(bf16_t{});
+  if (dtype == MEGA_F16) return go(f16_t{});
+  return go(float{});
 }
 
 // Split-precision activation planes (igemm_params.h, igemm8.hip SP kernels).  An f32 activation x [N,H,W,C] lives in HBM as

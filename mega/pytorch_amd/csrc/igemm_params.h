@@ -27,6 +27,11 @@ struct ConvParams {
   int split_out;     // 1: out is split planes [M][ldo] with hi at column n and lo at column Cout + n (bf16 output only)
                      // (a residual given to an SP launch is ALWAYS split planes: res[m][n] + res[m][Cout + n])
   unsigned mg_howo, sh_howo, mg_wo, sh_wo;   // magic multipliers / shifts for m / (Ho Wo) and rem / Wo (set by the launcher)
+  // ---- igemm.hip only.  Sub-pixel output (mega_conv2d_nhwc_subpixel): a ConvTranspose2d(k = 4, s = 2) run as a 2 x 2 / pad 1
+  //      conv with 4 ps_C output columns n = (a, b, co): GEMM row m = (t, mh, mw) lands at pixel (2 mh + a - ps_crop,
+  //      2 mw + b - ps_crop), channel ps_coff + co of an NHWC tensor [N][ps_H][ps_W][ldo]; pixels outside it are dropped
+  int ps;            // 1: the fields below apply
+  int ps_H, ps_W, ps_C, ps_crop, ps_coff;
 };
 
 // igemm8.hip: bf16 operands, 8 waves, 256 (BM8 rows) x 256 tile; returns MEGA_OK / MEGA_ERR_*.  out_f32: 0 bf16, 1 f32.

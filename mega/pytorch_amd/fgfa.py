@@ -8,10 +8,13 @@
 with the reference's module / parameter names (state_dict compatible: flownet.*, embednet.*,
 roi_heads.box.feature_extractor.{head,conv,fc6,fc7}.*).
 
-Kernel mapping: every Conv2d / ConvTranspose2d / Linear is the implicit-GEMM MFMA kernel (igemm.hip); a
-ConvTranspose2d(k=4, s=2) is run as a stride-1 4x4 conv with the flipped kernel over the zero-stuffed input;
-channel counts that are not a multiple of the GEMM K-vector (6, 2, 1026, 770, 386, 194) are zero-padded (weights
-too), which changes no result.  The flow-guided warp + cosine weights + softmax + sum is ONE fused kernel
+Kernel mapping: every Conv2d / ConvTranspose2d / Linear is the implicit-GEMM MFMA kernel (igemm.hip).  A
+ConvTranspose2d(Cin, C, 4, stride=2) is ONE sub-pixel GEMM (its four output phases = a 2 x 2 / pad 1 conv with 4 C output
+columns, ops.deconv4x4s2_into) that writes its cropped result straight into the level's concatenation buffer; the 2-channel
+flow up-sampling, the skip connection and the zero padding of that buffer are one more kernel (ops.flow_level_assemble).
+`FlowNetS.subpixel = False` keeps the literal form (stride-1 4x4 conv with the flipped kernel over the zero-stuffed input,
+crop, cat, pad: 4x the matrix work) -- tests compare the two.  Channel counts that are not a multiple of the GEMM K-vector
+(6, 2, 1026, 770, 386, 194) are zero-padded (weights too), which changes no result.  The flow-guided warp + cosine weights + softmax + sum is ONE fused kernel
 (fgfa.hip).  torch is used for memory plumbing only (concat / crop / zero-stuffing copies).
 """
 from collections import deque
@@ -72,6 +75,7 @@ class FlowNetS(_Packed):
              ("Convolution5", 194)]
     DECONVS = [("deconv5", 1024, 512), ("deconv4", 1026, 256), ("deconv3", 770, 128), ("deconv2", 386, 64)]
     UPS = ["upsample_flow6to5", "upsample_flow5to4", "upsample_flow4to3", "upsample_flow3to2"]
+    subpixel = True        # the refinement levels' transposed convs as sub-pixel GEMMs (False: zero-stuffed, the literal form)
 
     def __init__(self, cfg):
         super().__init__()
@@ -104,6 +108,13 @@ class FlowNetS(_Packed):
             mod = getattr(self, name)
             w = mod.weight.detach().permute(1, 0, 2, 3).flip(2, 3)      # [in,out,kh,kw] -> conv kernel [out,in,kh,kw]
             pk[name] = (_pack_w(w, dtype, m).to(device), mod.bias.detach().float().to(device).contiguous())
+        for name, _, co in self.DECONVS:     # the sub-pixel form: [4 C, 2, 2, Cin] + the bias once per phase
+            mod = getattr(self, name)
+            pk[name + ".sp"] = (ops.pack_deconv4x4s2(mod.weight, dtype, m).to(device),
+                                mod.bias.detach().float().repeat(4).to(device).contiguous(), co)
+        for name in self.UPS:                # f32 ConvTranspose2d weight [in, out, kh, kw] as it is
+            mod = getattr(self, name)
+            pk[name + ".sp"] = (mod.weight.detach().float().to(device).contiguous(), mod.bias.detach().float().to(device).contiguous())
         if self.method == "dff":
             pk["scale_w"] = _pack_w(self.Convolution5_scale.weight, dtype, m).to(device)
             pk["ones"] = torch.ones((1024,), dtype=torch.float32, device=device)
@@ -177,6 +188,13 @@ class FlowNetS(_Packed):
 
         def level(feat_in, skip, pred_name, up_name, deconv_name):
             flow = self._pred(pk, pred_name, feat_in)                       # [.,.,.,2]
+            if self.subpixel:
+                w4, b4, C = pk[deconv_name + ".sp"]
+                Cs = skip.shape[-1]
+                cc = torch.empty(skip.shape[:3] + ((Cs + C + 2 + m - 1) // m * m,), dtype=skip.dtype, device=skip.device)
+                ops.deconv4x4s2_into(feat_in, w4, b4, cc, Cs, relu=2)       # cc[..., Cs:Cs+C] = crop(leaky(deconv(feat_in)))
+                wu, bu = pk[up_name + ".sp"]
+                return ops.flow_level_assemble(skip, flow, wu, bu, cc, C)  # skip | . | crop(up(flow)) | zeros
             up = _crop_like(self._deconv(pk, up_name, flow, 0), skip)
             dec = _crop_like(self._deconv(pk, deconv_name, feat_in, 2), skip)
             return _padc(torch.cat([skip, dec, up], dim=-1), m)             # concatN (channel-padded)

@@ -137,9 +137,10 @@ def _igemm_family(lib, M, Cout, K, dtype, shape=None):
 
 
 def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,
-                out=None):
+                out=None, ksplit=None):
     """x [N,H,W,Cin] (contiguous), w [Cout,R,S,Cin] -> [N,Ho,Wo,Cout].  y = act(conv*scale + bias (+res));
-    relu: False/0 none, True/1 ReLU, 2 LeakyReLU(0.1)."""
+    relu: False/0 none, True/1 ReLU, 2 LeakyReLU(0.1).  ksplit (int >= 1): the caller's split-K count
+    (mega_conv2d_nhwc_ks: small-M / long-K layers of FlowNetS and the FGFA box head); None: the library's K-only rule."""
     _gpu(x, w, scale, bias, residual)
     lib = _lib.load()
     N, H, W, Cin = x.shape
@@ -168,6 +169,15 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
         raise ValueError("conv2d_nhwc: operand of %.2f GiB; the kernels use 32-bit buffer offsets (< 2 GiB per operand): "
                          "lower the frame-stage batch (ClipEngine steps_per_batch) or split the call over M"
                          % (max(x.numel() * x.element_size(), w.numel() * w.element_size()) / 2.0 ** 30))
+    if ksplit is not None:
+        nb = lib.mega_conv2d_nhwc_ks_workspace_bytes(N * Ho * Wo, Cout, R * S * Cin, _dt(x), int(ksplit))
+        ws = _ws(nb, x.device) if nb else None
+        rc = lib.mega_conv2d_nhwc_ks(_ptr(x), _ptr(w), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin,
+                                     Cout, R, S, stride, pad, dil, int(relu), Cout, Cout, _dt(x), _DT[odt], int(ksplit),
+                                     _ptr(ws), nb, _stream())
+        _pe(_tok)
+        _lib.check(rc, "mega_conv2d_nhwc_ks")
+        return out
     nb = lib.mega_conv2d_nhwc_workspace_bytes(N * Ho * Wo, Cout, R * S * Cin)     # > 0: long-K layer, split-K
     ws = _ws(nb, x.device) if nb else None
     rc = lib.mega_conv2d_nhwc_ws(_ptr(x), _ptr(w), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin,
@@ -175,6 +185,67 @@ def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil
                                  _stream())
     _pe(_tok)
     _lib.check(rc, "mega_conv2d_nhwc")
+    return out
+
+
+def pack_deconv4x4s2(wt, dtype, cin_mult):
+    """nn.ConvTranspose2d(Cin, C, 4, stride=2).weight [Cin,C,4,4] -> the sub-pixel conv's operand [4 C, 2, 2, Cin padded to
+    cin_mult]: w4[(a*2 + b)*C + co, r, s, ci] = wt[ci, co, a + 2 (1 - r), b + 2 (1 - s)]  (mega_conv2d_nhwc_subpixel)."""
+    Cin, C = wt.shape[:2]
+    cp = (Cin + cin_mult - 1) // cin_mult * cin_mult
+    w4 = torch.zeros((2, 2, C, 2, 2, cp), dtype=torch.float32)
+    wf = wt.detach().float().cpu()
+    for a in range(2):
+        for b in range(2):
+            for r in range(2):
+                for s_ in range(2):
+                    w4[a, b, :, r, s_, :Cin] = wf[:, :, a + 2 * (1 - r), b + 2 * (1 - s_)].t()
+    return w4.view(4 * C, 2, 2, cp).to(dtype).contiguous()
+
+
+def deconv4x4s2_into(x, w4, bias4, out, coff, relu=0, ksplit=1):
+    """crop_like(act(ConvTranspose2d(Cin, C, 4, stride=2)(x))) written to out[..., coff:coff + C] (flownet.py:9-13,:40-52,:94-111):
+    x [N,H,W,Cin] NHWC, w4 = pack_deconv4x4s2(weight), bias4 f32 [4 C] (the bias repeated four times) or None, out
+    [N,H2,W2,ldo] contiguous (the level's concatenation buffer); crop_like's rule: the full map is (2H+2) x (2W+2); when its
+    size differs from (H2, W2) one row / column is dropped at the top / left."""
+    _gpu(x, w4, bias4, out)
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    C = w4.shape[0] // 4
+    assert tuple(w4.shape) == (4 * C, 2, 2, Cin) and x.is_contiguous() and w4.is_contiguous() and out.is_contiguous()
+    assert x.dtype == w4.dtype == out.dtype and out.shape[0] == N
+    H2, W2, ldo = out.shape[1:]
+    crop = 0 if (2 * H + 2, 2 * W + 2) == (H2, W2) else 1
+    assert H2 + crop <= 2 * H + 2 and W2 + crop <= 2 * W + 2
+    M = N * (H + 1) * (W + 1)
+    _tok = _pb("deconv_subpixel", 2.0 * M * 4 * C * 4 * Cin, (x.numel() + w4.numel() + N * H2 * W2 * C) * x.element_size(),
+               detail="%dx%dx%d (2x2 sub-pixel)" % (M, 4 * C, 4 * Cin))
+    nb = lib.mega_conv2d_nhwc_ks_workspace_bytes(M, 4 * C, 4 * Cin, _dt(x), int(ksplit))
+    ws = _ws(nb, x.device) if nb else None
+    rc = lib.mega_conv2d_nhwc_subpixel(_ptr(x), _ptr(w4), _ptr(bias4), _ptr(out), N, H, W, Cin, C, int(relu), H2, W2, crop, ldo,
+                                       coff, _dt(x), int(ksplit), _ptr(ws), nb, _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_conv2d_nhwc_subpixel")
+    return out
+
+
+def flow_level_assemble(skip, flow, w_up, b_up, out, C):
+    """the rest of a FlowNetS refinement level's concatenation (mega_flow_level_assemble): out[..., :Cs] = skip,
+    out[..., Cs+C:Cs+C+2] = crop_like(ConvTranspose2d(2, 2, 4, stride=2)(flow)) from the f32 weights w_up [2,2,4,4] / b_up [2],
+    zeros up to out's channel stride; out[..., Cs:Cs+C] (the deconvolution's slice) is left alone."""
+    _gpu(skip, flow, w_up, b_up, out)
+    lib = _lib.load()
+    N, H2, W2, Cs = skip.shape
+    _, h, w, two = flow.shape
+    assert two == 2 and out.shape[:3] == skip.shape[:3] and flow.shape[0] == N
+    assert skip.is_contiguous() and flow.is_contiguous() and out.is_contiguous() and skip.dtype == flow.dtype == out.dtype
+    assert w_up.dtype == torch.float32 and tuple(w_up.shape) == (2, 2, 4, 4) and w_up.is_contiguous() and b_up.dtype == torch.float32
+    crop = 0 if (2 * h + 2, 2 * w + 2) == (H2, W2) else 1
+    _tok = _pb("flow_level_assemble", 0.0, (skip.numel() + N * H2 * W2 * (out.shape[3] - C)) * skip.element_size())
+    rc = lib.mega_flow_level_assemble(_ptr(skip), _ptr(flow), _ptr(w_up), _ptr(b_up), _ptr(out), N, H2, W2, Cs, C, out.shape[3],
+                                      h, w, crop, _dt(skip), _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_flow_level_assemble")
     return out
 
 

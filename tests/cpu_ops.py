@@ -14,7 +14,7 @@ from oracle import native
 
 
 def conv2d_nhwc(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False, out_dtype=None,
-                out=None):
+                out=None, ksplit=None):
     y = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=stride, padding=pad, dilation=dil)
     if scale is not None:
         y = y * scale.view(1, -1, 1, 1)
@@ -350,3 +350,29 @@ def install(monkeypatch):
     g = globals()
     for name in ALL:
         monkeypatch.setattr(ops, name, g[name])
+
+
+def deconv4x4s2_into(x, w4, bias4, out, coff, relu=0, ksplit=1):
+    """the sub-pixel GEMM's arithmetic: a 2 x 2 / pad 1 conv with (a, b, co) output columns, scattered to (2m + a - crop, 2n + b - crop)"""
+    N, H, W, _ = x.shape
+    C = w4.shape[0] // 4
+    H2, W2 = out.shape[1:3]
+    crop = 0 if (2 * H + 2, 2 * W + 2) == (H2, W2) else 1
+    y = conv2d_nhwc(x, w4, None, bias4, pad=1, relu=relu, out_dtype=torch.float32)          # [N,H+1,W+1,4C]
+    full = y.view(N, H + 1, W + 1, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H + 2, 2 * W + 2, C)
+    out[..., coff:coff + C] = full[:, crop:crop + H2, crop:crop + W2].to(out.dtype)
+    return out
+
+
+def flow_level_assemble(skip, flow, w_up, b_up, out, C):
+    N, H2, W2, Cs = skip.shape
+    h, w = flow.shape[1:3]
+    crop = 0 if (2 * h + 2, 2 * w + 2) == (H2, W2) else 1
+    up = F.conv_transpose2d(flow.float().permute(0, 3, 1, 2), w_up, b_up, stride=2).permute(0, 2, 3, 1)
+    out[..., :Cs] = skip
+    out[..., Cs + C:Cs + C + 2] = up[:, crop:crop + H2, crop:crop + W2].to(out.dtype)
+    out[..., Cs + C + 2:] = 0
+    return out
+
+
+ALL += ["deconv4x4s2_into", "flow_level_assemble"]

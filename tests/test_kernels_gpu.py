@@ -1226,3 +1226,66 @@ def test_conv_scale_bias_at_unaligned_addresses(dev):
     pa = ops.conv2d_sp(xp, w3, a_s, a_b, relu=True, out_mode="f32")
     pu = ops.conv2d_sp(xp, w3, u_s, u_b, relu=True, out_mode="f32")
     assert torch.equal(pa, pu)
+
+
+DECONV_CASES = [
+    # N, H, W, Cin (padded to the K vector), C, H2, W2 (the skip connection's size), Cs, ksplit
+    (2, 5, 8, 1024, 512, 10, 16, 512, 1),        # deconv5 at 600 x 1000 (even target: one row / column cropped)
+    (3, 10, 16, 1026, 256, 19, 32, 512, 1),      # deconv4: Cin zero-padded, odd target height
+    (2, 7, 9, 770, 128, 13, 17, 256, 3),         # odd x odd target, split-K
+    (1, 4, 6, 386, 64, 10, 14, 128, 1),          # target = the full (2H+2) x (2W+2) map: crop_like keeps everything
+    (21, 5, 8, 1024, 512, 10, 16, 512, 4),       # the 21-pair window, split-K
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_deconv_subpixel_and_level_assemble_vs_torch(dev, case, dtype):
+    """ops.deconv4x4s2_into + ops.flow_level_assemble (a FlowNetS refinement level's concatenation,
+    mega_core/modeling/backbone/flownet.py:9-13,:40-52,:94-111) against F.conv_transpose2d + crop_like + torch.cat in f32 on the
+    rounded operands.  f32: 1e-4 of the output scale (summation order); 16-bit: one output rounding (2^-8 / 2^-10) + the order."""
+    ops = _ops()
+    N, H, W, Cin, C, H2, W2, Cs, ks = case
+    mult = 32 if dtype == torch.float32 else 64
+    g = torch.Generator().manual_seed(hash(case) % 997)
+    x = torch.randn((N, H, W, Cin), generator=g).to(dtype)
+    wt = torch.randn((Cin, C, 4, 4), generator=g) / math.sqrt(Cin * 4.0)
+    b = torch.randn((C,), generator=g) * 0.1
+    skip = torch.randn((N, H2, W2, Cs), generator=g).to(dtype)
+    flow = torch.randn((N, H, W, 2), generator=g).to(dtype)
+    wu = torch.randn((2, 2, 4, 4), generator=g) * 0.3
+    bu = torch.randn((2,), generator=g) * 0.1
+    crop = 0 if (2 * H + 2, 2 * W + 2) == (H2, W2) else 1
+    full = F.leaky_relu(F.conv_transpose2d(x.float().permute(0, 3, 1, 2), wt.to(dtype).float(), b, stride=2), 0.1)
+    dec = full[:, :, crop:crop + H2, crop:crop + W2].permute(0, 2, 3, 1)
+    up = F.conv_transpose2d(flow.float().permute(0, 3, 1, 2), wu, bu, stride=2)[:, :, crop:crop + H2, crop:crop + W2].permute(0, 2, 3, 1)
+    cp = (Cin + mult - 1) // mult * mult
+    xp = torch.zeros((N, H, W, cp), dtype=dtype)
+    xp[..., :Cin] = x
+    w4 = ops.pack_deconv4x4s2(wt, dtype, mult)
+    ldo = (Cs + C + 2 + mult - 1) // mult * mult
+    out = torch.full((N, H2, W2, ldo), float("nan"), dtype=dtype, device=dev)
+    ops.deconv4x4s2_into(xp.to(dev), w4.to(dev), b.repeat(4).to(dev), out, Cs, relu=2, ksplit=ks)
+    ops.flow_level_assemble(skip.to(dev), flow.to(dev), wu.to(dev), bu.to(dev), out, C)
+    got = out.float().cpu()
+    assert torch.equal(got[..., :Cs], skip.float()), "skip connection not copied bit for bit"
+    assert torch.equal(got[..., Cs + C + 2:], torch.zeros((N, H2, W2, ldo - Cs - C - 2))), "padding channels not zero"
+    eps = {torch.float32: 1e-4, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -9}[dtype]
+    for name, a, r in (("deconv", got[..., Cs:Cs + C], dec), ("flow up-sampling", got[..., Cs + C:Cs + C + 2], up)):
+        err = (a - r).abs().max().item()
+        assert err <= eps * r.abs().max().item(), "%s: max |d| %.3g against scale %.3g" % (name, err, r.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv2d_caller_split_k(dev, dtype):
+    """mega_conv2d_nhwc_ks: a small-M / long-K conv with 1, 2, 5 and more K ranges than K-tiles (clamped) against F.conv2d."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((2, 5, 8, 512), generator=g).to(dtype)
+    w = (torch.randn((96, 3, 3, 512), generator=g) / math.sqrt(512 * 9.0)).to(dtype)
+    bias = torch.randn((96,), generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1), 0.1).permute(0, 2, 3, 1)
+    eps = 1e-4 if dtype == torch.float32 else 2.0 ** -7
+    for ks in (1, 2, 5, 1000):
+        y = ops.conv2d_nhwc(x.to(dev), w.to(dev), None, bias.to(dev), pad=1, relu=2, ksplit=ks).float().cpu()
+        assert (y - ref).abs().max().item() <= eps * ref.abs().max().item(), "ksplit %d" % ks
