@@ -427,6 +427,14 @@ int mega_conv2d_nhwc_subpixel(const void* in, const void* w4, const float* bias4
 int mega_flow_level_assemble(const void* skip, const void* flow, const float* w_up, const float* b_up, void* out, int N,
                              int H2, int W2, int Cs, int C, int ldo, int h, int w, int crop, int dtype, void* stream);
 
+/* FlowNetS flow prediction (flownet.py:40-52 Convolution1..5 = nn.Conv2d(Cin, 2, 3, padding=1)), second half: by linearity the
+ * 3 x 3 conv with two output channels is a 1 x 1 conv with 18 columns z[p][(r*3 + s)*2 + c] = sum_ci x[p][ci] w[c][ci][r][s]
+ * (mega_conv2d_nhwc, f32 output: one pass over x, K = Cin instead of 9 Cin on 64-wide tiles) followed by
+ *   out[t][y][x][c] = (sum_{r,s} z[t][y+r-1][x+s-1][(r*3+s)*2 + c]) * scale + bias[c]     (f32, taps outside the map skipped).
+ * z f32 [N][H][W][ldz], ldz >= 18 and even; bias f32 [2]; out [N][H][W][2] of out_dtype (MEGA_F32 / MEGA_BF16 / MEGA_F16). */
+int mega_flow_pred_finish(const float* z, int ldz, const float* bias, float scale, void* out, int N, int H, int W,
+                          int out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

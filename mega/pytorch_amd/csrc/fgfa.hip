@@ -571,3 +571,46 @@ extern "C" int mega_flow_level_assemble(const void* skip, const void* flow, cons
                        w_up, b_up, (float*)out, N, H2, W2, Cs, C, ldo, h, w, crop);
   return mega_check_launch();
 }
+
+// ---- FlowNetS flow prediction (flownet.py:40-52 Convolution1..5: nn.Conv2d(Cin, 2, 3, padding=1)), second half.  A 3 x 3 conv
+// with TWO output channels on 64-wide GEMM tiles spends 32x its products on padding columns; by linearity it is a 1 x 1 conv
+// with 18 columns -- z[p][(r*3 + s)*2 + c] = sum_ci x[p][ci] w[c][ci][r][s], ONE pass over x, K = Cin instead of 9 Cin, f32
+// output (mega_conv2d_nhwc) -- followed by this kernel: flow[t][y][x][c] = (sum_{r,s} z[t][y+r-1][x+s-1][(r*3+s)*2 + c]) * scale
+// + bias[c], taps outside the map skipped (zero padding), summed in f32 in (r, s) order.
+template <typename OT>
+__global__ __launch_bounds__(256) void flow_pred_finish_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ bias,
+                                                               float scale, OT* __restrict__ out, int N, int H, int W) {
+  const long long total = (long long)N * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int yy = y + r - 1, xx = x + s - 1;
+        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+        const float2 v = *reinterpret_cast<const float2*>(z + (i + (long long)(r - 1) * W + (s - 1)) * ldz + (r * 3 + s) * 2);
+        a0 += v.x;
+        a1 += v.y;
+      }
+    Elem<OT>::st(out + i * 2, fmaf(a0, scale, bias[0]));
+    Elem<OT>::st(out + i * 2 + 1, fmaf(a1, scale, bias[1]));
+  }
+}
+
+/* see flow_pred_finish_kernel.  z f32 [N][H][W][ldz] (ldz >= 18, even), bias f32 [2] (already multiplied by `scale` if the
+ * caller wants (conv + b) * scale), out [N][H][W][2] of out_dtype (MEGA_F32 / BF16 / F16). */
+extern "C" int mega_flow_pred_finish(const float* z, int ldz, const float* bias, float scale, void* out, int N, int H, int W,
+                                     int out_dtype, void* stream) {
+  mega_clear_error();
+  if (!z || !bias || !out || N <= 0 || H <= 0 || W <= 0 || ldz < 18 || (ldz & 1) || (reinterpret_cast<size_t>(z) & 7)) return MEGA_ERR_ARG;
+  const long long total = (long long)N * H * W;
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == MEGA_F32) hipLaunchKernelGGL((flow_pred_finish_kernel<float>), dim3(blocks), dim3(256), 0, st, z, ldz, bias, scale, (float*)out, N, H, W);
+  else if (out_dtype == MEGA_BF16) hipLaunchKernelGGL((flow_pred_finish_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, ldz, bias, scale, (bf16_t*)out, N, H, W);
+  else if (out_dtype == MEGA_F16) hipLaunchKernelGGL((flow_pred_finish_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, z, ldz, bias, scale, (f16_t*)out, N, H, W);
+  else return MEGA_ERR_ARG;
+  return mega_check_launch();
+}

@@ -108,6 +108,13 @@ class FlowNetS(_Packed):
             mod = getattr(self, name)
             w = mod.weight.detach().permute(1, 0, 2, 3).flip(2, 3)      # [in,out,kh,kw] -> conv kernel [out,in,kh,kw]
             pk[name] = (_pack_w(w, dtype, m).to(device), mod.bias.detach().float().to(device).contiguous())
+        pk["Convolution5.b2.5"] = self.Convolution5.bias.detach().float().to(device).contiguous() * 2.5
+        for name, _ in self.PREDS:           # Conv2d(Cin, 2, 3, padding=1) as a 1 x 1 conv with 18 (tap, channel) columns (of 64)
+            mod = getattr(self, name)
+            w = mod.weight.detach().float()                                  # [2, Cin, 3, 3]
+            w18 = torch.zeros((64, 1, 1, w.shape[1]), dtype=torch.float32)
+            w18[:18, 0, 0] = w.permute(2, 3, 0, 1).reshape(18, w.shape[1])   # row (r*3 + s)*2 + c
+            pk[name + ".18"] = (_padc(w18, m).to(dtype).to(device).contiguous(), mod.bias.detach().float().to(device).contiguous())
         for name, _, co in self.DECONVS:     # the sub-pixel form: [4 C, 2, 2, Cin] + the bias once per phase
             mod = getattr(self, name)
             pk[name + ".sp"] = (ops.pack_deconv4x4s2(mod.weight, dtype, m).to(device),
@@ -130,13 +137,21 @@ class FlowNetS(_Packed):
             pk["flow_conv1_taps"] = wt.to(dtype).to(device).contiguous()
         return pk
 
-    def _conv(self, pk, name, x, act=2):
+    def _conv(self, pk, name, x, act=2, ksplit=None):
         w, b, s, p = pk[name]
-        return ops.conv2d_nhwc(_padc(x, pk["m"]), w, None, b, stride=s, pad=p, relu=act)
+        return ops.conv2d_nhwc(_padc(x, pk["m"]), w, None, b, stride=s, pad=p, relu=act, ksplit=ksplit)
 
-    def _pred(self, pk, name, x):
+    def _pred(self, pk, name, x, scale=1.0, out_dtype=None):
+        """flow prediction * scale: [N,H,W,2]"""
+        if self.subpixel:      # one pass over x for the 18 (tap, channel) partial maps in f32, then the shifted sum
+            w18, b = pk[name + ".18"]
+            z = ops.conv2d_nhwc(x, w18, None, None, out_dtype=torch.float32)
+            return ops.flow_pred_finish(z, pk[name + ".b2.5"] if scale == 2.5 else (b * scale if scale != 1.0 else b), scale,
+                                        out_dtype or x.dtype)
         w, b = pk[name]
-        return ops.conv2d_nhwc(x, w, None, b, pad=1, relu=0)
+        if scale != 1.0:
+            return ops.conv2d_nhwc(x, w, pk["x2.5"] * (scale / 2.5), b * scale, pad=1, relu=0, out_dtype=out_dtype)
+        return ops.conv2d_nhwc(x, w, None, b, pad=1, relu=0, out_dtype=out_dtype)
 
     def _deconv(self, pk, name, x, act):
         w, b = pk[name]
@@ -184,7 +199,7 @@ class FlowNetS(_Packed):
         r7 = self._conv(pk, "conv5", r6)
         r8 = self._conv(pk, "conv5_1", r7)
         r9 = self._conv(pk, "conv6", r8)
-        r10 = self._conv(pk, "conv6_1", r9)
+        r10 = self._conv(pk, "conv6_1", r9, ksplit=4 if self.subpixel else None)    # 840 rows x K = 9216: 53 -> 39 us
 
         def level(feat_in, skip, pred_name, up_name, deconv_name):
             flow = self._pred(pk, pred_name, feat_in)                       # [.,.,.,2]
@@ -203,8 +218,7 @@ class FlowNetS(_Packed):
         c4 = level(c3, r4, "Convolution3", "upsample_flow4to3", "deconv3")
         c5 = level(c4, r2, "Convolution4", "upsample_flow3to2", "deconv2")
         c5 = ops.avgpool2x2_ceil(c5)
-        w, b = pk["Convolution5"]                                            # Convolution5 * 2.5 (flownet.py:118)
-        flow = ops.conv2d_nhwc(c5, w, pk["x2.5"], b * 2.5, pad=1, relu=0, out_dtype=torch.float32)
+        flow = self._pred(pk, "Convolution5", c5, 2.5, torch.float32)       # Convolution5 * 2.5 (flownet.py:118)
         flow = flow.permute(0, 3, 1, 2).contiguous()
         if self.method == "dff":          # Convolution5_scale + 1 (flownet.py:112-116), NHWC [T,h,w,1024]
             return flow, ops.conv2d_nhwc(c5, pk["scale_w"], None, pk["ones"], relu=0)
@@ -270,16 +284,28 @@ class ResNetConv52MLPFeatureExtractor(_Packed):
             pk["rc_b"] = self.conv.bias.detach().float().to(device).contiguous()
         return pk
 
-    def forward(self, x, proposals):
+    FC6_KSPLIT = 24      # fc6 on <= 300 rows, K = 100352: 211 us with the library's 3 ranges, 120 us with 24 (tools/gpu/ksplit_sweep.py)
+
+    def full_map(self, x):
+        """res5 (+ the 1x1 reduce conv) on the whole map: needs no proposals (the engine runs it beside the RPN selection)"""
         feat = _nhwc(x[0] if isinstance(x, (list, tuple)) else x)
         pk = self._packed(feat.dtype, feat.device)
         y = self.head.run(feat)
         if self.conv is not None:
             y = ops.conv2d_nhwc(y, pk["rc_w"], None, pk["rc_b"], relu=True)
+        return y
+
+    def pooled_fc(self, y, proposals):
+        pk = self._packed(y.dtype, y.device)
         pooled = ops.roi_align(y, convert_to_roi_format(proposals), self.scale, (self.resolution, self.resolution),
                                self.sampling_ratio)
-        h = ops.linear(pooled.view(pooled.shape[0], -1), pk["w6"], pk["b6"], relu=True)
+        # split-K chosen by K alone (the rows of a batch keep their bits whatever the batch): long-K fc6 only
+        ks = self.FC6_KSPLIT if pk["w6"].shape[1] >= 32768 else None
+        h = ops.linear(pooled.view(pooled.shape[0], -1), pk["w6"], pk["b6"], relu=True, ksplit=ks)
         return ops.linear(h, pk["w7"], pk["b7"], relu=True)
+
+    def forward(self, x, proposals):
+        return self.pooled_fc(self.full_map(x), proposals)
 
 
 class ROIBoxHead(nn.Module):
@@ -314,6 +340,7 @@ class GeneralizedRCNNFGFA(nn.Module):
         self.flownet._dtype = self.dtype
         self.embednet = EmbedNet(cfg)
         self.rpn = build_rpn(cfg, self.backbone.out_channels)
+        self.rpn.head.conv_ksplit = 4        # one frame per call: see RPNHead.conv_ksplit
         self.roi_heads = CombinedROIHeads(cfg, [("box", ROIBoxHead(cfg, self.backbone.out_channels))])
         self.all_frame_interval = cfg.MODEL.VID.FGFA.ALL_FRAME_INTERVAL
         self.key_frame_location = cfg.MODEL.VID.FGFA.KEY_FRAME_LOCATION
@@ -398,6 +425,7 @@ class GeneralizedRCNN(nn.Module):
         self.dtype = compute_dtype(cfg)
         self.backbone = build_backbone(cfg)
         self.rpn = build_rpn(cfg, self.backbone.out_channels)
+        self.rpn.head.conv_ksplit = 4        # one frame per call: see RPNHead.conv_ksplit
         self.roi_heads = CombinedROIHeads(cfg, [("box", ROIBoxHead(cfg, self.backbone.out_channels))])
         self.eval()
 
@@ -437,6 +465,7 @@ class GeneralizedRCNNDFF(nn.Module):
         self.flownet = FlowNetS(cfg)
         self.flownet._dtype = self.dtype
         self.rpn = build_rpn(cfg, self.backbone.out_channels)
+        self.rpn.head.conv_ksplit = 4        # one frame per call: see RPNHead.conv_ksplit
         self.roi_heads = CombinedROIHeads(cfg, [("box", ROIBoxHead(cfg, self.backbone.out_channels))])
         self.key_images = None
         self.key_feats = None
@@ -488,8 +517,10 @@ class FgfaClipEngine(object):
         post-processor) -- is ONE hipGraph replayed per key frame; detection counts are read a batch of steps later.
     Detections are identical to `model(images)` frame by frame (tests/test_e2e_gpu.py::test_fgfa_engine_equals_model)."""
 
-    def __init__(self, model, lookahead=20, graphs=True):
+    def __init__(self, model, lookahead=20, graphs=True, pipeline=True):
         self.m = model
+        self.pipeline = pipeline             # the key frame as two graphs on two streams (see _step); False: one graph
+        self._sb = None
         self.T = model.all_frame_interval
         self.key = model.key_frame_location
         self.ahead = self.T - self.key - 1
@@ -524,24 +555,47 @@ class FgfaClipEngine(object):
         ent["graph"].replay()
         return ent["out"].clone()
 
-    # ---- one key frame on the ring state (this body is what the graph captures)
-    def _body(self, size):
+    # ---- one key frame on the ring state, in two halves (these bodies are what the graphs capture)
+    def _body_a(self):
+        """FlowNetS on the window's pairs + flow-guided aggregation -> the aggregated C4 map [h,w,1024]"""
         m = self.m
-        W, H = size
-        T = self.T
         flow = m.flownet.pairs(self.img_ring, None, m.dtype, order=self.order)     # the key frame = ring slot order[0]
         nfeat = m.backbone.out_channels
         agg = ops.fgfa_warp_aggregate(self.feat_ring, flow, nfeat, 0, order=self.order)
+        if self.keep_intermediates:
+            self._dbg_a = (flow, agg)
+        return agg
+
+    def _body_b(self, agg, size):
+        """RPN + conv5 box head + post-processing on the aggregated map"""
+        m = self.m
+        W, H = size
         feats = (_nchw_view(agg.unsqueeze(0)),)
-        props, _, cnt = m.rpn.propose(_nhwc(feats[0]), W, H, "key")
         box = m.roi_heads.box
-        x = box.feature_extractor(feats, [props[0]])
+        fe = box.feature_extractor
+        if agg.is_cuda and not ops.profiling():
+            # the proposal selection is ONE block (top-k, decode, NMS of one frame: ~0.38 ms on 1 of 256 CUs) and res5 on the
+            # whole map does not need its result: fork it to a side stream, join before ROIAlign
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=agg.device)
+            hold = []
+            props, _, cnt = m.rpn.propose(_nhwc(feats[0]), W, H, "key", select_stream=self._side, hold=hold)
+            y = fe.full_map(feats)
+            torch.cuda.current_stream(agg.device).wait_stream(self._side)
+            del hold
+            x = fe.pooled_fc(y, [props[0]])
+        else:
+            props, _, cnt = m.rpn.propose(_nhwc(feats[0]), W, H, "key")
+            x = fe(feats, [props[0]])
         logits, deltas = box.predictor(x)
         pp = box.post_processor
         if self.keep_intermediates:
-            self._dbg = (flow, agg, props, logits, deltas, x, cnt)
+            self._dbg = self._dbg_a + (props, logits, deltas, x, cnt)
         return ops.postprocess(logits.float().contiguous(), deltas.float().contiguous(), props[0].contiguous(), cnt,
                                pp.weights, W, H, pp.score_thresh, pp.nms, pp.detections_per_img, pp.strict_gt)
+
+    def _body(self, size):
+        return self._body_b(self._body_a(), size)
 
     def _step(self, size):
         if not (self.use_graphs and self.img_ring.is_cuda):
@@ -549,15 +603,51 @@ class FgfaClipEngine(object):
         if self.graph is None:
             self.graph = "armed"
             return self._body(size)
+        cur = torch.cuda.current_stream()
+        if not self.pipeline:
+            if self.graph == "armed":
+                cur.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._out = self._body(size)
+                self.graph = g
+            self.graph.replay()
+            self.replays += 1
+            return tuple(t.clone() for t in self._out)
+        # Two graphs per key frame on two streams: A (FlowNetS + warp: whole-chip GEMMs) on the current stream, B (RPN, box head,
+        # post-processing: ~0.8 ms of one-block kernels and GEMMs on 2394 / 300 rows that fill a fraction of the chip) on a
+        # second stream, so that B of key frame k runs BESIDE A of key frame k + 1.  B reads its own copy of the aggregated map
+        # (5 MB, made on B's stream right after A); A's next replay waits for that copy only.  The graphs replay concurrently:
+        # each has its own memory pool (torch's default for separately captured graphs).
         if self.graph == "armed":
-            torch.cuda.current_stream().synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._out = self._body(size)
-            self.graph = g
-        self.graph.replay()
+            cur.synchronize()
+            if self._sb is None:
+                self._sb = torch.cuda.Stream(device=self.img_ring.device)
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                self._agg_out = self._body_a()
+            self._agg_in = self._agg_out.clone()
+            cur.synchronize()
+            with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                self._out = self._body_b(self._agg_in, size)
+            self.graph = (ga, gb)
+            self._ea, self._ec = torch.cuda.Event(), torch.cuda.Event()
+            self._ec.record(cur)
+        ga, gb = self.graph
+        cur.wait_event(self._ec)              # B's copy of the previous aggregated map is done
+        ga.replay()
+        self._ea.record(cur)
+        sb = self._sb
+        sb.wait_event(self._ea)
+        with torch.cuda.stream(sb):
+            self._agg_in.copy_(self._agg_out)
+            self._ec.record(sb)
+            gb.replay()
+            outs = tuple(t.clone() for t in self._out)
+        for t in outs:
+            t.record_stream(cur)              # read on the current stream after the join in run()'s flush
         self.replays += 1
-        return tuple(t.clone() for t in self._out)
+        return outs
 
     @torch.no_grad()
     def run(self, frames, first=0, last=None, sync_every=16):
@@ -574,6 +664,8 @@ class FgfaClipEngine(object):
         def flush():
             if not pending:
                 return
+            if self._sb is not None:
+                torch.cuda.current_stream().wait_stream(self._sb)     # (the second halves of the pending key frames)
             counts = torch.cat([p[3] for p in pending]).tolist()
             for (ob, os_, ol, _), n in zip(pending, counts):
                 out.append(PostProcessor.materialize((ob, os_, ol, None), int(n), (W, H)))

@@ -494,6 +494,9 @@ class RPNHead(_Packed):
                 "w2": w2.permute(0, 2, 3, 1).contiguous().to(dtype).to(device), "b2": b2.float().to(device).contiguous()}
 
     sp_mode = None     # "x3" / "wide" when the backbone hands over C4 as ops.Planes (set by RPNWithRefModule)
+    conv_ksplit = None  # the 3x3 conv's caller-chosen split-K (ops.conv2d_nhwc): set by the ONE-frame detectors (FGFA / DFF /
+                        # base: 2394 rows x K = 9216 on 64 x 64 tiles, 94 -> 63 us with 4 K ranges); MEGA's batched frame
+                        # stage never sets it (a frame's bits must not depend on the batch it is computed in)
 
     def run(self, feat_nhwc):
         """-> [B, H*W, 5A] f32 (channel a = objectness of anchor a, A + 4a + j = delta j)."""
@@ -505,7 +508,7 @@ class RPNHead(_Packed):
             B, H, W, C = o.shape
             return o.view(B, H * W, C)
         pk = self._packed(feat_nhwc.dtype, feat_nhwc.device)
-        t = ops.conv2d_nhwc(feat_nhwc, pk["w1"], None, pk["b1"], pad=1, relu=True)
+        t = ops.conv2d_nhwc(feat_nhwc, pk["w1"], None, pk["b1"], pad=1, relu=True, ksplit=self.conv_ksplit)
         o = ops.conv2d_nhwc(t, pk["w2"], None, pk["b2"], out_dtype=torch.float32)
         B, H, W, C = o.shape
         return o.view(B, H * W, C)
@@ -539,15 +542,22 @@ class RPNWithRefModule(nn.Module):
             self.head.sp_mode = conv_mode(cfg)
         self.keep_index = False       # tests: frame records also carry the kept proposals' flat anchor indices
 
-    def propose(self, feat_nhwc, im_w, im_h, version="key", want_index=False):
+    def propose(self, feat_nhwc, im_w, im_h, version="key", want_index=False, select_stream=None, hold=None):
         """Batched, sync-free: -> (proposals [B,post,4], objectness [B,post], counts [B] i32[, anchor index [B,post] i32])
-        on device."""
+        on device.  select_stream: the selection kernels (one block per frame: top-k, decode, NMS) are launched on that
+        stream, forked from the current one after the head's convs; the CALLER joins (current.wait_stream(select_stream))
+        before it reads the results and keeps `hold` (a list that receives the workspace) alive until then."""
         rpn_out = self.head.run(feat_nhwc)
         B, H, W, _ = feat_nhwc.shape
         cell = next(iter(self.anchor_generator.cell_anchors)).to(feat_nhwc.device).float().contiguous()
-        return ops.rpn_select(rpn_out, cell, H, W, self.anchor_generator.strides[0], self.pre_nms_top_n[version],
-                              self.post_nms_top_n[version], self.nms_thresh, self.min_size, im_w, im_h, self.strict_gt,
-                              want_index=want_index)
+        if select_stream is not None:
+            select_stream.wait_stream(torch.cuda.current_stream(feat_nhwc.device))
+            if hold is not None:
+                hold.append(rpn_out)
+        with ops.launch_on(select_stream):
+            return ops.rpn_select(rpn_out, cell, H, W, self.anchor_generator.strides[0], self.pre_nms_top_n[version],
+                                  self.post_nms_top_n[version], self.nms_thresh, self.min_size, im_w, im_h, self.strict_gt,
+                                  want_index=want_index, hold=hold)
 
     def forward(self, images, features, targets=None, version="key"):
         if self.training:

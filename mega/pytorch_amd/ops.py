@@ -229,6 +229,21 @@ def deconv4x4s2_into(x, w4, bias4, out, coff, relu=0, ksplit=1):
     return out
 
 
+def flow_pred_finish(z, bias, scale, out_dtype):
+    """second half of a FlowNetS flow prediction (mega_flow_pred_finish): z f32 [N,H,W,ldz] = the 1 x 1 conv of the level's map
+    with the 18 (tap, channel) columns of Conv2d(Cin, 2, 3, padding=1) -> [N,H,W,2] = (sum of the shifted taps) * scale + bias."""
+    _gpu(z, bias)
+    lib = _lib.load()
+    N, H, W, ldz = z.shape
+    assert z.dtype == torch.float32 and z.is_contiguous() and bias.dtype == torch.float32 and bias.numel() == 2
+    out = torch.empty((N, H, W, 2), dtype=out_dtype, device=z.device)
+    _tok = _pb("flow_pred_finish", 0.0, N * H * W * (18 * 4.0 + 2 * out.element_size()))
+    rc = lib.mega_flow_pred_finish(_ptr(z), ldz, _ptr(bias), float(scale), _ptr(out), N, H, W, _DT[out_dtype], _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_flow_pred_finish")
+    return out
+
+
 def flow_level_assemble(skip, flow, w_up, b_up, out, C):
     """the rest of a FlowNetS refinement level's concatenation (mega_flow_level_assemble): out[..., :Cs] = skip,
     out[..., Cs+C:Cs+C+2] = crop_like(ConvTranspose2d(2, 2, 4, stride=2)(flow)) from the f32 weights w_up [2,2,4,4] / b_up [2],
@@ -300,15 +315,15 @@ def bottleneck64_ds(x, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, bd):
     return out
 
 
-def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None):
-    """x [M,K], w [Nout,K] (nn.Linear layout) -> [M,Nout]."""
+def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None, ksplit=None):
+    """x [M,K], w [Nout,K] (nn.Linear layout) -> [M,Nout].  ksplit: the caller's split-K count (conv2d_nhwc)."""
     if isinstance(w, X3Weight):      # split-precision: f32 in, f32 out
         assert x.dtype == torch.float32 and residual is None and scale is None and out_dtype in (None, torch.float32)
         return linear_sp(split_planes(x.contiguous()), w.w3, bias, relu=relu)
     M, K = x.shape
     y = conv2d_nhwc(x.view(M, 1, 1, K), w.view(w.shape[0], 1, 1, K), scale=scale, bias=bias,
                     residual=None if residual is None else residual.view(M, 1, 1, -1), relu=relu,
-                    out_dtype=out_dtype)
+                    out_dtype=out_dtype, ksplit=ksplit)
     return y.view(M, w.shape[0])
 
 
@@ -468,9 +483,11 @@ def nms(dets, scores, thr, strict_gt=True):
 
 
 def rpn_select(rpn_out, cell_anchors, Hf, Wf, anchor_stride, pre_nms, post_nms, nms_thresh, min_size, im_w, im_h,
-               strict_gt=True, want_index=False):
+               strict_gt=True, want_index=False, hold=None):
     """rpn_out [B,Hf*Wf,5A] f32 -> proposals [B,post_nms,4], scores [B,post_nms], counts [B] (all on device).
-    want_index: also the kept proposals' flat anchor indices (y*Wf + x)*A + a, [B,post_nms] i32, -1 past the count."""
+    want_index: also the kept proposals' flat anchor indices (y*Wf + x)*A + a, [B,post_nms] i32, -1 past the count.
+    hold (a list): the workspace is appended to it -- a caller that launches this on a side stream (launch_on) keeps it
+    alive until the streams have joined, so that the allocator cannot hand the block to the current stream's next op."""
     _gpu(rpn_out, cell_anchors)
     lib = _lib.load()
     B = rpn_out.shape[0]
@@ -493,6 +510,8 @@ def rpn_select(rpn_out, cell_anchors, Hf, Wf, anchor_stride, pre_nms, post_nms, 
                                  _ptr(props), _ptr(scores), _ptr(cnt), _ptr(index), _ptr(ws), nb, _stream())
     _pe(_tok)
     _lib.check(rc, "mega_rpn_select")
+    if hold is not None:
+        hold.append(ws)
     return (props, scores, cnt, index) if want_index else (props, scores, cnt)
 
 

@@ -39,7 +39,7 @@ def _w32(w):
     return w
 
 
-def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None):
+def linear(x, w, bias=None, relu=False, residual=None, out_dtype=None, scale=None, ksplit=None):
     w = _w32(w)
     M, K = x.shape
     y = conv2d_nhwc(x.view(M, 1, 1, K), w.view(w.shape[0], 1, 1, K), scale=scale, bias=bias,
@@ -85,7 +85,7 @@ def nms(dets, scores, thr, strict_gt=True):
 
 
 def rpn_select(rpn_out, cell_anchors, Hf, Wf, anchor_stride, pre_nms, post_nms, nms_thresh, min_size, im_w, im_h,
-               strict_gt=True, want_index=False):
+               strict_gt=True, want_index=False, hold=None):
     B = rpn_out.shape[0]
     A = cell_anchors.shape[0]
     anchors = mo.grid_anchors(cell_anchors, Hf, Wf, anchor_stride)
@@ -375,4 +375,14 @@ def flow_level_assemble(skip, flow, w_up, b_up, out, C):
     return out
 
 
-ALL += ["deconv4x4s2_into", "flow_level_assemble"]
+def flow_pred_finish(z, bias, scale, out_dtype):
+    N, H, W, _ = z.shape
+    zp = F.pad(z, (0, 0, 1, 1, 1, 1))
+    acc = torch.zeros((N, H, W, 2))
+    for r in range(3):
+        for s in range(3):
+            acc = acc + zp[:, r:r + H, s:s + W, (r * 3 + s) * 2:(r * 3 + s) * 2 + 2]
+    return (acc * scale + bias.view(1, 1, 1, 2)).to(out_dtype)
+
+
+ALL += ["deconv4x4s2_into", "flow_level_assemble", "flow_pred_finish"]
