@@ -435,6 +435,15 @@ int mega_flow_level_assemble(const void* skip, const void* flow, const float* w_
 int mega_flow_pred_finish(const float* z, int ldz, const float* bias, float scale, void* out, int N, int H, int W,
                           int out_dtype, void* stream);
 
+/* FlowNetS flow_conv1 (flownet.py:52,:56: Conv2d(6, 64, 7, stride 2) + LeakyReLU(0.1) on cat([key, frame_t]) / 255) per FRAME
+ * instead of per pair: the conv is linear before its activation, so conv(pair) = conv_key(key frame) + conv_ref(frame_t); both
+ * halves [A | B] of a frame are computed once, when it enters the window (mega_conv2d_nhwc with 128 output channels over that
+ * frame's tap operand, f32 out), and a key frame's 21 pairs are  out[t][p][c] = leaky(A[key][p][c] + B[t][p][c] + bias[c]).
+ * ab f32 [S][P][128]; bias f32 [64]; order (device int; NULL: use `key`): order[0] = slot of the key frame; out [T][P][64] of
+ * dtype (MEGA_BF16 / MEGA_F16), pair t = (key frame, the frame in slot t). */
+int mega_flow_conv1_combine(const float* ab, const float* bias, const int* order, int key, void* out, int T, long long P,
+                            int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

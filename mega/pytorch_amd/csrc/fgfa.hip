@@ -614,3 +614,59 @@ extern "C" int mega_flow_pred_finish(const float* z, int ldz, const float* bias,
   else return MEGA_ERR_ARG;
   return mega_check_launch();
 }
+
+// ---- FlowNetS flow_conv1 per FRAME instead of per pair (round 6).  flow_conv1 (flownet.py:52,:56: Conv2d(6, 64, 7, stride 2) +
+// LeakyReLU(0.1)) is linear before its activation, and its input is cat([key, frame_t]): conv(pair) = conv_key(key frame) +
+// conv_ref(frame_t).  Both halves depend on ONE frame, so they are computed once when a frame enters the window (a conv with
+// 128 output channels [A | B] over that frame's tap operand, f32 out) instead of 21 times per key frame; what is left per key
+// frame is this kernel:  out[t][p][c] = leaky(A[key][p][c] + B[t][p][c] + bias[c]),  one 16-byte vector of 8 channels per thread.
+// ab f32 [S][P][128] (A = channels 0..63, B = 64..127); key: slot of the key frame (order ? order[0] : key).
+template <typename HT>
+__global__ __launch_bounds__(256) void flow_conv1_combine_kernel(const float* __restrict__ ab, const float* __restrict__ bias,
+                                                                 const int* __restrict__ order, int key, unsigned short* __restrict__ out,
+                                                                 int T, long long P) {
+  const long long total = (long long)T * P * 8;
+  const int ks = order ? order[0] : key;
+  const int v = threadIdx.x & 7;
+  float bi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bi[e] = bias[v * 8 + e];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long px = i >> 3;                 // t * P + p
+    const long long p = px % P;
+    const float4* a = reinterpret_cast<const float4*>(ab + ((long long)ks * P + p) * 128 + v * 8);
+    const float4* b = reinterpret_cast<const float4*>(ab + px * 128 + 64 + v * 8);
+    const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    float x[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+    u32x4_t o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float y0 = x[2 * d] + bi[2 * d], y1 = x[2 * d + 1] + bi[2 * d + 1];
+      y0 = y0 > 0.f ? y0 : y0 * 0.1f;
+      y1 = y1 > 0.f ? y1 : y1 * 0.1f;
+      o[d] = Half16<HT>::pack2(y0, y1);
+    }
+    *reinterpret_cast<u32x4_t*>(out + px * 64 + v * 8) = o;
+  }
+}
+
+/* see flow_conv1_combine_kernel.  ab f32 [S][P][128] with S >= T frames' [A | B] halves (mega_conv2d_nhwc, f32 output);
+ * bias f32 [64]; order (device int, NULL: use `key`): order[0] = slot of the key frame; out [T][P][64] of dtype
+ * (MEGA_BF16 / MEGA_F16): pair t = (key frame, frame in slot t). */
+extern "C" int mega_flow_conv1_combine(const float* ab, const float* bias, const int* order, int key, void* out, int T,
+                                       long long P, int dtype, void* stream) {
+  mega_clear_error();
+  if (!ab || !bias || !out || T <= 0 || P <= 0 || (!order && key < 0) || (reinterpret_cast<size_t>(ab) & 15) ||
+      (reinterpret_cast<size_t>(out) & 15))
+    return MEGA_ERR_ARG;
+  const long long total = (long long)T * P * 8;
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 32768 ? 32768 : (total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MEGA_BF16)
+    hipLaunchKernelGGL((flow_conv1_combine_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ab, bias, order, key, (unsigned short*)out, T, P);
+  else if (dtype == MEGA_F16)
+    hipLaunchKernelGGL((flow_conv1_combine_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, ab, bias, order, key, (unsigned short*)out, T, P);
+  else
+    return MEGA_ERR_ARG;
+  return mega_check_launch();
+}

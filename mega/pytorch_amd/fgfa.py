@@ -135,6 +135,13 @@ class FlowNetS(_Packed):
             for s_ in range(7):
                 wt[:, :, 0, s_ * 8:s_ * 8 + 6] = w1[:, :, :, s_].permute(0, 2, 1)   # [o, r, c]
             pk["flow_conv1_taps"] = wt.to(dtype).to(device).contiguous()
+            # the per-FRAME halves (conv1_parts): against the operand of the pair (frame, frame), rows 0..63 see the key-frame
+            # channels (c < 3) only, rows 64..127 the reference-frame channels (c = 3..5) only
+            wab = torch.zeros((128, 7, 1, 64), dtype=torch.float32)
+            for s_ in range(7):
+                wab[:64, :, 0, s_ * 8:s_ * 8 + 3] = wt[:, :, 0, s_ * 8:s_ * 8 + 3]
+                wab[64:, :, 0, s_ * 8 + 3:s_ * 8 + 6] = wt[:, :, 0, s_ * 8 + 3:s_ * 8 + 6]
+            pk["flow_conv1_ab"] = wab.to(dtype).to(device).contiguous()
         return pk
 
     def _conv(self, pk, name, x, act=2, ksplit=None):
@@ -178,6 +185,22 @@ class FlowNetS(_Packed):
         x = ops.fgfa_pair_taps(refs, cur, order, dtype)
         w, b, s, p = pk["flow_conv1"]
         r1 = ops.conv2d_nhwc(x, pk["flow_conv1_taps"], None, b, stride=2, pad=0, relu=2)
+        return self._trunk(pk, r1, _mult(dtype))
+
+    def conv1_parts(self, frames, dtype):
+        """flow_conv1 is linear before its LeakyReLU and its input is cat([key, frame]): conv(pair) = A(key) + B(frame) with
+        A / B the convs of ONE frame against the key / reference half of the weights.  frames f32 [n,3,H,W] -> f32
+        [n,h1,w1,128] = [A | B] (no bias): computed once per frame, when it enters the window (16-bit compute dtypes)."""
+        pk = self._packed(dtype, frames.device)
+        x = ops.fgfa_pair_taps(frames, frames, None, dtype)            # the operand of the pair (frame, frame)
+        return ops.conv2d_nhwc(x, pk["flow_conv1_ab"], None, None, stride=2, pad=0, relu=0, out_dtype=torch.float32)
+
+    def run_parts(self, ab, dtype, key=None, order=None, T=None):
+        """flow of the pairs (key frame, frame t), t = 0 .. T-1, from the frames' conv1 halves ab [S,h1,w1,128] (conv1_parts);
+        the key frame is slot `key` or order[0].  flow_conv1 = leaky(A[key] + B[t] + bias): one element-wise kernel per key frame
+        instead of the pair assembly + a K = 448 conv over 21 pairs (0.30 -> 0.06 ms of config 5's key frame)."""
+        pk = self._packed(dtype, ab.device)
+        r1 = ops.flow_conv1_combine(ab, pk["flow_conv1"][1], dtype, key=key, order=order, T=T)
         return self._trunk(pk, r1, _mult(dtype))
 
     def pairs(self, refs, cur, dtype, order=None):
@@ -359,8 +382,12 @@ class GeneralizedRCNNFGFA(nn.Module):
         if feats is None:
             f = _nhwc(self.backbone(img)[0])
             feats = torch.cat([f, self.embednet.run(f)], dim=-1)
+            if self.dtype in (torch.bfloat16, torch.float16):      # FlowNetS's first conv, per frame (FlowNetS.conv1_parts)
+                feats = (feats, self.flownet.conv1_parts(img, self.dtype))
+        if isinstance(feats, tuple):
+            self.flow_ab.append(feats[1])
         self.images.append(img)
-        self.features.append(feats)
+        self.features.append(feats[0] if isinstance(feats, tuple) else feats)
         return feats
 
     @torch.no_grad()
@@ -377,6 +404,7 @@ class GeneralizedRCNNFGFA(nn.Module):
             self.end_id = 0
             self.images = deque(maxlen=self.all_frame_interval)
             self.features = deque(maxlen=self.all_frame_interval)
+            self.flow_ab = deque(maxlen=self.all_frame_interval)
             f0 = self._update_feature(cur)
             while len(self.images) < self.key_frame_location + 1:
                 self._update_feature(cur, f0)
@@ -401,7 +429,10 @@ class GeneralizedRCNNFGFA(nn.Module):
         all_features = torch.cat(list(self.features), dim=0)                   # [T,h,w,3072] NHWC
         cur_image = self.images[self.key_frame_location]
         T = all_images.shape[0]
-        flow = self.flownet.pairs(all_images, cur_image, self.dtype)             # :196-198 (the /255 lives in conv1)
+        if len(self.flow_ab) == T:                                              # :196-198 (the /255 lives in conv1)
+            flow = self.flownet.run_parts(torch.cat(list(self.flow_ab), dim=0), self.dtype, key=self.key_frame_location)
+        else:
+            flow = self.flownet.pairs(all_images, cur_image, self.dtype)
         nfeat = self.backbone.out_channels
         agg = ops.fgfa_warp_aggregate(all_features.contiguous(), flow, nfeat, self.key_frame_location)   # [h,w,1024]
         feats = (_nchw_view(agg.unsqueeze(0)),)
@@ -520,6 +551,7 @@ class FgfaClipEngine(object):
     def __init__(self, model, lookahead=20, graphs=True, pipeline=True):
         self.m = model
         self.pipeline = pipeline             # the key frame as two graphs on two streams (see _step); False: one graph
+        self.parts = model.dtype in (torch.bfloat16, torch.float16)    # FlowNetS's first conv per frame, kept in a ring
         self._sb = None
         self.T = model.all_frame_interval
         self.key = model.key_frame_location
@@ -537,7 +569,10 @@ class FgfaClipEngine(object):
 
         def body(x):
             f = _nhwc(m.backbone(x)[0])
-            return torch.cat([f, m.embednet.run(f)], dim=-1)
+            out = torch.cat([f, m.embednet.run(f)], dim=-1)
+            if self.parts:               # + FlowNetS's first conv per frame (FlowNetS.conv1_parts)
+                return out, m.flownet.conv1_parts(x, m.dtype)
+            return out, None
         if not (self.use_graphs and imgs.is_cuda):
             return body(imgs)
         ent = self.fgraphs.setdefault(tuple(imgs.shape), {})
@@ -553,13 +588,16 @@ class FgfaClipEngine(object):
             ent["graph"] = g
         ent["in"].copy_(imgs)
         ent["graph"].replay()
-        return ent["out"].clone()
+        return tuple(None if t is None else t.clone() for t in ent["out"])
 
     # ---- one key frame on the ring state, in two halves (these bodies are what the graphs capture)
     def _body_a(self):
         """FlowNetS on the window's pairs + flow-guided aggregation -> the aggregated C4 map [h,w,1024]"""
         m = self.m
-        flow = m.flownet.pairs(self.img_ring, None, m.dtype, order=self.order)     # the key frame = ring slot order[0]
+        if self.parts:                  # the key frame = ring slot order[0]
+            flow = m.flownet.run_parts(self.ab_ring, m.dtype, order=self.order)
+        else:
+            flow = m.flownet.pairs(self.img_ring, None, m.dtype, order=self.order)
         nfeat = m.backbone.out_channels
         agg = ops.fgfa_warp_aggregate(self.feat_ring, flow, nfeat, 0, order=self.order)
         if self.keep_intermediates:
@@ -680,10 +718,11 @@ class FgfaClipEngine(object):
                 end = min(end + 1, L - 1)
                 ids.append(end)
             uniq = sorted(set(ids))
-            f = self._features(frames[torch.tensor(uniq, device=dev)] if len(uniq) > 1 else frames[uniq[0]:uniq[0] + 1])
+            f, ab = self._features((frames[torch.tensor(uniq, device=dev)] if len(uniq) > 1 else frames[uniq[0]:uniq[0] + 1]).float())
             pos = {u: i for i, u in enumerate(uniq)}
             sel = torch.tensor([pos[i] for i in ids], device=dev)
             fr = f.index_select(0, sel)
+            abr = None if ab is None else ab.index_select(0, sel).contiguous()
             ir = frames[torch.tensor(ids, device=dev)].float()
             self.window = list(range(T))                # slot of window position t
             self.end_id = end
@@ -693,8 +732,10 @@ class FgfaClipEngine(object):
                 self.feat_ring.copy_(fr)                 # a new video of the same size: the rings (and the captured
                 self.img_ring.copy_(ir)                  # graph that reads them) stay where they are
                 self.order.copy_(od)
+                if abr is not None:
+                    self.ab_ring.copy_(abr)
             else:
-                self.feat_ring, self.img_ring, self.order = fr.contiguous(), ir.contiguous(), od
+                self.feat_ring, self.img_ring, self.order, self.ab_ring = fr.contiguous(), ir.contiguous(), od, abr
                 self.graph = None
             self.cache = {}                              # frame id -> [h,w,3072] computed ahead of need
             pending.append(self._step((W, H)))
@@ -705,10 +746,12 @@ class FgfaClipEngine(object):
             if fid not in self.cache:                    # features of the next `lookahead` new frames in one batch
                 ids = sorted(set(min(fid + j, L - 1) for j in range(self.lookahead)))
                 ids = ids + [ids[-1]] * (self.lookahead - len(ids))      # keep the batch shape (one hipGraph)
-                fb = self._features(frames[torch.tensor(ids, device=dev)].float())
-                self.cache = {i: fb[j] for j, i in enumerate(ids)}
+                fb, ab = self._features(frames[torch.tensor(ids, device=dev)].float())
+                self.cache = {i: (fb[j], None if ab is None else ab[j]) for j, i in enumerate(ids)}
             s = self.window[0]                            # the oldest frame's slot is overwritten
-            self.feat_ring[s].copy_(self.cache[fid])
+            self.feat_ring[s].copy_(self.cache[fid][0])
+            if self.parts:
+                self.ab_ring[s].copy_(self.cache[fid][1])
             self.img_ring[s].copy_(frames[fid])
             self.window = self.window[1:] + [s]
             od = torch.tensor([self.window[key]] + self.window, dtype=torch.int32)

@@ -229,6 +229,25 @@ def deconv4x4s2_into(x, w4, bias4, out, coff, relu=0, ksplit=1):
     return out
 
 
+def flow_conv1_combine(ab, bias, dtype, key=None, order=None, T=None):
+    """FlowNetS flow_conv1 of the pairs (key frame, frame t) from the per-frame halves (mega_flow_conv1_combine): ab f32
+    [S,h,w,128] = [A | B] of S frames, bias f32 [64] -> `dtype` [T,h,w,64] = leaky(A[key] + B[t] + bias), t = 0 .. T-1 (T = S by
+    default).  The key frame's slot is `key` (host int) or order[0] (device i32: the engine's ring)."""
+    _gpu(ab, bias, order)
+    lib = _lib.load()
+    S, h, w, c = ab.shape
+    T = S if T is None else T
+    assert c == 128 and ab.dtype == torch.float32 and ab.is_contiguous() and bias.dtype == torch.float32 and bias.numel() == 64
+    assert dtype in _HALF and (key is not None or order is not None) and T <= S
+    out = torch.empty((T, h, w, 64), dtype=dtype, device=ab.device)
+    _tok = _pb("flow_conv1_combine", 0.0, T * h * w * 64 * 6.0)
+    rc = lib.mega_flow_conv1_combine(_ptr(ab), _ptr(bias), _ptr(order), -1 if key is None else int(key), _ptr(out), T, h * w,
+                                     _DT[dtype], _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_flow_conv1_combine")
+    return out
+
+
 def flow_pred_finish(z, bias, scale, out_dtype):
     """second half of a FlowNetS flow prediction (mega_flow_pred_finish): z f32 [N,H,W,ldz] = the 1 x 1 conv of the level's map
     with the 18 (tap, channel) columns of Conv2d(Cin, 2, 3, padding=1) -> [N,H,W,2] = (sum of the shifted taps) * scale + bias."""

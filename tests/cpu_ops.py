@@ -375,6 +375,14 @@ def flow_level_assemble(skip, flow, w_up, b_up, out, C):
     return out
 
 
+def flow_conv1_combine(ab, bias, dtype, key=None, order=None, T=None):
+    S = ab.shape[0]
+    T = S if T is None else T
+    ks = int(order[0]) if order is not None else int(key)
+    y = ab[ks:ks + 1, :, :, :64] + ab[:T, :, :, 64:] + bias.view(1, 1, 1, 64)
+    return F.leaky_relu(y, 0.1).to(dtype)
+
+
 def flow_pred_finish(z, bias, scale, out_dtype):
     N, H, W, _ = z.shape
     zp = F.pad(z, (0, 0, 1, 1, 1, 1))
@@ -385,4 +393,4 @@ def flow_pred_finish(z, bias, scale, out_dtype):
     return (acc * scale + bias.view(1, 1, 1, 2)).to(out_dtype)
 
 
-ALL += ["deconv4x4s2_into", "flow_level_assemble", "flow_pred_finish"]
+ALL += ["deconv4x4s2_into", "flow_level_assemble", "flow_pred_finish", "flow_conv1_combine"]

@@ -180,8 +180,14 @@ def test_flownet_pair_taps_path_on_cpu_twins(monkeypatch):
         old = fn.run(pair.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)).float()
         new = fn.pairs(refs, cur, torch.bfloat16).float()
         ring = fn.pairs(refs, None, torch.bfloat16, order=torch.tensor([1, 0, 1, 2], dtype=torch.int32)).float()
+        # the per-frame form (round 6): conv1 halves of every frame once, the pairs by one element-wise kernel
+        ab = fn.conv1_parts(refs, torch.bfloat16)
+        parts = fn.run_parts(ab, torch.bfloat16, key=1).float()
+        parts_ring = fn.run_parts(ab, torch.bfloat16, order=torch.tensor([1, 0, 1, 2], dtype=torch.int32)).float()
     assert new.shape == old.shape and torch.equal(new, ring)
     assert (new - old).abs().max().item() <= 0.02 * max(old.abs().max().item(), 1e-6)
+    assert tuple(ab.shape[:1] + ab.shape[3:]) == (3, 128) and torch.equal(parts, parts_ring)
+    assert (parts - old).abs().max().item() <= 0.02 * max(old.abs().max().item(), 1e-6)
 
 
 def test_fgfa_clip_engine_equals_model_on_cpu_twins(monkeypatch):

@@ -181,11 +181,13 @@ def config5(args, dev):
     return {"metric": "frames/sec FGFA R-101 inference, 21-frame window, %dx%d frames" % (args.width, args.height),
             "value": round(args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(1e3 * med / args.steps, 3),
             "config": {"workload": "GeneralizedRCNNFGFA R-101-C4, ALL_FRAME_INTERVAL 21 / KEY_FRAME_LOCATION 10 (BASELINE "
-                                   "configs[4]): per key frame 1 backbone + EmbedNet pass, FlowNetS on 21 image pairs, fused warp + "
-                                   "aggregation, RPN + conv5 box head",
-                       "driver": "fgfa.FgfaClipEngine: backbone + EmbedNet for 20 upcoming frames per launch, the window in "
-                                 "rings addressed through a device index table, one hipGraph per key frame (identical "
-                                 "detections to the per-call path)",
+                                   "configs[4]): per key frame 1 backbone + EmbedNet pass (+ FlowNetS's first conv of that frame), "
+                                   "FlowNetS on 21 image pairs (refinement levels as sub-pixel GEMMs), fused warp + aggregation, RPN "
+                                   "+ conv5 box head",
+                       "driver": "fgfa.FgfaClipEngine: backbone + EmbedNet + the per-frame halves of FlowNetS's first conv for 20 "
+                                 "upcoming frames per launch, the window in rings addressed through a device index table, the "
+                                 "key frame as two hipGraphs on two streams (box head of key frame k beside FlowNetS of key "
+                                 "frame k + 1; identical detections to the per-call path)",
                        "reference_call_convention_fps": round(args.steps / med_call, 2),
                        "graph_replays": engine.replays},
             "roofline": roof, "kernel_families": fam, "blocks_ms": [round(1e3 * b, 2) for b in blocks]}
