@@ -415,7 +415,7 @@ int mega_conv2d_nhwc_ks(const void* in, const void* w, const float* scale, const
  * in [N][H][W][Cin]; w4 [4 C][2][2][Cin] with w4[(a*2 + b)*C + co][r][s][ci] = Wt[ci][co][a + 2 (1 - r)][b + 2 (1 - s)]
  * (Wt = the ConvTranspose2d weight [Cin][C][4][4]); bias4 f32 [4 C] (the bias once per phase) or NULL; relu as
  * mega_conv2d_nhwc; dtype = operand AND output type (MEGA_BF16 / MEGA_F16: Cin % 64 == 0; MEGA_F32: Cin % 32 == 0);
- * C, ldo, coff multiples of the 16-byte vector.  ksplit / ws as mega_conv2d_nhwc_ks with M = N (H+1) (W+1), Cout = 4 C,
+ * C a multiple of 16 (4 C = whole 64-column tiles), ldo, coff multiples of the 16-byte vector.  ksplit / ws as mega_conv2d_nhwc_ks with M = N (H+1) (W+1), Cout = 4 C,
  * K = 4 Cin.  A quarter of the matrix work of the zero-stuffed form, no zero-stuffing / crop / cat copies. */
 int mega_conv2d_nhwc_subpixel(const void* in, const void* w4, const float* bias4, void* out, int N, int H, int W, int Cin,
                               int C, int relu, int out_H, int out_W, int crop, int ldo, int coff, int dtype, int ksplit,

@@ -784,7 +784,9 @@ extern "C" int mega_conv2d_nhwc_subpixel(const void* in, const void* w4, const f
   }
   hipStream_t st = (hipStream_t)stream;
   const long b128 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 128) * p.ksplit, b12864 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 64) * p.ksplit;
-  const int tile = b128 >= 384 ? 0 : (b12864 >= 384 ? 1 : 2);     // (choose_tile's rule for the register-staged tiles)
+  // (the sub-pixel read-out is the tiles' vector path: whole tiles of columns only)
+  if (p.Cout % 64 != 0) return MEGA_ERR_ARG;
+  const int tile = (b128 >= 384 && p.Cout % 128 == 0) ? 0 : (b12864 >= 384 ? 1 : 2);     // (choose_tile's rule for the register-staged tiles)
   auto go = [&](auto tag) -> int {
     typedef decltype(tag) T;
     int rc = tile == 0 ? launch<T, T, 128, 128, true>(p, st) : (tile == 1 ? launch<T, T, 128, 64, true>(p, st) : launch<T, T, 64, 64, true>(p, st));

@@ -190,6 +190,36 @@ def test_flownet_pair_taps_path_on_cpu_twins(monkeypatch):
     assert (parts - old).abs().max().item() <= 0.02 * max(old.abs().max().item(), 1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 8, 10, 16), (1, 4, 6, 10, 14), (2, 7, 9, 13, 17)])
+def test_subpixel_deconv_packing_equals_conv_transpose(shape):
+    """ops.pack_deconv4x4s2 (host-side weight packing of mega_conv2d_nhwc_subpixel) + the sub-pixel scatter rule, restated on
+    torch-CPU by the twin, against F.conv_transpose2d(k = 4, s = 2) + flownet.py:9-13 crop_like: the four output phases of the
+    transposed conv ARE a 2 x 2 / pad 1 conv with (a, b, co) output columns; targets with and without the crop, odd sizes."""
+    import torch.nn.functional as F
+    from mega.pytorch_amd import ops
+    N, H, W, H2, W2 = shape
+    Cin, C, Cs = 24, 8, 16
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn((N, H, W, Cin), generator=g)
+    wt = torch.randn((Cin, C, 4, 4), generator=g)
+    b = torch.randn((C,), generator=g)
+    flow = torch.randn((N, H, W, 2), generator=g)
+    wu, bu = torch.randn((2, 2, 4, 4), generator=g), torch.randn((2,), generator=g)
+    skip = torch.randn((N, H2, W2, Cs), generator=g)
+    crop = 0 if (2 * H + 2, 2 * W + 2) == (H2, W2) else 1
+    w4 = ops.pack_deconv4x4s2(wt, torch.float32, 32)
+    assert tuple(w4.shape) == (4 * C, 2, 2, 32) and float(w4[..., Cin:].abs().max()) == 0.0
+    xp = torch.zeros((N, H, W, 32))
+    xp[..., :Cin] = x
+    out = torch.full((N, H2, W2, 32), float("nan"))
+    cpu_ops.deconv4x4s2_into(xp, w4, b.repeat(4), out, Cs, relu=0)
+    cpu_ops.flow_level_assemble(skip, flow, wu, bu, out, C)
+    full = F.conv_transpose2d(x.permute(0, 3, 1, 2), wt, b, stride=2)[:, :, crop:crop + H2, crop:crop + W2].permute(0, 2, 3, 1)
+    up = F.conv_transpose2d(flow.permute(0, 3, 1, 2), wu, bu, stride=2)[:, :, crop:crop + H2, crop:crop + W2].permute(0, 2, 3, 1)
+    assert torch.equal(out[..., :Cs], skip) and float(out[..., Cs + C + 2:].abs().max()) == 0.0
+    assert (out[..., Cs:Cs + C] - full).abs().max().item() < 1e-4 and (out[..., Cs + C:Cs + C + 2] - up).abs().max().item() < 1e-5
+
+
 def test_fgfa_clip_engine_equals_model_on_cpu_twins(monkeypatch):
     """fgfa.FgfaClipEngine's host logic -- features of upcoming frames in look-ahead batches, the window in rings with a
     rotating slot table, the cold-start fill, the end-of-video clamp, restart on a second video -- against
