@@ -499,6 +499,7 @@ extern "C" int mega_fgfa_pair_taps(const float* ring, long long ring_stride, con
 // out pixel (Y, X) = (y + crop, x + crop) of the full map sees coarse pixels (Y / 2 - dy, X / 2 - dx) through taps
 // (Y % 2 + 2 dy, X % 2 + 2 dx) -- and zeros up to the pixel stride.  Replaces a GEMM on 64-padded channels over a zero-stuffed
 // map, two crops, a cat and a pad (five launches, ~0.15 ms per level of the 21-pair key frame).
+namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void flow_level_assemble_kernel(const T* __restrict__ skip, const T* __restrict__ flow,
                                                                   const float* __restrict__ wup, const float* __restrict__ bup,
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(256) void flow_level_assemble_kernel(const T* __res
     *reinterpret_cast<uint4*>(o + Cs + C + (v - vs) * VE) = z;
   }
 }
+}  // namespace
 
 /* see flow_level_assemble_kernel.  skip [N][H2][W2][Cs], flow [N][h][w][2], out [N][H2][W2][ldo] of `dtype` (MEGA_F32 / BF16 /
  * F16); w_up f32 [2][2][4][4] (ConvTranspose2d weight, [in][out][kh][kw]), b_up f32 [2]; Cs, C, ldo multiples of the 16-byte
@@ -577,6 +579,7 @@ extern "C" int mega_flow_level_assemble(const void* skip, const void* flow, cons
 // with 18 columns -- z[p][(r*3 + s)*2 + c] = sum_ci x[p][ci] w[c][ci][r][s], ONE pass over x, K = Cin instead of 9 Cin, f32
 // output (mega_conv2d_nhwc) -- followed by this kernel: flow[t][y][x][c] = (sum_{r,s} z[t][y+r-1][x+s-1][(r*3+s)*2 + c]) * scale
 // + bias[c], taps outside the map skipped (zero padding), summed in f32 in (r, s) order.
+namespace {
 template <typename OT>
 __global__ __launch_bounds__(256) void flow_pred_finish_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ bias,
                                                                float scale, OT* __restrict__ out, int N, int H, int W) {
@@ -598,6 +601,7 @@ __global__ __launch_bounds__(256) void flow_pred_finish_kernel(const float* __re
     Elem<OT>::st(out + i * 2 + 1, fmaf(a1, scale, bias[1]));
   }
 }
+}  // namespace
 
 /* see flow_pred_finish_kernel.  z f32 [N][H][W][ldz] (ldz >= 18, even), bias f32 [2] (already multiplied by `scale` if the
  * caller wants (conv + b) * scale), out [N][H][W][2] of out_dtype (MEGA_F32 / BF16 / F16). */
@@ -621,6 +625,7 @@ extern "C" int mega_flow_pred_finish(const float* z, int ldz, const float* bias,
 // 128 output channels [A | B] over that frame's tap operand, f32 out) instead of 21 times per key frame; what is left per key
 // frame is this kernel:  out[t][p][c] = leaky(A[key][p][c] + B[t][p][c] + bias[c]),  one 16-byte vector of 8 channels per thread.
 // ab f32 [S][P][128] (A = channels 0..63, B = 64..127); key: slot of the key frame (order ? order[0] : key).
+namespace {
 template <typename HT>
 __global__ __launch_bounds__(256) void flow_conv1_combine_kernel(const float* __restrict__ ab, const float* __restrict__ bias,
                                                                  const int* __restrict__ order, int key, unsigned short* __restrict__ out,
@@ -649,6 +654,7 @@ __global__ __launch_bounds__(256) void flow_conv1_combine_kernel(const float* __
     *reinterpret_cast<u32x4_t*>(out + px * 64 + v * 8) = o;
   }
 }
+}  // namespace
 
 /* see flow_conv1_combine_kernel.  ab f32 [S][P][128] with S >= T frames' [A | B] halves (mega_conv2d_nhwc, f32 output);
  * bias f32 [64]; order (device int, NULL: use `key`): order[0] = slot of the key frame; out [T][P][64] of dtype
