@@ -440,9 +440,16 @@ int mega_flow_pred_finish(const float* z, int ldz, const float* bias, float scal
  * halves [A | B] of a frame are computed once, when it enters the window (mega_conv2d_nhwc with 128 output channels over that
  * frame's tap operand, f32 out), and a key frame's 21 pairs are  out[t][p][c] = leaky(A[key][p][c] + B[t][p][c] + bias[c]).
  * ab f32 [S][P][128]; bias f32 [64]; order (device int; NULL: use `key`): order[0] = slot of the key frame; out [T][P][64] of
- * dtype (MEGA_BF16 / MEGA_F16), pair t = (key frame, the frame in slot t). */
+ * dtype (MEGA_BF16 / MEGA_F16), pair t = (key frame, the frame in slot t).  nwin > 0: order holds G rows [key slot, slot of
+ * window position 0 .. nwin-1], T = G nwin, pair g nwin + t = (key frame of row g, window position t): exactly the pairs of G
+ * key frames, in window order. */
 int mega_flow_conv1_combine(const float* ab, const float* bias, const int* order, int key, void* out, int T, long long P,
-                            int dtype, void* stream);
+                            int nwin, int dtype, void* stream);
+/* mega_fgfa_warp_aggregate_ring with the flow fields in WINDOW order: flow [T][2][H][W] = the T pairs (key frame, window
+ * position t) and nothing else; key_pos = the key frame's window position (cfg KEY_FRAME_LOCATION).  What a FlowNetS pass over
+ * the exact pairs of several key frames (mega_flow_conv1_combine with nwin > 0) hands to the warp. */
+int mega_fgfa_warp_aggregate_ring_pos(const void* feats, const float* flow, void* out, float* weights_out, int T, int H,
+                                      int W, int Cf, int Ce, const int* order, int key_pos, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

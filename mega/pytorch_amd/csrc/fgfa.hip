@@ -131,11 +131,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats, const float* __restrict__ flow,
                                                     T* __restrict__ out, float* __restrict__ weights_out, int NT,
                                                     int H, int W, int Cf, int Ce, int key,
-                                                    const int* __restrict__ order) {
+                                                    const int* __restrict__ order, int flow_key_pos) {
   // order (optional, device): the T maps live in a RING -- order[0] = slot of the key frame, order[1 + t] = slot of the
   // frame at window position t.  Frames are visited in window order whatever their slots, so the sums have the bits of
-  // the contiguous (deque-ordered) call; flow is indexed by slot like feats.  (engine: one hipGraph for every step.)
+  // the contiguous (deque-ordered) call; flow is indexed by slot like feats (flow_key_pos < 0) or by WINDOW POSITION
+  // (flow_key_pos >= 0 = the key frame's position: flow [NT][2][H][W] holds exactly the window's pairs, in window order).
   auto slot_of = [&](int t) { return order ? order[1 + t] : t; };
+  auto flow_of = [&](int t, int slot) { return flow_key_pos >= 0 ? t : slot; };
+  const int key_flow = (order && flow_key_pos >= 0) ? flow_key_pos : (order ? order[0] : key);
   if (order) key = order[0];
   constexpr int VE = Elem<T>::VE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats,
   const int px = pix % W, py = pix / W;
 
   struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
-  auto taps = [&](int t) {           // t = SLOT of the frame
+  auto taps = [&](int t) {           // t = index of the frame's flow field (its slot, or its window position)
     const float fx = flow[((size_t)t * 2 + 0) * H * W + py * W + px];
     const float fy = flow[((size_t)t * 2 + 1) * H * W + py * W + px];
     const float gx = ((float)px + fx) / ((float)(W - 1) / 2.f) - 1.f;   // :55-58
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats,
 
   // ---- A. the key frame's warped embedding (all 256 threads) and its norm
   {
-    const Taps tp = taps(key);
+    const Taps tp = taps(key_flow);
     const T* base = feats + (size_t)key * H * W * C + Cf;
     float n2 = 0.f;
     for (int v = tid; v < evec; v += 256) {
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats,
   // ---- B. cosine weights: wave w takes frames w, w + 4, ...; no block barrier inside
   for (int t = wave; t < NT; t += 4) {
     const int st = slot_of(t);
-    const Taps tp = taps(st);
+    const Taps tp = taps(flow_of(t, st));
     const T* base = feats + (size_t)st * H * W * C + Cf;
     float dot = 0.f, nn = 0.f;
     for (int v0 = 0; v0 < evec; v0 += 256) {           // 4 vectors per lane per round: 16 loads in flight
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats,
     const int t2 = t + G;
     const bool has2 = t2 < NT;
     const int s1 = slot_of(t), s2 = slot_of(has2 ? t2 : t);
-    const Taps tp = taps(s1), tq = taps(s2);
+    const Taps tp = taps(flow_of(t, s1)), tq = taps(flow_of(has2 ? t2 : t, s2));
     const T* p = feats + (size_t)s1 * H * W * C + (size_t)v * VE;
     const T* q2 = feats + (size_t)s2 * H * W * C + (size_t)v * VE;
     const uint4 a = *reinterpret_cast<const uint4*>(p + tp.o00), b = *reinterpret_cast<const uint4*>(p + tp.o01);
@@ -418,7 +421,7 @@ extern "C" int mega_dff_warp_scale(const void* feats, const float* flow, const v
 }
 
 static int fgfa_impl(const void* feats, const float* flow, void* out, float* weights_out, int T, int H, int W, int Cf,
-                     int Ce, int key, const int* order, int dtype, void* stream);
+                     int Ce, int key, const int* order, int dtype, void* stream, int flow_key_pos = -1);
 
 extern "C" int mega_fgfa_warp_aggregate(const void* feats, const float* flow, void* out, float* weights_out, int T,
                                         int H, int W, int Cf, int Ce, int key, int dtype, void* stream) {
@@ -433,8 +436,18 @@ extern "C" int mega_fgfa_warp_aggregate_ring(const void* feats, const float* flo
   return fgfa_impl(feats, flow, out, weights_out, T, H, W, Cf, Ce, 0, order, dtype, stream);
 }
 
+// The ring form with the flow fields in WINDOW order: flow [T][2][H][W] = the T pairs (key frame, window position t) and
+// nothing else (the engine's FlowNetS pass over several key frames enumerates exactly each key frame's pairs); key_pos = the
+// key frame's window position (cfg KEY_FRAME_LOCATION).  Same arithmetic, same order of the sums.
+extern "C" int mega_fgfa_warp_aggregate_ring_pos(const void* feats, const float* flow, void* out, float* weights_out, int T,
+                                                 int H, int W, int Cf, int Ce, const int* order, int key_pos, int dtype,
+                                                 void* stream) {
+  if (!order || key_pos < 0 || key_pos >= T) return MEGA_ERR_ARG;
+  return fgfa_impl(feats, flow, out, weights_out, T, H, W, Cf, Ce, 0, order, dtype, stream, key_pos);
+}
+
 static int fgfa_impl(const void* feats, const float* flow, void* out, float* weights_out, int T, int H, int W, int Cf,
-                     int Ce, int key, const int* order, int dtype, void* stream) {
+                     int Ce, int key, const int* order, int dtype, void* stream, int flow_key_pos) {
   mega_clear_error();
   if (!feats || !flow || !out || T <= 0 || T > 64 || H <= 1 || W <= 1 || Cf <= 0 || Ce <= 0 || key < 0 || key >= T)
     return MEGA_ERR_ARG;
@@ -447,10 +460,10 @@ static int fgfa_impl(const void* feats, const float* flow, void* out, float* wei
     const size_t smem2 = ((size_t)Ce + (size_t)(256 / fvec - 1) * Cf) * sizeof(float);
     if (dtype == MEGA_BF16)
       hipLaunchKernelGGL((fgfa2_kernel<bf16_t>), dim3(H * W), dim3(256), smem2, st, (const bf16_t*)feats, flow,
-                         (bf16_t*)out, weights_out, T, H, W, Cf, Ce, key, order);
+                         (bf16_t*)out, weights_out, T, H, W, Cf, Ce, key, order, flow_key_pos);
     else if (dtype == MEGA_F32)
       hipLaunchKernelGGL((fgfa2_kernel<float>), dim3(H * W), dim3(256), smem2, st, (const float*)feats, flow,
-                         (float*)out, weights_out, T, H, W, Cf, Ce, key, order);
+                         (float*)out, weights_out, T, H, W, Cf, Ce, key, order, flow_key_pos);
     else
       return MEGA_ERR_ARG;
     return mega_check_launch();
@@ -629,18 +642,28 @@ namespace {
 template <typename HT>
 __global__ __launch_bounds__(256) void flow_conv1_combine_kernel(const float* __restrict__ ab, const float* __restrict__ bias,
                                                                  const int* __restrict__ order, int key, unsigned short* __restrict__ out,
-                                                                 int T, long long P) {
+                                                                 int T, long long P, int nwin) {
+  // nwin == 0: pair t = (key frame, the frame in slot t), key slot = order ? order[0] : key.
+  // nwin > 0:  order = [G][1 + nwin] rows [key slot, slot of window position 0 .. nwin-1]; pair q = g nwin + t = (key frame of
+  //            row g, window position t): exactly the pairs of G key frames, in window order (T = G nwin pairs).
   const long long total = (long long)T * P * 8;
-  const int ks = order ? order[0] : key;
+  const int ks0 = order ? order[0] : key;
   const int v = threadIdx.x & 7;
   float bi[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bi[e] = bias[v * 8 + e];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long px = i >> 3;                 // t * P + p
+    const long long px = i >> 3;                 // q * P + p
     const long long p = px % P;
+    int ks = ks0;
+    long long bs = px - p;                       // (slot of the pair's second frame) * P
+    if (nwin > 0) {
+      const int q = (int)(px / P), g = q / nwin, t = q - g * nwin;
+      ks = order[g * (nwin + 1)];
+      bs = (long long)order[g * (nwin + 1) + 1 + t] * P;
+    }
     const float4* a = reinterpret_cast<const float4*>(ab + ((long long)ks * P + p) * 128 + v * 8);
-    const float4* b = reinterpret_cast<const float4*>(ab + px * 128 + 64 + v * 8);
+    const float4* b = reinterpret_cast<const float4*>(ab + (bs + p) * 128 + 64 + v * 8);
     const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
     float x[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
     u32x4_t o;
@@ -658,20 +681,21 @@ __global__ __launch_bounds__(256) void flow_conv1_combine_kernel(const float* __
 
 /* see flow_conv1_combine_kernel.  ab f32 [S][P][128] with S >= T frames' [A | B] halves (mega_conv2d_nhwc, f32 output);
  * bias f32 [64]; order (device int, NULL: use `key`): order[0] = slot of the key frame; out [T][P][64] of dtype
- * (MEGA_BF16 / MEGA_F16): pair t = (key frame, frame in slot t). */
+ * (MEGA_BF16 / MEGA_F16): pair t = (key frame, frame in slot t).  nwin > 0: order = [G][1 + nwin] rows [key slot, slots of the
+ * window positions], T = G nwin, pair g nwin + t = (key frame of row g, the frame at window position t). */
 extern "C" int mega_flow_conv1_combine(const float* ab, const float* bias, const int* order, int key, void* out, int T,
-                                       long long P, int dtype, void* stream) {
+                                       long long P, int nwin, int dtype, void* stream) {
   mega_clear_error();
   if (!ab || !bias || !out || T <= 0 || P <= 0 || (!order && key < 0) || (reinterpret_cast<size_t>(ab) & 15) ||
-      (reinterpret_cast<size_t>(out) & 15))
+      (reinterpret_cast<size_t>(out) & 15) || nwin < 0 || (nwin > 0 && (!order || T % nwin != 0)))
     return MEGA_ERR_ARG;
   const long long total = (long long)T * P * 8;
   const unsigned blocks = (unsigned)((total + 255) / 256 > 32768 ? 32768 : (total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MEGA_BF16)
-    hipLaunchKernelGGL((flow_conv1_combine_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ab, bias, order, key, (unsigned short*)out, T, P);
+    hipLaunchKernelGGL((flow_conv1_combine_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ab, bias, order, key, (unsigned short*)out, T, P, nwin);
   else if (dtype == MEGA_F16)
-    hipLaunchKernelGGL((flow_conv1_combine_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, ab, bias, order, key, (unsigned short*)out, T, P);
+    hipLaunchKernelGGL((flow_conv1_combine_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, ab, bias, order, key, (unsigned short*)out, T, P, nwin);
   else
     return MEGA_ERR_ARG;
   return mega_check_launch();

@@ -203,6 +203,15 @@ class FlowNetS(_Packed):
         r1 = ops.flow_conv1_combine(ab, pk["flow_conv1"][1], dtype, key=key, order=order, T=T)
         return self._trunk(pk, r1, _mult(dtype))
 
+    def run_parts_multi(self, ab, dtype, orders):
+        """run_parts for several key frames in ONE trunk pass: orders i32 [G, 1 + T] on the device, row g = [slot of key frame g,
+        slot of window position 0 .. T-1] -> flow [G * T, 2, h, w], rows g * T + t = the pair (key frame g, window position
+        t): exactly the key frames' pairs, in window order.  The trunk's kernels are batch-invariant: the bits of G separate
+        run_parts calls on the windows' frames."""
+        pk = self._packed(dtype, ab.device)
+        r1 = ops.flow_conv1_combine(ab, pk["flow_conv1"][1], dtype, order=orders, nwin=orders.shape[1] - 1)
+        return self._trunk(pk, r1, _mult(dtype))
+
     def pairs(self, refs, cur, dtype, order=None):
         """flow of the pairs (cur | refs[t]): the one-kernel input stage for the 16-bit dtypes, the generic path otherwise"""
         if dtype in (torch.bfloat16, torch.float16):
@@ -537,31 +546,39 @@ class FgfaClipEngine(object):
 
     The reference (and `model(images)` here) runs ~200 launches per key frame at batch 1, re-concatenates the window's
     21 images and 21 x 3072-channel maps every step, and reads the detection count back before the next frame: on
-    MI355X that is host-bound (8.7 ms per key frame for 5.6 ms of kernels) and the single-frame backbone fills 15 % of
-    the chip.  Here
-      * backbone + EmbedNet run for `lookahead` upcoming frames in ONE batch (the kernels are batch-invariant: same bits);
-      * the window lives in rings of T slots (images, [features | embeddings]); a step overwrites the oldest slot and
-        rotates an index table on the device (`order`); FlowNetS takes the pairs in slot order and the warp kernel visits
-        the frames in window order through `order` (mega_fgfa_warp_aggregate_ring) -- the bits of the contiguous call;
-      * everything after the ring update -- pair assembly, FlowNetS, warp + aggregation, RPN selection, res5 + ROIAlign +
-        fc6/fc7, predictor, post-processing (fixed 300 proposal rows, the device-side proposal count goes to the
-        post-processor) -- is ONE hipGraph replayed per key frame; detection counts are read a batch of steps later.
+    MI355X that is host-bound and its single-frame launches fill a fraction of the chip.  Here
+      * backbone + EmbedNet (+ the per-frame halves of FlowNetS's first conv) run for `lookahead` upcoming frames in ONE
+        batch (the kernels are batch-invariant: same bits), once per frame of the video;
+      * a frame's maps live in ring slot `frame id mod R`, R = T + group - 1: the window of key frame k is the frames
+        clamp(k - key + t, 0, L - 1), t = 0 .. T-1 (what the reference's deque holds: frame 0 replicated at the start, the
+        last frame at the end), i.e. a row of a device index table (`order[b]` = [slot of the key frame, slot of window
+        position t ...]); FlowNetS takes a key frame's pairs in slot order over the whole ring and the warp kernel visits the
+        window in window order through the table (mega_fgfa_warp_aggregate_ring) -- the bits of the contiguous call;
+      * `group` consecutive key frames share ONE FlowNetS pass over exactly their group x T pairs (its coarse levels have
+        840-12 768 GEMM rows at 21 pairs and leave half the chip idle: 1.05 ms per key frame at 21 pairs, 0.84 at 42, 0.77
+        at 84); the flow fields come out in window order per key frame (mega_fgfa_warp_aggregate_ring_pos);
+      * the key frame is TWO hipGraphs on two streams: A = FlowNetS + warp of a group, B = RPN selection, res5 + ROIAlign +
+        fc6 / fc7, predictor, post-processing of one key frame (fixed 300 proposal rows, the device-side proposal count goes
+        to the post-processor); B of one group runs beside A of the next (its one-block selection / NMS kernels and
+        300-row GEMMs leave most of the chip idle); detection counts are read a batch of steps later.
     Detections are identical to `model(images)` frame by frame (tests/test_e2e_gpu.py::test_fgfa_engine_equals_model)."""
 
-    def __init__(self, model, lookahead=20, graphs=True, pipeline=True):
+    def __init__(self, model, lookahead=20, graphs=True, pipeline=True, group=2):
         self.m = model
-        self.pipeline = pipeline             # the key frame as two graphs on two streams (see _step); False: one graph
+        self.pipeline = pipeline             # graphs A and B on two streams (see _step); False: one graph on one stream
         self.parts = model.dtype in (torch.bfloat16, torch.float16)    # FlowNetS's first conv per frame, kept in a ring
+        self.group = max(1, int(group))      # key frames per FlowNetS pass
         self._sb = None
         self.T = model.all_frame_interval
         self.key = model.key_frame_location
-        self.ahead = self.T - self.key - 1
+        self.R = self.T + self.group - 1
         self.lookahead = lookahead
         self.use_graphs = graphs
         self.graph = None
         self.fgraphs = {}
         self.replays = 0
-        self.keep_intermediates = False      # tests / diagnostics: self._dbg = (flow, aggregated map, proposals, logits)
+        self.feat_ring = None
+        self.keep_intermediates = False      # tests / diagnostics: self._dbg = per key frame (flow, aggregated map, proposals, ...)
 
     # ---- features of a batch of frames (backbone + EmbedNet), replayed from a hipGraph per batch size
     def _features(self, imgs):
@@ -590,22 +607,26 @@ class FgfaClipEngine(object):
         ent["graph"].replay()
         return tuple(None if t is None else t.clone() for t in ent["out"])
 
-    # ---- one key frame on the ring state, in two halves (these bodies are what the graphs capture)
+    # ---- a group of key frames on the ring state, in two halves (these bodies are what the graphs capture)
     def _body_a(self):
-        """FlowNetS on the window's pairs + flow-guided aggregation -> the aggregated C4 map [h,w,1024]"""
+        """FlowNetS on the pairs of the group's key frames + flow-guided aggregation -> aggregated C4 maps [group,h,w,1024]"""
         m = self.m
-        if self.parts:                  # the key frame = ring slot order[0]
-            flow = m.flownet.run_parts(self.ab_ring, m.dtype, order=self.order)
-        else:
-            flow = m.flownet.pairs(self.img_ring, None, m.dtype, order=self.order)
+        G, T = self.group, self.T
         nfeat = m.backbone.out_channels
-        agg = ops.fgfa_warp_aggregate(self.feat_ring, flow, nfeat, 0, order=self.order)
+        if self.parts:                  # key frame b = ring slot order[b][0]; ONE trunk pass over exactly the G x T pairs
+            flow = m.flownet.run_parts_multi(self.ab_ring, m.dtype, self.order)
+            flows = [flow[b * T:(b + 1) * T] for b in range(G)]
+            aggs = [ops.fgfa_warp_aggregate(self.feat_ring, flows[b], nfeat, 0, order=self.order[b], flow_pos=self.key)
+                    for b in range(G)]
+        else:                           # (exact-f32 mode: the generic pair path, a key frame's pairs in slot order over the ring)
+            flows = [m.flownet.pairs(self.img_ring, None, m.dtype, order=self.order[b]) for b in range(G)]
+            aggs = [ops.fgfa_warp_aggregate(self.feat_ring, flows[b], nfeat, 0, order=self.order[b]) for b in range(G)]
         if self.keep_intermediates:
-            self._dbg_a = (flow, agg)
-        return agg
+            self._dbg_a = [(flows[b], aggs[b]) for b in range(G)]
+        return torch.stack(aggs, dim=0)
 
     def _body_b(self, agg, size):
-        """RPN + conv5 box head + post-processing on the aggregated map"""
+        """RPN + conv5 box head + post-processing on ONE aggregated map [h,w,1024]"""
         m = self.m
         W, H = size
         feats = (_nchw_view(agg.unsqueeze(0)),)
@@ -628,43 +649,41 @@ class FgfaClipEngine(object):
         logits, deltas = box.predictor(x)
         pp = box.post_processor
         if self.keep_intermediates:
-            self._dbg = self._dbg_a + (props, logits, deltas, x, cnt)
+            self._dbg_b = (props, logits, deltas, x, cnt)
         return ops.postprocess(logits.float().contiguous(), deltas.float().contiguous(), props[0].contiguous(), cnt,
                                pp.weights, W, H, pp.score_thresh, pp.nms, pp.detections_per_img, pp.strict_gt)
 
-    def _body(self, size):
-        return self._body_b(self._body_a(), size)
+    def _eager(self, size, n):
+        aggs = self._body_a()
+        outs = []
+        for b in range(n):
+            outs.append(self._body_b(aggs[b], size))
+            if self.keep_intermediates:
+                self._dbg = self._dbg_a[b] + self._dbg_b
+        return outs
 
-    def _step(self, size):
-        if not (self.use_graphs and self.img_ring.is_cuda):
-            return self._body(size)
+    def _step(self, size, n):
+        """the group on the ring state (order holds `group` rows; the first n are real key frames) -> n output tuples"""
+        if not (self.use_graphs and self.feat_ring.is_cuda):
+            return self._eager(size, n)
         if self.graph is None:
             self.graph = "armed"
-            return self._body(size)
+            return self._eager(size, n)
         cur = torch.cuda.current_stream()
-        if not self.pipeline:
-            if self.graph == "armed":
-                cur.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._out = self._body(size)
-                self.graph = g
-            self.graph.replay()
-            self.replays += 1
-            return tuple(t.clone() for t in self._out)
-        # Two graphs per key frame on two streams: A (FlowNetS + warp: whole-chip GEMMs) on the current stream, B (RPN, box head,
-        # post-processing: ~0.8 ms of one-block kernels and GEMMs on 2394 / 300 rows that fill a fraction of the chip) on a
-        # second stream, so that B of key frame k runs BESIDE A of key frame k + 1.  B reads its own copy of the aggregated map
-        # (5 MB, made on B's stream right after A); A's next replay waits for that copy only.  The graphs replay concurrently:
-        # each has its own memory pool (torch's default for separately captured graphs).
         if self.graph == "armed":
+            # Graph A (FlowNetS + warp of the group: whole-chip GEMMs) replays on the current stream, graph B (RPN, box head,
+            # post-processing of ONE key frame: ~0.8 ms of one-block kernels and GEMMs on 2394 / 300 rows) on a second stream
+            # (pipeline=True), so that B of a group runs BESIDE A of the next.  B reads its own copy of an aggregated map (5 MB,
+            # made on B's stream); A's next replay waits for the last of those copies only.  The graphs replay concurrently:
+            # each has its own memory pool (torch's default for separately captured graphs).
             cur.synchronize()
-            if self._sb is None:
-                self._sb = torch.cuda.Stream(device=self.img_ring.device)
+            if self._sb is None and self.pipeline:
+                self._sb = torch.cuda.Stream(device=self.feat_ring.device)
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 self._agg_out = self._body_a()
-            self._agg_in = self._agg_out.clone()
+            self._agg_in = self._agg_out[0].clone()
+            self._agg_stage = self._agg_out.clone()
             cur.synchronize()
             with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                 self._out = self._body_b(self._agg_in, size)
@@ -672,31 +691,72 @@ class FgfaClipEngine(object):
             self._ea, self._ec = torch.cuda.Event(), torch.cuda.Event()
             self._ec.record(cur)
         ga, gb = self.graph
-        cur.wait_event(self._ec)              # B's copy of the previous aggregated map is done
+        cur.wait_event(self._ec)              # B's copy of the previous group's aggregated maps is done
         ga.replay()
         self._ea.record(cur)
-        sb = self._sb
+        sb = self._sb if self.pipeline else cur
         sb.wait_event(self._ea)
+        outs = []
         with torch.cuda.stream(sb):
-            self._agg_in.copy_(self._agg_out)
+            self._agg_stage.copy_(self._agg_out)      # the group's maps, copied at once: A's next replay waits for this only
             self._ec.record(sb)
-            gb.replay()
-            outs = tuple(t.clone() for t in self._out)
-        for t in outs:
-            t.record_stream(cur)              # read on the current stream after the join in run()'s flush
-        self.replays += 1
+            for b in range(n):
+                self._agg_in.copy_(self._agg_stage[b])
+                gb.replay()
+                outs.append(tuple(t.clone() for t in self._out))
+        for o in outs:
+            for t in o:
+                t.record_stream(cur)          # read on the current stream after the join in run()'s flush
+        self.replays += n
         return outs
+
+    def _reset(self, frames):
+        """rings for a video of this size (kept, with the captured graphs that read them, when the size repeats)"""
+        m = self.m
+        dev = frames.device
+        H, W = frames.shape[-2:]
+        sig = (H, W, str(dev))
+        if self.feat_ring is None or self._sig != sig:
+            f, ab = self._features(frames[0:1].float())
+            self.feat_ring = f.new_zeros((self.R,) + tuple(f.shape[1:]))
+            self.ab_ring = None if ab is None else ab.new_zeros((self.R,) + tuple(ab.shape[1:]))
+            self.img_ring = None if self.parts else frames.new_zeros((self.R, 3, H, W), dtype=torch.float32)
+            self.order = torch.zeros((self.group, self.T + 1), dtype=torch.int32, device=dev)
+            self._sig = sig
+            self.graph = None
+        self.slot_fid = [-1] * self.R
+        self.cache = {}                                  # frame id -> ([h,w,3072], conv1 halves) computed ahead of need
+
+    def _ensure(self, frames, fids):
+        """the frames `fids` resident in their ring slots (slot = id mod R); features of the next `lookahead` new frames in one
+        batch (one hipGraph shape)"""
+        L = frames.shape[0]
+        dev = frames.device
+        for fid in fids:
+            s = fid % self.R
+            if self.slot_fid[s] == fid:
+                continue
+            if fid not in self.cache:
+                ids = sorted(set(min(fid + j, L - 1) for j in range(self.lookahead)))
+                ids = ids + [ids[-1]] * (self.lookahead - len(ids))      # keep the batch shape
+                fb, ab = self._features(frames[torch.tensor(ids, device=dev)].float())
+                self.cache = {i: (fb[j], None if ab is None else ab[j]) for j, i in enumerate(ids)}
+            f, ab = self.cache[fid]
+            self.feat_ring[s].copy_(f)
+            if ab is not None:
+                self.ab_ring[s].copy_(ab)
+            if self.img_ring is not None:
+                self.img_ring[s].copy_(frames[fid])
+            self.slot_fid[s] = fid
 
     @torch.no_grad()
     def run(self, frames, first=0, last=None, sync_every=16):
         """frames: preprocessed f32 [L,3,H,W] on the device (the whole video, or a FrameSource-like object with
         __getitem__ over index tensors).  Key frames first..last-1 (first = 0 starts a new video).  -> list[BoxList]."""
-        m = self.m
         L = frames.shape[0]
         last = L if last is None else last
         H, W = frames.shape[-2:]
-        dev = frames.device
-        T, key, ahead = self.T, self.key, self.ahead
+        T, key, G, R = self.T, self.key, self.group, self.R
         out, pending = [], []
 
         def flush():
@@ -709,55 +769,19 @@ class FgfaClipEngine(object):
                 out.append(PostProcessor.materialize((ob, os_, ol, None), int(n), (W, H)))
             del pending[:]
 
+        if first == 0 or self.feat_ring is None:
+            self._reset(frames)
         idx = first
-        if idx == 0 and idx < last:
-            # frame_category 0 (:163-176): the window = frame 0 replicated key + 1 times, then frames 1 .. ahead (clamped)
-            ids = [0] * (key + 1)
-            end = 0
-            for _ in range(ahead):
-                end = min(end + 1, L - 1)
-                ids.append(end)
-            uniq = sorted(set(ids))
-            f, ab = self._features((frames[torch.tensor(uniq, device=dev)] if len(uniq) > 1 else frames[uniq[0]:uniq[0] + 1]).float())
-            pos = {u: i for i, u in enumerate(uniq)}
-            sel = torch.tensor([pos[i] for i in ids], device=dev)
-            fr = f.index_select(0, sel)
-            abr = None if ab is None else ab.index_select(0, sel).contiguous()
-            ir = frames[torch.tensor(ids, device=dev)].float()
-            self.window = list(range(T))                # slot of window position t
-            self.end_id = end
-            od = torch.tensor([self.window[key]] + self.window, dtype=torch.int32, device=dev)
-            if getattr(self, "feat_ring", None) is not None and self.feat_ring.shape == fr.shape \
-                    and self.img_ring.shape == ir.shape and self.feat_ring.device == fr.device:
-                self.feat_ring.copy_(fr)                 # a new video of the same size: the rings (and the captured
-                self.img_ring.copy_(ir)                  # graph that reads them) stay where they are
-                self.order.copy_(od)
-                if abr is not None:
-                    self.ab_ring.copy_(abr)
-            else:
-                self.feat_ring, self.img_ring, self.order, self.ab_ring = fr.contiguous(), ir.contiguous(), od, abr
-                self.graph = None
-            self.cache = {}                              # frame id -> [h,w,3072] computed ahead of need
-            pending.append(self._step((W, H)))
-            idx = 1
         while idx < last:
-            self.end_id = min(self.end_id + 1, L - 1)
-            fid = self.end_id
-            if fid not in self.cache:                    # features of the next `lookahead` new frames in one batch
-                ids = sorted(set(min(fid + j, L - 1) for j in range(self.lookahead)))
-                ids = ids + [ids[-1]] * (self.lookahead - len(ids))      # keep the batch shape (one hipGraph)
-                fb, ab = self._features(frames[torch.tensor(ids, device=dev)].float())
-                self.cache = {i: (fb[j], None if ab is None else ab[j]) for j, i in enumerate(ids)}
-            s = self.window[0]                            # the oldest frame's slot is overwritten
-            self.feat_ring[s].copy_(self.cache[fid][0])
-            if self.parts:
-                self.ab_ring[s].copy_(self.cache[fid][1])
-            self.img_ring[s].copy_(frames[fid])
-            self.window = self.window[1:] + [s]
-            od = torch.tensor([self.window[key]] + self.window, dtype=torch.int32)
+            n = min(G, last - idx)
+            keys = [idx + b for b in range(n)] + [idx + n - 1] * (G - n)        # (a short last group repeats its last key frame)
+            # generalized_rcnn_fgfa.py:163-176,:178-181: the deque of key frame k holds frames clamp(k - key + t, 0, L - 1)
+            wins = [[min(max(k - key + t, 0), L - 1) for t in range(T)] for k in keys]
+            self._ensure(frames, sorted(set(f for w in wins for f in w)))
+            od = torch.tensor([[k % R] + [f % R for f in w] for k, w in zip(keys, wins)], dtype=torch.int32)
             self.order.copy_(od.pin_memory() if self.order.is_cuda else od, non_blocking=True)
-            pending.append(self._step((W, H)))
-            idx += 1
+            pending.extend(self._step((W, H), n))
+            idx += n
             if len(pending) >= sync_every:
                 flush()
         flush()

@@ -229,20 +229,30 @@ def deconv4x4s2_into(x, w4, bias4, out, coff, relu=0, ksplit=1):
     return out
 
 
-def flow_conv1_combine(ab, bias, dtype, key=None, order=None, T=None):
+def flow_conv1_combine(ab, bias, dtype, key=None, order=None, T=None, out=None, nwin=0):
     """FlowNetS flow_conv1 of the pairs (key frame, frame t) from the per-frame halves (mega_flow_conv1_combine): ab f32
     [S,h,w,128] = [A | B] of S frames, bias f32 [64] -> `dtype` [T,h,w,64] = leaky(A[key] + B[t] + bias), t = 0 .. T-1 (T = S by
-    default).  The key frame's slot is `key` (host int) or order[0] (device i32: the engine's ring)."""
+    default).  The key frame's slot is `key` (host int) or order[0] (device i32: the engine's ring).
+    nwin > 0: order i32 [G, 1 + nwin] = rows [key slot, slot of window position 0 .. nwin-1]: -> [G * nwin,h,w,64], pair
+    g * nwin + t = (key frame of row g, the frame at window position t) -- exactly the pairs of G key frames, in window order."""
     _gpu(ab, bias, order)
     lib = _lib.load()
     S, h, w, c = ab.shape
-    T = S if T is None else T
+    if nwin > 0:
+        assert order is not None and order.dim() == 2 and order.shape[1] == nwin + 1
+        T = order.shape[0] * nwin
+    else:
+        T = S if T is None else T
+        assert T <= S
     assert c == 128 and ab.dtype == torch.float32 and ab.is_contiguous() and bias.dtype == torch.float32 and bias.numel() == 64
-    assert dtype in _HALF and (key is not None or order is not None) and T <= S
-    out = torch.empty((T, h, w, 64), dtype=dtype, device=ab.device)
+    assert dtype in _HALF and (key is not None or order is not None)
+    assert order is None or (order.dtype == torch.int32 and order.is_contiguous())
+    if out is None:
+        out = torch.empty((T, h, w, 64), dtype=dtype, device=ab.device)
+    assert out.dtype == dtype and tuple(out.shape) == (T, h, w, 64) and out.is_contiguous()
     _tok = _pb("flow_conv1_combine", 0.0, T * h * w * 64 * 6.0)
     rc = lib.mega_flow_conv1_combine(_ptr(ab), _ptr(bias), _ptr(order), -1 if key is None else int(key), _ptr(out), T, h * w,
-                                     _DT[dtype], _stream())
+                                     int(nwin), _DT[dtype], _stream())
     _pe(_tok)
     _lib.check(rc, "mega_flow_conv1_combine")
     return out
@@ -1160,19 +1170,29 @@ def dff_warp_scale(feats, flow, scale):
     return out
 
 
-def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
+def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None, flow_pos=None):
     """feats NHWC [T,H,W,Cf+Ce], flow [T,2,H,W] f32 -> aggregated key-frame features [H,W,Cf] (+ weights [T,H,W]).
-    order (i32 [1 + T] on the device): feats / flow are rings of T slots, order[0] = the key frame's slot, order[1 + t] =
-    the slot of window position t (`key` is ignored); same bits as the call on the frames in window order."""
+    order (i32 [1 + T] on the device): feats is a ring of S >= T slots, order[0] = the key frame's slot, order[1 + t] = the
+    slot of window position t (`key` is ignored); same bits as the call on the frames in window order.  flow is indexed by
+    slot like feats ([S,2,H,W]) or, with flow_pos = the key frame's window position, by window position ([T,2,H,W]: exactly
+    the window's pairs, in window order)."""
     _gpu(feats, flow, order)
     lib = _lib.load()
-    T, H, W, C = feats.shape
-    assert feats.is_contiguous() and flow.is_contiguous() and flow.dtype == torch.float32 and flow.shape == (T, 2, H, W)
+    S, H, W, C = feats.shape
+    T = S if order is None else order.numel() - 1
+    assert feats.is_contiguous() and flow.is_contiguous() and flow.dtype == torch.float32
+    assert flow.shape == ((T if flow_pos is not None else S), 2, H, W) and (flow_pos is None or order is not None)
     out = torch.empty((H, W, Cf), dtype=feats.dtype, device=feats.device)
     wts = torch.empty((T, H, W), dtype=torch.float32, device=feats.device) if want_weights else None
     _tok = _pb("fgfa_warp", 0.0, 4.0 * feats.numel() * feats.element_size())
     if order is not None:
-        assert order.dtype == torch.int32 and order.numel() == T + 1 and order.is_contiguous()
+        assert order.dtype == torch.int32 and order.is_contiguous()
+        if flow_pos is not None:
+            rc = lib.mega_fgfa_warp_aggregate_ring_pos(_ptr(feats), _ptr(flow), _ptr(out), _ptr(wts), T, H, W, Cf, C - Cf,
+                                                       _ptr(order), int(flow_pos), _dt(feats), _stream())
+            _pe(_tok)
+            _lib.check(rc, "mega_fgfa_warp_aggregate_ring_pos")
+            return (out, wts) if want_weights else out
         rc = lib.mega_fgfa_warp_aggregate_ring(_ptr(feats), _ptr(flow), _ptr(out), _ptr(wts), T, H, W, Cf, C - Cf,
                                                _ptr(order), _dt(feats), _stream())
     else:

@@ -257,11 +257,13 @@ def fgfa_pair_taps(refs, cur=None, order=None, dtype=torch.bfloat16):
     return out
 
 
-def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None):
+def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None, flow_pos=None):
     if order is not None:          # ring form: window position t lives in slot order[1 + t], the key frame in order[0]
         slots = order[1:].long()
-        key = int((slots == int(order[0])).nonzero()[0])
-        feats, flow = feats.index_select(0, slots), flow.index_select(0, slots)
+        key = int((slots == int(order[0])).nonzero()[0]) if flow_pos is None else int(flow_pos)
+        feats = feats.index_select(0, slots)
+        if flow_pos is None:       # (flow by slot; with flow_pos it already is in window order)
+            flow = flow.index_select(0, slots)
     out, w = mo.fgfa_aggregate(feats.float().permute(0, 3, 1, 2), flow, key, nfeat=Cf)
     out = out[0].permute(1, 2, 0).contiguous().to(feats.dtype)
     return (out, w[:, 0]) if want_weights else out
@@ -375,12 +377,23 @@ def flow_level_assemble(skip, flow, w_up, b_up, out, C):
     return out
 
 
-def flow_conv1_combine(ab, bias, dtype, key=None, order=None, T=None):
+def flow_conv1_combine(ab, bias, dtype, key=None, order=None, T=None, out=None, nwin=0):
     S = ab.shape[0]
-    T = S if T is None else T
-    ks = int(order[0]) if order is not None else int(key)
-    y = ab[ks:ks + 1, :, :, :64] + ab[:T, :, :, 64:] + bias.view(1, 1, 1, 64)
-    return F.leaky_relu(y, 0.1).to(dtype)
+    if nwin > 0:
+        ys = []
+        for g in range(order.shape[0]):
+            slots = order[g, 1:].long()
+            ys.append(ab[int(order[g, 0]):int(order[g, 0]) + 1, :, :, :64] + ab.index_select(0, slots)[:, :, :, 64:])
+        y = torch.cat(ys, dim=0) + bias.view(1, 1, 1, 64)
+    else:
+        T = S if T is None else T
+        ks = int(order[0]) if order is not None else int(key)
+        y = ab[ks:ks + 1, :, :, :64] + ab[:T, :, :, 64:] + bias.view(1, 1, 1, 64)
+    y = F.leaky_relu(y, 0.1).to(dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def flow_pred_finish(z, bias, scale, out_dtype):

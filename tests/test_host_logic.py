@@ -184,6 +184,12 @@ def test_flownet_pair_taps_path_on_cpu_twins(monkeypatch):
         ab = fn.conv1_parts(refs, torch.bfloat16)
         parts = fn.run_parts(ab, torch.bfloat16, key=1).float()
         parts_ring = fn.run_parts(ab, torch.bfloat16, order=torch.tensor([1, 0, 1, 2], dtype=torch.int32)).float()
+        # two key frames in one pass: exactly their pairs, in window order (windows with a replicated frame)
+        multi = fn.run_parts_multi(ab, torch.bfloat16, torch.tensor([[1, 0, 1, 2], [2, 1, 2, 2]], dtype=torch.int32)).float()
+        second = fn.run_parts(ab, torch.bfloat16, key=2).float()
+    assert torch.equal(multi[:3], parts) and torch.equal(multi[3:], second[torch.tensor([1, 2, 2])])
+    with torch.no_grad():
+        pass
     assert new.shape == old.shape and torch.equal(new, ring)
     assert (new - old).abs().max().item() <= 0.02 * max(old.abs().max().item(), 1e-6)
     assert tuple(ab.shape[:1] + ab.shape[3:]) == (3, 128) and torch.equal(parts, parts_ring)
@@ -220,7 +226,8 @@ def test_subpixel_deconv_packing_equals_conv_transpose(shape):
     assert (out[..., Cs:Cs + C] - full).abs().max().item() < 1e-4 and (out[..., Cs + C:Cs + C + 2] - up).abs().max().item() < 1e-5
 
 
-def test_fgfa_clip_engine_equals_model_on_cpu_twins(monkeypatch):
+@pytest.mark.parametrize("group", [1, 2, 3])
+def test_fgfa_clip_engine_equals_model_on_cpu_twins(monkeypatch, group):
     """fgfa.FgfaClipEngine's host logic -- features of upcoming frames in look-ahead batches, the window in rings with a
     rotating slot table, the cold-start fill, the end-of-video clamp, restart on a second video -- against
     GeneralizedRCNNFGFA.forward frame by frame, on the CPU twins (no graphs here; the GPU test covers the graph)."""
@@ -238,9 +245,10 @@ def test_fgfa_clip_engine_equals_model_on_cpu_twins(monkeypatch):
     m1.load_state_dict(sd)
     m2.load_state_dict(sd)
     frames = synth.preprocess_cpu(synth.make_clip(L, H, W, seed=6))
-    eng = fgfa_mod.FgfaClipEngine(m2, lookahead=2, graphs=False)
+    eng = fgfa_mod.FgfaClipEngine(m2, lookahead=2, graphs=False, group=group)
     with torch.no_grad():
-        got = eng.run(frames, first=0, last=nkey)
+        got = eng.run(frames, first=0, last=4)          # in two calls: the second continues on the ring state (and, for
+        got = got + eng.run(frames, first=4, last=nkey)  # group 2 / 3, ends on a short group)
         assert len(got) == nkey
         for idx in range(nkey):          # the window is 7 frames, the video 9: the last 3 key frames see the clamped tail
             images = {"cur": frames[idx], "ref": [frames[min(L - 1, idx + 3)]], "frame_category": 0 if idx == 0 else 1,

@@ -151,7 +151,7 @@ def config5(args, dev):
     L = 64 + 40 * args.steps
     frames = torch.cat([frame(i)[None] for i in range(Tc)], dim=0)
     video = frames[torch.arange(L, device=dev) % Tc].contiguous()
-    engine = fgfa_mod.FgfaClipEngine(model, lookahead=20)
+    engine = fgfa_mod.FgfaClipEngine(model, lookahead=20, group=args.fgfa_group, pipeline=not args.fgfa_no_pipeline)
     engine.run(video, first=0, last=1 + 3 * 20)            # cold start + the eager / capture / replay warm-up
     pos = [1 + 3 * 20]
     blocks = []
@@ -256,6 +256,9 @@ def main():
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fgfa-group", type=int, default=2, help="config 5: key frames per FlowNetS pass (FgfaClipEngine group)")
+    ap.add_argument("--fgfa-no-pipeline", action="store_true", help="config 5: both graphs of a key frame on one stream")
+    ap.add_argument("--skip-call-convention", action="store_true", help="config 5: do not time the reference call convention")
     ap.add_argument("--f32-conv", default="exact", choices=["exact", "bf16x3"],
                     help="config 2: exact-f32 MFMA, or the split-precision mode (cfg.F32_CONV) -- fp32 arithmetic from three bf16 "
                          "matrix-core passes per product")
