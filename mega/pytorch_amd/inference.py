@@ -83,14 +83,85 @@ def videos_for_rank(videos, rank, world, num_frames=None):
     return [v for v in videos if lo <= v["start"] < hi]
 
 
+def resident_video(src, cfg, chunk=32):
+    """the whole video of a feed.FrameSource as preprocessed f32 frames [L,3,H,W] on the device (decode -> resize ->
+    ToTensor / BGR255 / Normalize, data/transforms/build.py:6-37), fetched in chunks: what the per-key-frame detectors and
+    FgfaClipEngine index by frame id (7.2 MB per 600 x 1000 frame)."""
+    from . import ops
+    mean, to_bgr = tuple(cfg.INPUT.PIXEL_MEAN), bool(cfg.INPUT.TO_BGR255)
+    L = src.seg_len
+    parts = []
+    for o in range(0, L, chunk):
+        ids = list(range(o, min(L, o + chunk)))
+        parts.append(ops.preprocess_frames(src.fetch(ids).contiguous(), mean, to_bgr))
+    return torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
+
+
+def frame_feed(cfg, frames, idx):
+    """What the reference's test datasets hand the detector for frame `idx` of a video (frames = resident_video):
+      base  vid.py                the image
+      dff   vid_dff.py:53-71      {"cur", "is_key_frame": frame_id % 10 == 0}
+      rdn   vid_rdn.py:49-83      {"cur", "ref": [frame min(L-1, id + MAX_OFFSET)], "frame_category", "seg_len", ...}
+      fgfa  vid_fgfa.py:49-83     the same with FGFA.MAX_OFFSET
+    (for frame_category 0 the reference's detector reads frames 1 .. MAX_OFFSET itself through "img_dir" / "pattern" /
+    "transforms"; here they travel as the extension "ref_init": already preprocessed, already on the device)."""
+    method = cfg.MODEL.VID.METHOD
+    L = frames.shape[0]
+    if method == "base":
+        return frames[idx]
+    if method == "dff":
+        return {"cur": frames[idx], "is_key_frame": idx % 10 == 0}
+    if method in ("rdn", "fgfa"):
+        mo = (cfg.MODEL.VID.RDN if method == "rdn" else cfg.MODEL.VID.FGFA).MAX_OFFSET
+        d = {"cur": frames[idx], "ref": [frames[min(L - 1, idx + mo)]], "frame_category": 0 if idx == 0 else 1, "seg_len": L}
+        if idx == 0:
+            d["ref_init"] = [frames[i] for i in range(1, min(mo, L - 1) + 1)]
+        return d
+    raise ValueError("frame_feed: MODEL.VID.METHOD = %r (mega runs through ClipEngine)" % method)
+
+
 def compute_on_dataset(model, index, img_dir, device, videos=None, steps_per_batch=10, seed=0, timer=None,
                        source_kwargs=None, engine_kwargs=None):
-    """inference.py:17-47: -> {dataset index: BoxList on the host}.  The engine runs with reuse_records=True unless
-    engine_kwargs says otherwise: every frame of a video goes through the frame stage once and serves both its
-    local-window and its global-pool role (bit-identical detections on the GPU, ~half the backbone work)."""
+    """inference.py:17-47: -> {dataset index: BoxList on the host}, for every MODEL.VID.METHOD of the reference:
+      mega         ClipEngine on the video's FrameSource.  The engine runs with reuse_records=True unless engine_kwargs says
+                   otherwise: every frame of a video goes through the frame stage once and serves both its local-window and
+                   its global-pool role (bit-identical detections on the GPU, ~half the backbone work);
+      fgfa         fgfa.FgfaClipEngine on the resident video (engine_kwargs: lookahead, graphs, pipeline, group);
+                   engine_kwargs={"per_frame": True} runs the reference's call convention instead;
+      base / dff / rdn   the detector frame by frame on the reference's own test feed (frame_feed)."""
     model.eval()
     results = {}
     videos = index.videos if videos is None else videos
+    method = model.cfg.MODEL.VID.METHOD
+    if method != "mega":
+        ek = dict(engine_kwargs or {})
+        per_frame = bool(ek.pop("per_frame", False)) or method != "fgfa"
+        eng = None
+        if not per_frame:
+            from . import fgfa as _fgfa
+            eng = _fgfa.FgfaClipEngine(model, **{k: v for k, v in ek.items() if k in ("lookahead", "graphs", "pipeline", "group")})
+        for v in videos:
+            src = feed.FrameSource(os.path.join(img_dir, "%s.JPEG"), v["pattern"], v["seg_len"], device,
+                                   min_size=model.cfg.INPUT.MIN_SIZE_TEST, max_size=model.cfg.INPUT.MAX_SIZE_TEST,
+                                   **(source_kwargs or {}))
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                frames = resident_video(src, model.cfg)
+                if eng is not None:
+                    dets = eng.run(frames, first=0, last=v["seg_len"])
+                else:
+                    dets = []
+                    for i in range(v["seg_len"]):
+                        out = model(frame_feed(model.cfg, frames, i))
+                        dets.append(out[0] if isinstance(out, (list, tuple)) else out)
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            if timer is not None:
+                timer["inference_s"] = timer.get("inference_s", 0.0) + time.perf_counter() - t0
+            for i, det in enumerate(dets):
+                results[v["start"] + i] = det.to("cpu")
+            src.close()
+        return results
     ek = dict(reuse_records=True)
     ek.update(engine_kwargs or {})
     eng = _engine.ClipEngine(model, steps_per_batch=steps_per_batch, **ek)

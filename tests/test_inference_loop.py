@@ -188,3 +188,54 @@ def test_video_partition_equals_reference_sampler():
                 assert got == want, (lens, world, rank)
                 covered += got
             assert len(covered) == len(set(covered))
+
+
+@pytest.mark.parametrize("method", ["fgfa", "base", "dff"])
+def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_path, method):
+    """engine/inference.py:17-47 for MODEL.VID.METHOD fgfa / base / dff: compute_on_dataset feeds every video through
+    feed.FrameSource -> resident preprocessed frames -> FgfaClipEngine (fgfa) or the detector frame by frame on the
+    reference's own test feed (inference.frame_feed = vid_fgfa.py / vid.py / vid_dff.py `_get_test`), and the predictions
+    equal driving the model by hand on the pre-resized clip."""
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    import mega.pytorch_amd.fgfa  # noqa: F401
+    img_dir, idx, clips = _make_dataset(str(tmp_path))
+    cfg = config.get_cfg("R-50", method)
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = MIN_S, MAX_S
+    cfg.MODEL.RPN.POST_NMS_TOP_N_TEST = 30
+    if method == "fgfa":
+        cfg.MODEL.VID.FGFA.ALL_FRAME_INTERVAL, cfg.MODEL.VID.FGFA.KEY_FRAME_LOCATION = 5, 2
+        cfg.MODEL.VID.FGFA.MIN_OFFSET, cfg.MODEL.VID.FGFA.MAX_OFFSET = -2, 2
+    sd = synth.make_dff_state_dict(seed=3) if method == "dff" else synth.make_fgfa_state_dict(seed=3)
+    if method == "base":
+        sd = {k: v for k, v in sd.items() if not k.startswith(("flownet.", "embednet."))}
+
+    def build():
+        m = modeling.build_detection_model(cfg)
+        m.load_state_dict(sd)
+        return m
+    ek = {"graphs": False, "lookahead": 3} if method == "fgfa" else None
+    preds = inference.inference(cfg, build(), img_dir, idx, output_folder=str(tmp_path / "out"), engine_kwargs=ek,
+                                source_kwargs={"workers": 2})
+    assert len(preds) == 12 and all(p.size == (MAX_S, MIN_S) for p in preds)
+    # by hand: the same detector in the reference's call convention on the pre-resized, preprocessed clip
+    model = build()
+    start = 0
+    for name, L in VIDEOS:
+        clip = torch.from_numpy(np.stack([pil_resize.resize_bilinear_u8(f, MIN_S, MAX_S) for f in clips[name]]))
+        frames = synth.preprocess_cpu(clip)
+        for i in range(L):
+            with torch.no_grad():
+                out = model(inference.frame_feed(cfg, frames, i))
+            ref = out[0] if isinstance(out, (list, tuple)) else out
+            p = preds[start + i]
+            if method == "fgfa":      # (the engine batches the backbone over look-ahead frames: MKL is not batch-invariant on
+                assert abs(len(p) - len(ref)) <= 2, (name, i, len(p), len(ref))      # the CPU; the GPU test is bit-exact)
+            else:
+                assert torch.equal(p.bbox, ref.bbox) and torch.equal(p.get_field("scores"), ref.get_field("scores"))
+                assert torch.equal(p.get_field("labels"), ref.get_field("labels"))
+        start += L
+    back = inference.load_predictions(os.path.join(str(tmp_path / "out"), "predictions.pth"))
+    assert len(back) == 12 and all(torch.equal(a.bbox, b.bbox) for a, b in zip(back, preds))
