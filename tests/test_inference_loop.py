@@ -190,7 +190,7 @@ def test_video_partition_equals_reference_sampler():
             assert len(covered) == len(set(covered))
 
 
-@pytest.mark.parametrize("method", ["fgfa", "base", "dff"])
+@pytest.mark.parametrize("method", ["fgfa", "base", "dff", "rdn"])
 def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_path, method):
     """engine/inference.py:17-47 for MODEL.VID.METHOD fgfa / base / dff: compute_on_dataset feeds every video through
     feed.FrameSource -> resident preprocessed frames -> FgfaClipEngine (fgfa) or the detector frame by frame on the
@@ -200,6 +200,7 @@ def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_pat
     cpu_ops.install(monkeypatch)
     torch.set_num_threads(8)
     import mega.pytorch_amd.fgfa  # noqa: F401
+    import mega.pytorch_amd.rdn  # noqa: F401
     img_dir, idx, clips = _make_dataset(str(tmp_path))
     cfg = config.get_cfg("R-50", method)
     cfg.MODEL.DEVICE = "cpu"
@@ -208,7 +209,12 @@ def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_pat
     if method == "fgfa":
         cfg.MODEL.VID.FGFA.ALL_FRAME_INTERVAL, cfg.MODEL.VID.FGFA.KEY_FRAME_LOCATION = 5, 2
         cfg.MODEL.VID.FGFA.MIN_OFFSET, cfg.MODEL.VID.FGFA.MAX_OFFSET = -2, 2
-    sd = synth.make_dff_state_dict(seed=3) if method == "dff" else synth.make_fgfa_state_dict(seed=3)
+    if method == "rdn":
+        cfg.MODEL.VID.RDN.ALL_FRAME_INTERVAL, cfg.MODEL.VID.RDN.KEY_FRAME_LOCATION = 5, 2
+        cfg.MODEL.VID.RDN.MIN_OFFSET, cfg.MODEL.VID.RDN.MAX_OFFSET = -2, 2
+        cfg.MODEL.VID.RPN.REF_POST_NMS_TOP_N = 20
+    sd = synth.make_dff_state_dict(seed=3) if method == "dff" else (
+        synth.make_rdn_state_dict(advanced_stage=1, seed=3) if method == "rdn" else synth.make_fgfa_state_dict(seed=3))
     if method == "base":
         sd = {k: v for k, v in sd.items() if not k.startswith(("flownet.", "embednet."))}
 
