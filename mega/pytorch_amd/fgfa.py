@@ -563,6 +563,8 @@ class FgfaClipEngine(object):
         300-row GEMMs leave most of the chip idle); detection counts are read a batch of steps later.
     Detections are identical to `model(images)` frame by frame (tests/test_e2e_gpu.py::test_fgfa_engine_equals_model)."""
 
+    DEPTH = 3        # groups the first stream may run ahead of the second (staging buffers of aggregated maps)
+
     def __init__(self, model, lookahead=20, graphs=True, pipeline=True, group=2):
         self.m = model
         self.pipeline = pipeline             # graphs A and B on two streams (see _step); False: one graph on one stream
@@ -673,9 +675,10 @@ class FgfaClipEngine(object):
         if self.graph == "armed":
             # Graph A (FlowNetS + warp of the group: whole-chip GEMMs) replays on the current stream, graph B (RPN, box head,
             # post-processing of ONE key frame: ~0.8 ms of one-block kernels and GEMMs on 2394 / 300 rows) on a second stream
-            # (pipeline=True), so that B of a group runs BESIDE A of the next.  B reads its own copy of an aggregated map (5 MB,
-            # made on B's stream); A's next replay waits for the last of those copies only.  The graphs replay concurrently:
-            # each has its own memory pool (torch's default for separately captured graphs).
+            # (pipeline=True), so that B of a group runs BESIDE A of the following groups.  A's maps are copied (on A's stream,
+            # 10 MB) into one of DEPTH staging buffers; B takes them from there, so A runs up to DEPTH groups ahead of B: with a
+            # lead of one group A stalled 0.9 ms per key frame behind B's stretched (contended) replays (tools/gpu/trace_c5.sh).
+            # The graphs replay concurrently: each has its own memory pool (torch's default for separately captured graphs).
             cur.synchronize()
             if self._sb is None and self.pipeline:
                 self._sb = torch.cuda.Stream(device=self.feat_ring.device)
@@ -683,27 +686,32 @@ class FgfaClipEngine(object):
             with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 self._agg_out = self._body_a()
             self._agg_in = self._agg_out[0].clone()
-            self._agg_stage = self._agg_out.clone()
+            self._agg_stage = [self._agg_out.clone() for _ in range(self.DEPTH)]
             cur.synchronize()
             with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                 self._out = self._body_b(self._agg_in, size)
             self.graph = (ga, gb)
-            self._ea, self._ec = torch.cuda.Event(), torch.cuda.Event()
-            self._ec.record(cur)
+            self._es = [torch.cuda.Event() for _ in range(self.DEPTH)]      # staging buffer j holds a group's maps
+            self._eb = [torch.cuda.Event() for _ in range(self.DEPTH)]      # B has consumed staging buffer j
+            for e in self._eb:
+                e.record(cur)
+            self._turn = 0
         ga, gb = self.graph
-        cur.wait_event(self._ec)              # B's copy of the previous group's aggregated maps is done
+        j = self._turn
+        self._turn = (j + 1) % self.DEPTH
+        cur.wait_event(self._eb[j])           # B is done with the maps this group's copy overwrites (DEPTH groups ago)
         ga.replay()
-        self._ea.record(cur)
+        self._agg_stage[j].copy_(self._agg_out)
+        self._es[j].record(cur)
         sb = self._sb if self.pipeline else cur
-        sb.wait_event(self._ea)
+        sb.wait_event(self._es[j])
         outs = []
         with torch.cuda.stream(sb):
-            self._agg_stage.copy_(self._agg_out)      # the group's maps, copied at once: A's next replay waits for this only
-            self._ec.record(sb)
             for b in range(n):
-                self._agg_in.copy_(self._agg_stage[b])
+                self._agg_in.copy_(self._agg_stage[j][b])
                 gb.replay()
                 outs.append(tuple(t.clone() for t in self._out))
+            self._eb[j].record(sb)
         for o in outs:
             for t in o:
                 t.record_stream(cur)          # read on the current stream after the join in run()'s flush
@@ -738,8 +746,12 @@ class FgfaClipEngine(object):
                 continue
             if fid not in self.cache:
                 ids = sorted(set(min(fid + j, L - 1) for j in range(self.lookahead)))
-                ids = ids + [ids[-1]] * (self.lookahead - len(ids))      # keep the batch shape
-                fb, ab = self._features(frames[torch.tensor(ids, device=dev)].float())
+                if len(ids) == self.lookahead:                            # a contiguous run: a slice (no index upload: a
+                    batch = frames[ids[0]:ids[0] + self.lookahead]        # pageable H2D copy would drain the stream)
+                else:
+                    ids = ids + [ids[-1]] * (self.lookahead - len(ids))  # keep the batch shape
+                    batch = frames[torch.tensor(ids, device=dev)]
+                fb, ab = self._features(batch.float())
                 self.cache = {i: (fb[j], None if ab is None else ab[j]) for j, i in enumerate(ids)}
             f, ab = self.cache[fid]
             self.feat_ring[s].copy_(f)
@@ -771,17 +783,26 @@ class FgfaClipEngine(object):
 
         if first == 0 or self.feat_ring is None:
             self._reset(frames)
+        # the index tables of every group of this call, uploaded ONCE (a pinned upload per group cost the host a pinned
+        # allocation and the stream a host round trip per group)
+        plan, rows = [], []
         idx = first
         while idx < last:
             n = min(G, last - idx)
             keys = [idx + b for b in range(n)] + [idx + n - 1] * (G - n)        # (a short last group repeats its last key frame)
             # generalized_rcnn_fgfa.py:163-176,:178-181: the deque of key frame k holds frames clamp(k - key + t, 0, L - 1)
             wins = [[min(max(k - key + t, 0), L - 1) for t in range(T)] for k in keys]
-            self._ensure(frames, sorted(set(f for w in wins for f in w)))
-            od = torch.tensor([[k % R] + [f % R for f in w] for k, w in zip(keys, wins)], dtype=torch.int32)
-            self.order.copy_(od.pin_memory() if self.order.is_cuda else od, non_blocking=True)
-            pending.extend(self._step((W, H), n))
+            plan.append((n, sorted(set(f for w in wins for f in w))))
+            rows.append([[k % R] + [f % R for f in w] for k, w in zip(keys, wins)])
             idx += n
+        if not plan:
+            return out
+        od = torch.tensor(rows, dtype=torch.int32)                               # [groups, G, 1 + T]
+        od = od.pin_memory().to(self.order.device, non_blocking=True) if self.order.is_cuda else od
+        for gi, (n, fids) in enumerate(plan):
+            self._ensure(frames, fids)
+            self.order.copy_(od[gi])
+            pending.extend(self._step((W, H), n))
             if len(pending) >= sync_every:
                 flush()
         flush()

@@ -145,7 +145,10 @@ def config5(args, dev):
     def steady(_):
         step(state["i"])
         state["i"] += 1
-    med_call, blocks_call = timed(steady, args.steps, min_seconds=0.5)
+    if args.skip_call_convention:
+        med_call, blocks_call = float("inf"), []
+    else:
+        med_call, blocks_call = timed(steady, args.steps, min_seconds=0.5)
     # ---- the clip engine (fgfa.FgfaClipEngine): batched features, ring window, one hipGraph per key frame
     from mega.pytorch_amd import fgfa as fgfa_mod
     L = 64 + 40 * args.steps
@@ -166,7 +169,7 @@ def config5(args, dev):
             break
     sb = sorted(blocks)
     med = sb[len(sb) // 2]
-    fam, summ = families(ops, lambda: [steady(0) for _ in range(4)], 4)
+    fam, summ = ({}, {}) if args.skip_call_convention else families(ops, lambda: [steady(0) for _ in range(4)], 4)
     warp = summ.get("fgfa_warp")
     h, w = (args.height - 1) // 16 + 1, (args.width - 1) // 16 + 1
     esz = 2 if args.dtype == "bfloat16" else 4
