@@ -251,9 +251,54 @@ def config2(args, dev):
             "kernel_families": fam, "blocks_ms": [round(1e3 * b, 2) for b in blocks]}
 
 
+def method_line(args, dev, method):
+    """SURVEY 8f rows 3 / 4 (the reference's other video detectors) to the measurement bar: RDN (R-101, base + advanced stage,
+    configs/RDN/vid_R_101_C4_RDN_1x.yaml) and DFF (R-101, key frame every 10 frames, configs/DFF) driven frame by frame in the
+    reference's call convention on the reference's own test feed (inference.frame_feed), frames resident in HBM."""
+    from mega.pytorch_amd import config, inference, modeling, ops, synth
+    import mega.pytorch_amd.fgfa  # noqa: F401
+    import mega.pytorch_amd.rdn  # noqa: F401
+    cfg = config.get_cfg("R-101", method)
+    cfg.DTYPE = args.dtype
+    cfg.MODEL.DEVICE = str(dev)
+    if method == "rdn":
+        sd = synth.make_rdn_state_dict(blocks=(3, 4, 23), reduce_channel=False, advanced_stage=1, seed=0)
+    else:
+        sd = synth.make_dff_state_dict(blocks=(3, 4, 23), reduce_channel=False, seed=0)
+    model = modeling.build_detection_model(cfg)
+    model.load_state_dict(sd)
+    model.to(dev)
+    Tc = 16
+    clip = synth.make_clip(Tc, args.height, args.width, seed=0).to(dev)
+    mean = tuple(cfg.INPUT.PIXEL_MEAN)
+    L = 40 + 4 + 30 * args.steps
+    base = ops.preprocess_frames(clip.contiguous(), mean, True)
+    video = base[torch.arange(L, device=dev) % Tc].contiguous()
+    state = {"i": 0}
+
+    def step(_):
+        out = model(inference.frame_feed(cfg, video, state["i"]))
+        state["i"] += 1
+        return out
+    for i in range(24 if method == "rdn" else 12):      # cold start + window / key-frame state
+        step(i)
+    med, blocks = timed(step, args.steps, min_seconds=1.0, max_blocks=25)
+    fam, _ = families(ops, lambda: [step(0) for _ in range(10)], 10)
+    what = {"rdn": "GeneralizedRCNNRDN R-101-C4 (relation distillation: base stage over 300 key + 37 x 75 reference proposals, "
+                   "advanced stage on the distilled 20 %), one model(images) call per frame (SURVEY 8f row 3)",
+            "dff": "GeneralizedRCNNDFF R-101-C4: the backbone on every 10th frame, FlowNetS (1 pair) + warp x scale on the others, "
+                   "RPN + conv5 box head per frame; one model(images) call per frame (SURVEY 8f row 4)"}[method]
+    return {"metric": "frames/sec %s R-101 inference, %dx%d frames" % (method.upper(), args.width, args.height),
+            "value": round(args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(1e3 * med / args.steps, 3),
+            "config": {"workload": what, "driver": "the reference's call convention (no clip engine for this method): host-bound at "
+                                                   "batch 1, the detection count is read back every frame"},
+            "kernel_families": fam, "blocks_ms": [round(1e3 * b, 2) for b in blocks]}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, required=True, choices=[1, 2, 5])
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 5])
+    ap.add_argument("--method", default=None, choices=["rdn", "dff"], help="instead of --config: the line of SURVEY 8f row 3 / 4")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--height", type=int, default=600)
@@ -271,7 +316,10 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     with torch.no_grad():
-        line = {1: config1, 2: config2, 5: config5}[args.config](args, dev)
+        if args.method:
+            line = method_line(args, dev, args.method)
+        else:
+            line = {1: config1, 2: config2, 5: config5}[args.config](args, dev)
     line.setdefault("dtype", "bf16" if args.dtype == "bfloat16" else "f32")
     line.update({"n_gpus": 1, "steps": args.steps, "higher_is_better": True, "data": "synthetic", "vs_baseline": None})
     os.write(json_fd, (json.dumps(line) + "\n").encode())

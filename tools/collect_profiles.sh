@@ -26,6 +26,7 @@ for mode in bf16x3:x3 float16:f16 f16x2:f16x2; do
   python tools/pmc_summary.py $src/${m}_pmc_FETCH_SIZE/pmc_counter_collection.csv $src/${m}_pmc_WRITE_SIZE/pmc_counter_collection.csv $dst/${tag}_${s}_pmc > /dev/null
   python tools/pmc_summary.py --mfma-busy $src/${m}_pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_counter_collection.csv $src/${m}_pmc_GRBM_GUI_ACTIVE/pmc_counter_collection.csv $dst/${tag}_${s}_pmc_mfma_busy.csv > /dev/null
 done
+for m in rdn dff; do [ -s $src/method_$m.json ] && cp $src/method_$m.json $dst/${tag}_method_$m.json; done
 # config 5 under rocprofv3 + its per-launch table (round 6)
 [ -s $src/c5_prof/c5_kernel_stats.csv ] && cp $src/c5_prof/c5_kernel_stats.csv $dst/${tag}_c5_rocprofv3_kernel_stats.csv
 [ -s $src/config5_under_rocprof.json ] && cp $src/config5_under_rocprof.json $dst/${tag}_config5_under_rocprofv3.json

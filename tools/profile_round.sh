@@ -60,6 +60,7 @@ timeout 120 python tools/gpu/bneck_bench.py > $out/bneck_bench.txt 2>&1; tail -5
 # the other BASELINE configurations
 for c in 1 2 5; do timeout 300 python tools/bench_configs.py --config $c > $out/config$c.json 2> $out/config$c.err; cut -c1-160 $out/config$c.json; done
 timeout 300 python tools/bench_configs.py --config 1 --dtype float32 --no-cpu-baseline > $out/config1_f32.json 2> $out/config1_f32.err; cut -c1-160 $out/config1_f32.json
+for m in rdn dff; do timeout 300 python tools/bench_configs.py --method $m > $out/method_$m.json 2> $out/method_$m.err; cut -c1-120 $out/method_$m.json; done
 # config 5 (FGFA) under rocprofv3 (kernel stats of the engine's steady state) + its per-launch table
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/c5_prof -o c5 -- python $root/tools/bench_configs.py --config 5 --no-cpu-baseline > $root/$out/config5_under_rocprof.json 2> $root/$out/c5_prof.err); rm -f $out/c5_prof/c5_kernel_trace.csv; ls $out/c5_prof | head -3
 timeout 200 python tools/gpu/flownet_layers.py > $out/c5_layers.txt 2>&1; grep "FlowNetS on" $out/c5_layers.txt
