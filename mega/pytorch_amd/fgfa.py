@@ -564,9 +564,13 @@ class FgfaClipEngine(object):
     Detections are identical to `model(images)` frame by frame (tests/test_e2e_gpu.py::test_fgfa_engine_equals_model)."""
 
     DEPTH = 3        # groups the first stream may run ahead of the second (staging buffers of aggregated maps)
+    lanes = 1        # graph-B lanes (streams): 1 hides the box head beside FlowNetS here; DffClipEngine uses more
+    fork_select = True   # graph B forks the one-block proposal selection to a side stream beside res5
 
-    def __init__(self, model, lookahead=20, graphs=True, pipeline=True, group=2):
+    def __init__(self, model, lookahead=20, graphs=True, pipeline=True, group=2, lanes=1):
         self.m = model
+        self.lanes = max(1, int(lanes))
+        self.fork_select = self.lanes == 1   # (see DffClipEngine: forked graphs on several lanes crash the HIP runtime)
         self.pipeline = pipeline             # graphs A and B on two streams (see _step); False: one graph on one stream
         self.parts = model.dtype in (torch.bfloat16, torch.float16)    # FlowNetS's first conv per frame, kept in a ring
         self.group = max(1, int(group))      # key frames per FlowNetS pass
@@ -627,22 +631,24 @@ class FgfaClipEngine(object):
             self._dbg_a = [(flows[b], aggs[b]) for b in range(G)]
         return torch.stack(aggs, dim=0)
 
-    def _body_b(self, agg, size):
+    def _body_b(self, agg, size, lane=0):
         """RPN + conv5 box head + post-processing on ONE aggregated map [h,w,1024]"""
         m = self.m
         W, H = size
         feats = (_nchw_view(agg.unsqueeze(0)),)
         box = m.roi_heads.box
         fe = box.feature_extractor
-        if agg.is_cuda and not ops.profiling():
+        if agg.is_cuda and not ops.profiling() and self.fork_select:
             # the proposal selection is ONE block (top-k, decode, NMS of one frame: ~0.38 ms on 1 of 256 CUs) and res5 on the
-            # whole map does not need its result: fork it to a side stream, join before ROIAlign
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(device=agg.device)
+            # whole map does not need its result: fork it to a side stream (one per lane), join before ROIAlign
+            sides = self.__dict__.setdefault("_sides", {})
+            if lane not in sides:
+                sides[lane] = torch.cuda.Stream(device=agg.device)
+            side = sides[lane]
             hold = []
-            props, _, cnt = m.rpn.propose(_nhwc(feats[0]), W, H, "key", select_stream=self._side, hold=hold)
+            props, _, cnt = m.rpn.propose(_nhwc(feats[0]), W, H, "key", select_stream=side, hold=hold)
             y = fe.full_map(feats)
-            torch.cuda.current_stream(agg.device).wait_stream(self._side)
+            torch.cuda.current_stream(agg.device).wait_stream(side)
             del hold
             x = fe.pooled_fc(y, [props[0]])
         else:
@@ -680,38 +686,49 @@ class FgfaClipEngine(object):
             # lead of one group A stalled 0.9 ms per key frame behind B's stretched (contended) replays (tools/gpu/trace_c5.sh).
             # The graphs replay concurrently: each has its own memory pool (torch's default for separately captured graphs).
             cur.synchronize()
+            nl = self.lanes if self.pipeline else 1
             if self._sb is None and self.pipeline:
-                self._sb = torch.cuda.Stream(device=self.feat_ring.device)
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                self._sb = [torch.cuda.Stream(device=self.feat_ring.device) for _ in range(nl)]
+            ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 self._agg_out = self._body_a()
-            self._agg_in = self._agg_out[0].clone()
             self._agg_stage = [self._agg_out.clone() for _ in range(self.DEPTH)]
-            cur.synchronize()
-            with torch.cuda.graph(gb, capture_error_mode="thread_local"):
-                self._out = self._body_b(self._agg_in, size)
-            self.graph = (ga, gb)
+            # graph B once per LANE (its own input, outputs, pool and side stream): the key frames of a group are dealt to the
+            # lanes round-robin, each lane replaying on its own stream -- B is a latency chain of small launches (0.8-0.9 ms per
+            # key frame), and when graph A is short (DffClipEngine: 10 pairs per 10 frames) ONE lane of B is the bottleneck
+            self._agg_in, self._out, gbs = [], [], []
+            for l in range(nl):
+                self._agg_in.append(self._agg_out[0].clone())
+                cur.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._out.append(self._body_b(self._agg_in[l], size, lane=l))
+                gbs.append(g)
+            self.graph = (ga, gbs)
             self._es = [torch.cuda.Event() for _ in range(self.DEPTH)]      # staging buffer j holds a group's maps
-            self._eb = [torch.cuda.Event() for _ in range(self.DEPTH)]      # B has consumed staging buffer j
-            for e in self._eb:
-                e.record(cur)
+            self._eb = [[torch.cuda.Event() for _ in range(nl)] for _ in range(self.DEPTH)]   # lane l has consumed buffer j
+            for ev in self._eb:
+                for e in ev:
+                    e.record(cur)
             self._turn = 0
-        ga, gb = self.graph
+        ga, gbs = self.graph
         j = self._turn
         self._turn = (j + 1) % self.DEPTH
-        cur.wait_event(self._eb[j])           # B is done with the maps this group's copy overwrites (DEPTH groups ago)
+        for e in self._eb[j]:
+            cur.wait_event(e)                 # B is done with the maps this group's copy overwrites (DEPTH groups ago)
         ga.replay()
         self._agg_stage[j].copy_(self._agg_out)
         self._es[j].record(cur)
-        sb = self._sb if self.pipeline else cur
-        sb.wait_event(self._es[j])
-        outs = []
-        with torch.cuda.stream(sb):
-            for b in range(n):
-                self._agg_in.copy_(self._agg_stage[j][b])
-                gb.replay()
-                outs.append(tuple(t.clone() for t in self._out))
-            self._eb[j].record(sb)
+        outs = [None] * n
+        for l, g in enumerate(gbs):
+            sb = self._sb[l] if self.pipeline else cur
+            sb.wait_event(self._es[j])
+            with torch.cuda.stream(sb):
+                for b in range(l, n, len(gbs)):
+                    self._agg_in[l].copy_(self._agg_stage[j][b])
+                    g.replay()
+                    outs[b] = tuple(t.clone() for t in self._out[l])
+                self._eb[j][l].record(sb)
         for o in outs:
             for t in o:
                 t.record_stream(cur)          # read on the current stream after the join in run()'s flush
@@ -774,8 +791,8 @@ class FgfaClipEngine(object):
         def flush():
             if not pending:
                 return
-            if self._sb is not None:
-                torch.cuda.current_stream().wait_stream(self._sb)     # (the second halves of the pending key frames)
+            for s_ in (self._sb or []):
+                torch.cuda.current_stream().wait_stream(s_)           # (the second halves of the pending key frames)
             counts = torch.cat([p[3] for p in pending]).tolist()
             for (ob, os_, ol, _), n in zip(pending, counts):
                 out.append(PostProcessor.materialize((ob, os_, ol, None), int(n), (W, H)))
@@ -803,6 +820,123 @@ class FgfaClipEngine(object):
             self._ensure(frames, fids)
             self.order.copy_(od[gi])
             pending.extend(self._step((W, H), n))
+            if len(pending) >= sync_every:
+                flush()
+        flush()
+        return out
+
+
+class DffClipEngine(FgfaClipEngine):
+    """Clip-level driver for GeneralizedRCNNDFF (generalized_rcnn_dff.py:19-138, feed: vid_dff.py test mode --
+    a key frame every `interval` = 10 frames): the two-graph / two-stream form of FgfaClipEngine for deep feature flow.
+
+    `model(images)` runs, per frame and at batch 1, FlowNetS on ONE image pair (its coarse levels have 40-600 GEMM rows), a warp,
+    the RPN and the conv5 box head, and reads the detection count back: host- and latency-bound (600 FPS on R-101).  Here
+      * the backbone runs on `lookahead` upcoming KEY frames in one batch;
+      * graph A = FlowNetS on the `interval` pairs (frame, key frame) of a key-frame interval in ONE pass + their warp x scale
+        (mega_dff_warp_scale) -> `interval` feature maps;
+      * graph B = RPN selection, res5 + ROIAlign + fc6 / fc7, predictor, post-processing of one frame, replayed per frame on a
+        second stream beside graph A of the following intervals (FgfaClipEngine._step).
+    Detections are identical to `model(images)` frame by frame (tests/test_e2e_gpu.py::test_dff_engine_equals_model)."""
+
+    def __init__(self, model, interval=10, lookahead=8, graphs=True, pipeline=True, lanes=2):
+        self.m = model
+        self.pipeline = pipeline
+        self.lanes = max(1, int(lanes))      # graph-B lanes: two frames' box heads in flight (FgfaClipEngine._step)
+        # With several lanes graph B does NOT fork its proposal selection to a side stream: two lanes of forked graphs replayed
+        # concurrently segfault inside hipGraphLaunch on this runtime (ROCm 7.0.2; reproducibly at 2 lanes, not at 3 or 4:
+        # profiles/r06_dff_engine_lanes.txt) -- and two plain lanes are as fast as three forked ones (1260 vs 1270 FPS)
+        self.fork_select = self.lanes == 1
+        self.group = int(interval)           # frames per graph A = the key-frame interval (vid_dff.py:62: frame_id % 10 == 0)
+        self._sb = None
+        self.lookahead = lookahead
+        self.use_graphs = graphs
+        self.graph = None
+        self.fgraphs = {}
+        self.replays = 0
+        self.feat_ring = None
+        self.keep_intermediates = False
+
+    def _features(self, imgs):
+        """backbone of a batch of key frames -> NHWC [n,h,w,1024] (replayed from a hipGraph per batch size)"""
+        m = self.m
+
+        def body(x):
+            return _nhwc(m.backbone(x)[0]).contiguous()
+        if not (self.use_graphs and imgs.is_cuda):
+            return body(imgs)
+        ent = self.fgraphs.setdefault(tuple(imgs.shape), {})
+        if "seen" not in ent:
+            ent["seen"] = True
+            return body(imgs)
+        if "graph" not in ent:
+            ent["in"] = imgs.clone()
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                ent["out"] = body(ent["in"])
+            ent["graph"] = g
+        ent["in"].copy_(imgs)
+        ent["graph"].replay()
+        return ent["out"].clone()
+
+    def _body_a(self):
+        """FlowNetS on the interval's pairs (frame, key frame) + warp x scale -> [interval,h,w,1024]"""
+        m = self.m
+        n = self.group
+        flow, scale = m.flownet.pairs(self.key_img.expand(n, -1, -1, -1), self.cur_imgs, m.dtype)      # :132 cat([cur, key])
+        aggs = [ops.dff_warp_scale(self.key_feat, flow[i].contiguous(), scale[i].contiguous()) for i in range(n)]
+        if self.keep_intermediates:
+            self._dbg_a = [(flow[i], aggs[i]) for i in range(n)]
+        return torch.stack(aggs, dim=0)
+
+    @torch.no_grad()
+    def run(self, frames, first=0, last=None, sync_every=20):
+        """frames: preprocessed f32 [L,3,H,W] on the device.  Frames first..last-1 (first a multiple of the interval)
+        -> list[BoxList]."""
+        L = frames.shape[0]
+        last = L if last is None else last
+        H, W = frames.shape[-2:]
+        I = self.group
+        if first % I:
+            raise ValueError("DffClipEngine.run: first = %d is not a key frame (multiple of %d)" % (first, I))
+        out, pending = [], []
+
+        def flush():
+            if not pending:
+                return
+            for s_ in (self._sb or []):
+                torch.cuda.current_stream().wait_stream(s_)
+            counts = torch.cat([p[3] for p in pending]).tolist()
+            for (ob, os_, ol, _), n in zip(pending, counts):
+                out.append(PostProcessor.materialize((ob, os_, ol, None), int(n), (W, H)))
+            del pending[:]
+
+        sig = (H, W, str(frames.device))
+        if self.feat_ring is None or self._sig != sig:
+            f = self._features(frames[0:1].float())
+            self.key_feat = torch.zeros_like(f[0])
+            self.feat_ring = self.key_feat                        # (what FgfaClipEngine._step asks for the device)
+            self.key_img = frames.new_zeros((1, 3, H, W), dtype=torch.float32)
+            self.cur_imgs = frames.new_zeros((I, 3, H, W), dtype=torch.float32)
+            self._sig = sig
+            self.graph = None
+        cache = {}
+        k0 = first
+        while k0 < last:
+            if k0 not in cache:                                   # the backbone of the next `lookahead` key frames in one batch
+                ids = [k for k in range(k0, L, I)][:self.lookahead]
+                ids = ids + [ids[-1]] * (self.lookahead - len(ids))
+                fb = self._features(frames[torch.tensor(ids, device=frames.device)].float())
+                cache = {k: fb[j] for j, k in enumerate(ids)}
+            n = min(I, last - k0, L - k0)
+            self.key_feat.copy_(cache[k0])
+            self.key_img.copy_(frames[k0:k0 + 1])
+            self.cur_imgs[:n].copy_(frames[k0:k0 + n])
+            if n < I:                                             # a short last interval: the graph's shape stays, the tail repeats
+                self.cur_imgs[n:].copy_(frames[k0 + n - 1:k0 + n].expand(I - n, -1, -1, -1))
+            pending.extend(self._step((W, H), n))
+            k0 += I
             if len(pending) >= sync_every:
                 flush()
         flush()

@@ -275,6 +275,34 @@ def test_fgfa_clip_engine_equals_model_on_cpu_twins(monkeypatch, group):
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("labels"), b.get_field("labels"))
 
 
+def test_dff_clip_engine_equals_model_on_cpu_twins(monkeypatch):
+    """fgfa.DffClipEngine's host logic -- key frames every `interval` frames, their backbone in look-ahead batches, the
+    interval's pairs in one FlowNetS pass, a short last interval -- against GeneralizedRCNNDFF.forward frame by frame on
+    vid_dff.py's test feed, on the CPU twins (no graphs here; the GPU test covers graphs and streams)."""
+    from mega.pytorch_amd import fgfa as fgfa_mod, inference
+    cpu_ops.install(monkeypatch)
+    torch.set_num_threads(8)
+    H, W, L = 64, 96, 11
+    cfg = config.get_cfg("R-50", "dff")
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.RPN.POST_NMS_TOP_N_TEST = 40
+    sd = synth.make_dff_state_dict(seed=3)
+    m1, m2 = modeling.build_detection_model(cfg), modeling.build_detection_model(cfg)
+    m1.load_state_dict(sd)
+    m2.load_state_dict(sd)
+    frames = synth.preprocess_cpu(synth.make_clip(L, H, W, seed=6))
+    eng = fgfa_mod.DffClipEngine(m2, interval=10, lookahead=2, graphs=False)
+    with torch.no_grad():
+        got = eng.run(frames)
+        assert len(got) == L
+        for idx in range(L):
+            ref = m1(inference.frame_feed(cfg, frames, idx))[0]
+            # (the twins' GEMMs are not batch-invariant to the last bit: counts within round-off of the score threshold)
+            assert abs(len(ref) - len(got[idx])) <= 2, (idx, len(ref), len(got[idx]))
+            n = min(len(ref), len(got[idx]), 5)
+            assert (ref.bbox[:n] - got[idx].bbox[:n]).abs().max() < 0.05 if n else True
+
+
 def test_base_detector_matches_oracle(monkeypatch):
     """single-frame GeneralizedRCNN (BASELINE config 1) on the CPU twins == BaseOracle."""
     cpu_ops.install(monkeypatch)

@@ -154,7 +154,8 @@ def config5(args, dev):
     L = 64 + 40 * args.steps
     frames = torch.cat([frame(i)[None] for i in range(Tc)], dim=0)
     video = frames[torch.arange(L, device=dev) % Tc].contiguous()
-    engine = fgfa_mod.FgfaClipEngine(model, lookahead=20, group=args.fgfa_group, pipeline=not args.fgfa_no_pipeline)
+    engine = fgfa_mod.FgfaClipEngine(model, lookahead=20, group=args.fgfa_group, pipeline=not args.fgfa_no_pipeline,
+                                     lanes=args.lanes or 1)
     engine.run(video, first=0, last=1 + 3 * 20)            # cold start + the eager / capture / replay warm-up
     pos = [1 + 3 * 20]
     blocks = []
@@ -271,7 +272,7 @@ def method_line(args, dev, method):
     Tc = 16
     clip = synth.make_clip(Tc, args.height, args.width, seed=0).to(dev)
     mean = tuple(cfg.INPUT.PIXEL_MEAN)
-    L = 40 + 4 + 30 * args.steps
+    L = 120 + 4 + 40 * args.steps
     base = ops.preprocess_frames(clip.contiguous(), mean, True)
     video = base[torch.arange(L, device=dev) % Tc].contiguous()
     state = {"i": 0}
@@ -284,14 +285,34 @@ def method_line(args, dev, method):
         step(i)
     med, blocks = timed(step, args.steps, min_seconds=1.0, max_blocks=25)
     fam, _ = families(ops, lambda: [step(0) for _ in range(10)], 10)
+    engine_line = None
+    if method == "dff":       # the clip engine (fgfa.DffClipEngine): one FlowNetS pass per key-frame interval, two graphs / streams
+        from mega.pytorch_amd import fgfa as fgfa_mod
+        eng = fgfa_mod.DffClipEngine(model, interval=10, lookahead=8, lanes=args.lanes or 2)
+        if os.environ.get("MEGA_NO_FORK_SELECT") == "0":      # (experiments: the forked selection on several lanes)
+            eng.fork_select = True
+        eng.run(video, first=0, last=80)
+        eb, pos = [], 80
+        while pos + 40 <= L and sum(eb) < 1.0:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.run(video, first=pos, last=pos + 40, sync_every=40)
+            torch.cuda.synchronize()
+            eb.append(time.perf_counter() - t0)
+            pos += 40
+        em = sorted(eb)[len(eb) // 2]
+        engine_line = {"fps": round(40 / em, 2), "ms_per_frame": round(1e3 * em / 40, 3), "blocks_of_40_frames_ms": [round(1e3 * b, 2) for b in eb[:8]],
+                       "driver": "fgfa.DffClipEngine: backbone of 8 upcoming key frames per launch, FlowNetS on the 10 pairs of a key-frame "
+                                 "interval in one pass, the box head's hipGraph per frame on a second stream (identical detections to the "
+                                 "per-call path: tests/test_e2e_gpu.py::test_dff_engine_equals_model)", "graph_replays": eng.replays}
     what = {"rdn": "GeneralizedRCNNRDN R-101-C4 (relation distillation: base stage over 300 key + 37 x 75 reference proposals, "
                    "advanced stage on the distilled 20 %), one model(images) call per frame (SURVEY 8f row 3)",
             "dff": "GeneralizedRCNNDFF R-101-C4: the backbone on every 10th frame, FlowNetS (1 pair) + warp x scale on the others, "
                    "RPN + conv5 box head per frame; one model(images) call per frame (SURVEY 8f row 4)"}[method]
     return {"metric": "frames/sec %s R-101 inference, %dx%d frames" % (method.upper(), args.width, args.height),
             "value": round(args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(1e3 * med / args.steps, 3),
-            "config": {"workload": what, "driver": "the reference's call convention (no clip engine for this method): host-bound at "
-                                                   "batch 1, the detection count is read back every frame"},
+            "config": {"workload": what, "driver": "the reference's call convention: host-bound at batch 1, the detection count is read "
+                                                   "back every frame", "clip_engine": engine_line},
             "kernel_families": fam, "blocks_ms": [round(1e3 * b, 2) for b in blocks]}
 
 
@@ -306,6 +327,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fgfa-group", type=int, default=2, help="config 5: key frames per FlowNetS pass (FgfaClipEngine group)")
     ap.add_argument("--fgfa-no-pipeline", action="store_true", help="config 5: both graphs of a key frame on one stream")
+    ap.add_argument("--lanes", type=int, default=0, help="config 5 / --method dff: box-head graph lanes (0: the engine's default)")
     ap.add_argument("--skip-call-convention", action="store_true", help="config 5: do not time the reference call convention")
     ap.add_argument("--f32-conv", default="exact", choices=["exact", "bf16x3"],
                     help="config 2: exact-f32 MFMA, or the split-precision mode (cfg.F32_CONV) -- fp32 arithmetic from three bf16 "
