@@ -941,3 +941,68 @@ class DffClipEngine(FgfaClipEngine):
                 flush()
         flush()
         return out
+
+
+class BaseClipEngine(FgfaClipEngine):
+    """Clip-level driver for the single-frame GeneralizedRCNN (BASELINE configs[0], detector/generalized_rcnn.py:16-65): no
+    cross-frame state, so graph A is simply the backbone on `group` consecutive frames (one batched launch chain instead of
+    `group` single-frame ones) and graph B -- RPN selection, res5 + ROIAlign + fc6 / fc7, predictor, post-processing of one
+    frame -- replays per frame on two lanes / streams beside it (FgfaClipEngine._step).  Detections are identical to
+    `model(image)` frame by frame (tests/test_e2e_gpu.py::test_base_engine_equals_model)."""
+
+    def __init__(self, model, group=20, graphs=True, pipeline=True, lanes=2):
+        self.m = model
+        self.pipeline = pipeline
+        self.group = int(group)
+        self.lanes = max(1, int(lanes))
+        self.fork_select = self.lanes == 1
+        self._sb = None
+        self.use_graphs = graphs
+        self.graph = None
+        self.replays = 0
+        self.feat_ring = None
+        self.keep_intermediates = False
+
+    def _body_a(self):
+        maps = _nhwc(self.m.backbone(self.cur_imgs)[0]).contiguous()            # [group,h,w,1024]
+        if self.keep_intermediates:
+            self._dbg_a = [(None, maps[i]) for i in range(self.group)]
+        return maps
+
+    @torch.no_grad()
+    def run(self, frames, first=0, last=None, sync_every=40):
+        """frames: preprocessed f32 [L,3,H,W] on the device.  Frames first..last-1 -> list[BoxList]."""
+        L = frames.shape[0]
+        last = L if last is None else last
+        H, W = frames.shape[-2:]
+        G = self.group
+        out, pending = [], []
+
+        def flush():
+            if not pending:
+                return
+            for s_ in (self._sb or []):
+                torch.cuda.current_stream().wait_stream(s_)
+            counts = torch.cat([p[3] for p in pending]).tolist()
+            for (ob, os_, ol, _), n in zip(pending, counts):
+                out.append(PostProcessor.materialize((ob, os_, ol, None), int(n), (W, H)))
+            del pending[:]
+
+        sig = (H, W, str(frames.device))
+        if self.feat_ring is None or self._sig != sig:
+            self.cur_imgs = frames.new_zeros((G, 3, H, W), dtype=torch.float32)
+            self.feat_ring = self.cur_imgs                        # (what FgfaClipEngine._step asks for the device)
+            self._sig = sig
+            self.graph = None
+        k0 = first
+        while k0 < last:
+            n = min(G, last - k0)
+            self.cur_imgs[:n].copy_(frames[k0:k0 + n])
+            if n < G:
+                self.cur_imgs[n:].copy_(frames[k0 + n - 1:k0 + n].expand(G - n, -1, -1, -1))
+            pending.extend(self._step((W, H), n))
+            k0 += n
+            if len(pending) >= sync_every:
+                flush()
+        flush()
+        return out

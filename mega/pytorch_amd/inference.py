@@ -126,23 +126,26 @@ def compute_on_dataset(model, index, img_dir, device, videos=None, steps_per_bat
       mega         ClipEngine on the video's FrameSource.  The engine runs with reuse_records=True unless engine_kwargs says
                    otherwise: every frame of a video goes through the frame stage once and serves both its local-window and
                    its global-pool role (bit-identical detections on the GPU, ~half the backbone work);
-      fgfa / dff   fgfa.FgfaClipEngine / fgfa.DffClipEngine on the resident video (engine_kwargs: lookahead, graphs, pipeline,
-                   group / interval, lanes); engine_kwargs={"per_frame": True} runs the reference's call convention instead;
-      base / rdn   the detector frame by frame on the reference's own test feed (frame_feed)."""
+      fgfa / dff / base   fgfa.FgfaClipEngine / DffClipEngine / BaseClipEngine on the resident video (engine_kwargs: lookahead,
+                   graphs, pipeline, group / interval, lanes); engine_kwargs={"per_frame": True} runs the reference's call
+                   convention instead;
+      rdn          the detector frame by frame on the reference's own test feed (frame_feed)."""
     model.eval()
     results = {}
     videos = index.videos if videos is None else videos
     method = model.cfg.MODEL.VID.METHOD
     if method != "mega":
         ek = dict(engine_kwargs or {})
-        per_frame = bool(ek.pop("per_frame", False)) or method not in ("fgfa", "dff")
+        per_frame = bool(ek.pop("per_frame", False)) or method not in ("fgfa", "dff", "base")
         eng = None
         if not per_frame:
             from . import fgfa as _fgfa
             if method == "fgfa":
                 eng = _fgfa.FgfaClipEngine(model, **{k: v for k, v in ek.items() if k in ("lookahead", "graphs", "pipeline", "group", "lanes")})
-            else:
+            elif method == "dff":
                 eng = _fgfa.DffClipEngine(model, **{k: v for k, v in ek.items() if k in ("lookahead", "graphs", "pipeline", "interval", "lanes")})
+            else:
+                eng = _fgfa.BaseClipEngine(model, **{k: v for k, v in ek.items() if k in ("group", "graphs", "pipeline", "lanes")})
         for v in videos:
             src = feed.FrameSource(os.path.join(img_dir, "%s.JPEG"), v["pattern"], v["seg_len"], device,
                                    min_size=model.cfg.INPUT.MIN_SIZE_TEST, max_size=model.cfg.INPUT.MAX_SIZE_TEST,

@@ -222,7 +222,7 @@ def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_pat
         m = modeling.build_detection_model(cfg)
         m.load_state_dict(sd)
         return m
-    ek = {"graphs": False, "lookahead": 3} if method in ("fgfa", "dff") else None
+    ek = {"graphs": False, "lookahead": 3} if method in ("fgfa", "dff") else ({"graphs": False, "group": 3} if method == "base" else None)
     preds = inference.inference(cfg, build(), img_dir, idx, output_folder=str(tmp_path / "out"), engine_kwargs=ek,
                                 source_kwargs={"workers": 2})
     assert len(preds) == 12 and all(p.size == (MAX_S, MIN_S) for p in preds)
@@ -237,7 +237,7 @@ def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_pat
                 out = model(inference.frame_feed(cfg, frames, i))
             ref = out[0] if isinstance(out, (list, tuple)) else out
             p = preds[start + i]
-            if method in ("fgfa", "dff"):      # (the engines batch the backbone / FlowNetS: MKL is not batch-invariant on
+            if method in ("fgfa", "dff", "base"):      # (the engines batch the backbone / FlowNetS: MKL is not batch-invariant on
                 assert abs(len(p) - len(ref)) <= 2, (name, i, len(p), len(ref))      # the CPU; the GPU test is bit-exact)
             else:
                 assert torch.equal(p.bbox, ref.bbox) and torch.equal(p.get_field("scores"), ref.get_field("scores"))

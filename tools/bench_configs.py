@@ -78,6 +78,24 @@ def config1(args, dev):
         step(i)
     med, blocks = timed(step, args.steps)
     fam, _ = families(ops, lambda: [step(i) for i in range(4)], 4)
+    # ---- the clip engine (fgfa.BaseClipEngine): the backbone on 20 frames per launch chain, the box head's graph per frame
+    from mega.pytorch_amd import fgfa as fgfa_mod
+    Lv = 120 + 40 * args.steps
+    video = ops.preprocess_frames(clip.contiguous(), mean, True)[torch.arange(Lv, device=dev) % 8].contiguous()
+    eng = fgfa_mod.BaseClipEngine(model, group=20)
+    eng.run(video, first=0, last=80)
+    eb, pos = [], 80
+    while pos + 40 <= Lv and sum(eb) < 1.0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run(video, first=pos, last=pos + 40, sync_every=40)
+        torch.cuda.synchronize()
+        eb.append(time.perf_counter() - t0)
+        pos += 40
+    em = sorted(eb)[len(eb) // 2]
+    engine_line = {"fps": round(40 / em, 2), "ms_per_frame": round(1e3 * em / 40, 3), "blocks_of_40_frames_ms": [round(1e3 * b, 2) for b in eb[:8]],
+                   "driver": "fgfa.BaseClipEngine: the backbone on 20 frames per launch chain, the box head's hipGraph per frame on two "
+                             "lanes / streams beside it (identical detections to the per-call path: test_base_engine_equals_model)"}
     cpu = None
     if not args.no_cpu_baseline:
         # BASELINE configs[0] IS the CPU reference run: the port (oracle BaseOracle = the reference's GeneralizedRCNN
@@ -108,7 +126,8 @@ def config1(args, dev):
             "cpu_baseline": cpu,
             "value": round(args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(1e3 * med / args.steps, 3),
             "config": {"workload": "GeneralizedRCNN R-50-C4 + ResNetConv52MLPFeatureExtractor, 300 proposals, one frame "
-                                   "per call with a host read of the detection count (BASELINE configs[0])"},
+                                   "per call with a host read of the detection count (BASELINE configs[0])",
+                       "clip_engine": engine_line},
             "kernel_families": fam, "blocks_ms": [round(1e3 * b, 2) for b in blocks]}
 
 
