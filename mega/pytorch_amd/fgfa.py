@@ -558,17 +558,20 @@ class FgfaClipEngine(object):
         840-12 768 GEMM rows at 21 pairs and leave half the chip idle: 1.05 ms per key frame at 21 pairs, 0.84 at 42, 0.77
         at 84); the flow fields come out in window order per key frame (mega_fgfa_warp_aggregate_ring_pos);
       * the key frame is TWO hipGraphs on two streams: A = FlowNetS + warp of a group, B = RPN selection, res5 + ROIAlign +
-        fc6 / fc7, predictor, post-processing of one key frame (fixed 300 proposal rows, the device-side proposal count goes
-        to the post-processor); B of one group runs beside A of the next (its one-block selection / NMS kernels and
-        300-row GEMMs leave most of the chip idle); detection counts are read a batch of steps later.
+        fc6 / fc7, predictor, post-processing (fixed 300 proposal rows per frame, the device-side proposal counts go to the
+        post-processor) of the group's key frames as ONE batched launch chain (batch_head; or one replay per key frame);
+        B of one group runs beside A of the next (its one-block-per-frame selection / NMS kernels and 300-row GEMMs leave
+        most of the chip idle); detection counts are read a batch of steps later.
     Detections are identical to `model(images)` frame by frame (tests/test_e2e_gpu.py::test_fgfa_engine_equals_model)."""
 
     DEPTH = 3        # groups the first stream may run ahead of the second (staging buffers of aggregated maps)
     lanes = 1        # graph-B lanes (streams): 1 hides the box head beside FlowNetS here; DffClipEngine uses more
     fork_select = True   # graph B forks the one-block proposal selection to a side stream beside res5
+    batch_head = False   # graph B on all maps of a group in ONE batched replay (_body_bb) instead of one replay per map
 
-    def __init__(self, model, lookahead=20, graphs=True, pipeline=True, group=2, lanes=1):
+    def __init__(self, model, lookahead=20, graphs=True, pipeline=True, group=2, lanes=1, batch_head=True):
         self.m = model
+        self.batch_head = bool(batch_head)
         self.lanes = max(1, int(lanes))
         self.fork_select = self.lanes == 1   # (see DffClipEngine: forked graphs on several lanes crash the HIP runtime)
         self.pipeline = pipeline             # graphs A and B on two streams (see _step); False: one graph on one stream
@@ -661,8 +664,39 @@ class FgfaClipEngine(object):
         return ops.postprocess(logits.float().contiguous(), deltas.float().contiguous(), props[0].contiguous(), cnt,
                                pp.weights, W, H, pp.score_thresh, pp.nms, pp.detections_per_img, pp.strict_gt)
 
+    def _body_bb(self, aggs, size):
+        """_body_b for ALL maps of a group at once ([G,h,w,1024]): the RPN head, selection (one block per frame), res5, ROIAlign,
+        fc6 / fc7, predictor and post-processing as ONE batched launch chain (every kernel is batch-invariant and the batched
+        post-processor gives each image the bits of its own call) -> (boxes [G,cap,4], scores [G,cap], labels [G,cap], counts [G])"""
+        m = self.m
+        W, H = size
+        G = aggs.shape[0]
+        feats = (_nchw_view(aggs),)
+        box = m.roi_heads.box
+        fe = box.feature_extractor
+        if aggs.is_cuda and not ops.profiling():
+            sides = self.__dict__.setdefault("_sides", {})
+            if 0 not in sides:
+                sides[0] = torch.cuda.Stream(device=aggs.device)
+            hold = []
+            props, _, cnt = m.rpn.propose(_nhwc(feats[0]), W, H, "key", select_stream=sides[0], hold=hold)
+            y = fe.full_map(feats)
+            torch.cuda.current_stream(aggs.device).wait_stream(sides[0])
+            del hold
+        else:
+            props, _, cnt = m.rpn.propose(_nhwc(feats[0]), W, H, "key")
+            y = fe.full_map(feats)
+        x = fe.pooled_fc(y, [props[b] for b in range(G)])
+        logits, deltas = box.predictor(x)
+        pp = box.post_processor
+        return ops.postprocess_batched(logits.float().contiguous(), deltas.float().contiguous(), props.reshape(-1, 4).contiguous(), G,
+                                       pp.weights, W, H, pp.score_thresh, pp.nms, pp.detections_per_img, pp.strict_gt, nprop=cnt)
+
     def _eager(self, size, n):
         aggs = self._body_a()
+        if self.batch_head and not self.keep_intermediates:
+            ob, os_, ol, oc = self._body_bb(aggs, size)
+            return [(ob[b], os_[b], ol[b], oc[b:b + 1]) for b in range(n)]
         outs = []
         for b in range(n):
             outs.append(self._body_b(aggs[b], size))
@@ -686,7 +720,7 @@ class FgfaClipEngine(object):
             # lead of one group A stalled 0.9 ms per key frame behind B's stretched (contended) replays (tools/gpu/trace_c5.sh).
             # The graphs replay concurrently: each has its own memory pool (torch's default for separately captured graphs).
             cur.synchronize()
-            nl = self.lanes if self.pipeline else 1
+            nl = 1 if self.batch_head else (self.lanes if self.pipeline else 1)
             if self._sb is None and self.pipeline:
                 self._sb = [torch.cuda.Stream(device=self.feat_ring.device) for _ in range(nl)]
             ga = torch.cuda.CUDAGraph()
@@ -698,11 +732,12 @@ class FgfaClipEngine(object):
             # key frame), and when graph A is short (DffClipEngine: 10 pairs per 10 frames) ONE lane of B is the bottleneck
             self._agg_in, self._out, gbs = [], [], []
             for l in range(nl):
-                self._agg_in.append(self._agg_out[0].clone())
+                self._agg_in.append(self._agg_out.clone() if self.batch_head else self._agg_out[0].clone())
                 cur.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._out.append(self._body_b(self._agg_in[l], size, lane=l))
+                    self._out.append(self._body_bb(self._agg_in[l], size) if self.batch_head else
+                                     self._body_b(self._agg_in[l], size, lane=l))
                 gbs.append(g)
             self.graph = (ga, gbs)
             self._es = [torch.cuda.Event() for _ in range(self.DEPTH)]      # staging buffer j holds a group's maps
@@ -724,10 +759,17 @@ class FgfaClipEngine(object):
             sb = self._sb[l] if self.pipeline else cur
             sb.wait_event(self._es[j])
             with torch.cuda.stream(sb):
-                for b in range(l, n, len(gbs)):
-                    self._agg_in[l].copy_(self._agg_stage[j][b])
+                if self.batch_head:               # the whole group in one replay
+                    self._agg_in[l].copy_(self._agg_stage[j])
                     g.replay()
-                    outs[b] = tuple(t.clone() for t in self._out[l])
+                    ob, os_, ol, oc = (t.clone() for t in self._out[l])
+                    for b in range(n):
+                        outs[b] = (ob[b], os_[b], ol[b], oc[b:b + 1])
+                else:
+                    for b in range(l, n, len(gbs)):
+                        self._agg_in[l].copy_(self._agg_stage[j][b])
+                        g.replay()
+                        outs[b] = tuple(t.clone() for t in self._out[l])
                 self._eb[j][l].record(sb)
         for o in outs:
             for t in o:
@@ -839,8 +881,9 @@ class DffClipEngine(FgfaClipEngine):
         second stream beside graph A of the following intervals (FgfaClipEngine._step).
     Detections are identical to `model(images)` frame by frame (tests/test_e2e_gpu.py::test_dff_engine_equals_model)."""
 
-    def __init__(self, model, interval=10, lookahead=8, graphs=True, pipeline=True, lanes=2):
+    def __init__(self, model, interval=10, lookahead=8, graphs=True, pipeline=True, lanes=2, batch_head=True):
         self.m = model
+        self.batch_head = bool(batch_head)   # the box head of the interval's frames as ONE batched graph (else per frame, on lanes)
         self.pipeline = pipeline
         self.lanes = max(1, int(lanes))      # graph-B lanes: two frames' box heads in flight (FgfaClipEngine._step)
         # With several lanes graph B does NOT fork its proposal selection to a side stream: two lanes of forked graphs replayed
@@ -950,8 +993,9 @@ class BaseClipEngine(FgfaClipEngine):
     frame -- replays per frame on two lanes / streams beside it (FgfaClipEngine._step).  Detections are identical to
     `model(image)` frame by frame (tests/test_e2e_gpu.py::test_base_engine_equals_model)."""
 
-    def __init__(self, model, group=20, graphs=True, pipeline=True, lanes=2):
+    def __init__(self, model, group=20, graphs=True, pipeline=True, lanes=2, batch_head=True):
         self.m = model
+        self.batch_head = bool(batch_head)   # the box head of the group's frames as ONE batched graph (else per frame, on lanes)
         self.pipeline = pipeline
         self.group = int(group)
         self.lanes = max(1, int(lanes))

@@ -576,7 +576,7 @@ def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh,
 
 
 def postprocess_batched(logits, deltas, props, B, weights, im_w, im_h, score_thresh, nms_thresh, max_det,
-                        strict_gt=True):
+                        strict_gt=True, nprop=None):
     """B images of R = rows / B proposals each (logits [B*R,NC], deltas [B*R,NC*4], props [B*R,4]) in one launch chain.
     Returns (boxes [B,cap,4], scores [B,cap], labels [B,cap] i64, counts [B] i32 device); image b has the bits of
     postprocess() on its own rows."""
@@ -601,7 +601,10 @@ def postprocess_batched(logits, deltas, props, B, weights, im_w, im_h, score_thr
     assert deltas.shape == (B * R, NC * 4) and props.shape == (B * R, 4)
     wx, wy, ww, wh = weights
     _tok = _pb("postprocess", 0.0, (logits.numel() + deltas.numel()) * 4)
-    rc = lib.mega_postprocess_batched(_ptr(logits), _ptr(deltas), _ptr(props), None, B, R, NC, wx, wy, ww, wh,
+    if nprop is not None:      # device i32 [B]: the valid proposal rows of each image (rows past it are ignored)
+        _gpu(nprop)
+        assert nprop.dtype == torch.int32 and nprop.numel() == B and nprop.is_contiguous()
+    rc = lib.mega_postprocess_batched(_ptr(logits), _ptr(deltas), _ptr(props), _ptr(nprop), B, R, NC, wx, wy, ww, wh,
                                       float(im_w), float(im_h), float(score_thresh), float(nms_thresh), int(strict_gt),
                                       int(max_det), _ptr(ob), _ptr(os_), _ptr(ol), _ptr(oc), None, _ptr(ws), nb,
                                       _stream())

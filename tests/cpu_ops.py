@@ -118,9 +118,11 @@ def postprocess(logits, deltas, props, nprop, weights, im_w, im_h, score_thresh,
     return ob, os_, ol, torch.tensor([n], dtype=torch.int32)
 
 
-def postprocess_batched(logits, deltas, props, B, weights, im_w, im_h, score_thresh, nms_thresh, max_det, strict_gt=True):
+def postprocess_batched(logits, deltas, props, B, weights, im_w, im_h, score_thresh, nms_thresh, max_det, strict_gt=True,
+                        nprop=None):
     R = logits.shape[0] // B
-    res = [postprocess(logits[b * R:(b + 1) * R], deltas[b * R:(b + 1) * R], props[b * R:(b + 1) * R], None, weights,
+    res = [postprocess(logits[b * R:(b + 1) * R], deltas[b * R:(b + 1) * R], props[b * R:(b + 1) * R],
+                       None if nprop is None else nprop[b:b + 1], weights,
                        im_w, im_h, score_thresh, nms_thresh, max_det, strict_gt) for b in range(B)]
     return tuple(torch.stack([r[i] for r in res]) for i in range(3)) + (torch.cat([r[3] for r in res]),)
 

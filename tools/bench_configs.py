@@ -82,7 +82,7 @@ def config1(args, dev):
     from mega.pytorch_amd import fgfa as fgfa_mod
     Lv = 120 + 40 * args.steps
     video = ops.preprocess_frames(clip.contiguous(), mean, True)[torch.arange(Lv, device=dev) % 8].contiguous()
-    eng = fgfa_mod.BaseClipEngine(model, group=20)
+    eng = fgfa_mod.BaseClipEngine(model, group=20, batch_head=args.batch_head != 0)
     eng.run(video, first=0, last=80)
     eb, pos = [], 80
     while pos + 40 <= Lv and sum(eb) < 1.0:
@@ -94,8 +94,9 @@ def config1(args, dev):
         pos += 40
     em = sorted(eb)[len(eb) // 2]
     engine_line = {"fps": round(40 / em, 2), "ms_per_frame": round(1e3 * em / 40, 3), "blocks_of_40_frames_ms": [round(1e3 * b, 2) for b in eb[:8]],
-                   "driver": "fgfa.BaseClipEngine: the backbone on 20 frames per launch chain, the box head's hipGraph per frame on two "
-                             "lanes / streams beside it (identical detections to the per-call path: test_base_engine_equals_model)"}
+                   "driver": "fgfa.BaseClipEngine: the backbone on 20 frames per launch chain (graph A), RPN + box head + post-processing of "
+                             "those 20 frames as one batched launch chain (graph B) on a second stream beside the next group's backbone "
+                             "(identical detections to the per-call path: test_base_engine_equals_model)"}
     cpu = None
     if not args.no_cpu_baseline:
         # BASELINE configs[0] IS the CPU reference run: the port (oracle BaseOracle = the reference's GeneralizedRCNN
@@ -174,7 +175,7 @@ def config5(args, dev):
     frames = torch.cat([frame(i)[None] for i in range(Tc)], dim=0)
     video = frames[torch.arange(L, device=dev) % Tc].contiguous()
     engine = fgfa_mod.FgfaClipEngine(model, lookahead=20, group=args.fgfa_group, pipeline=not args.fgfa_no_pipeline,
-                                     lanes=args.lanes or 1)
+                                     lanes=args.lanes or 1, batch_head=args.batch_head != 0)
     engine.run(video, first=0, last=1 + 3 * 20)            # cold start + the eager / capture / replay warm-up
     pos = [1 + 3 * 20]
     blocks = []
@@ -208,9 +209,9 @@ def config5(args, dev):
                                    "FlowNetS on 21 image pairs (refinement levels as sub-pixel GEMMs), fused warp + aggregation, RPN "
                                    "+ conv5 box head",
                        "driver": "fgfa.FgfaClipEngine: backbone + EmbedNet + the per-frame halves of FlowNetS's first conv for 20 "
-                                 "upcoming frames per launch, the window in rings addressed through a device index table, the "
-                                 "key frame as two hipGraphs on two streams (box head of key frame k beside FlowNetS of key "
-                                 "frame k + 1; identical detections to the per-call path)",
+                                 "upcoming frames per launch, the window in rings addressed through a device index table, two key "
+                                 "frames per FlowNetS pass, two hipGraphs on two streams (the batched box head of a group beside "
+                                 "FlowNetS of the next; identical detections to the per-call path)",
                        "reference_call_convention_fps": round(args.steps / med_call, 2),
                        "graph_replays": engine.replays},
             "roofline": roof, "kernel_families": fam, "blocks_ms": [round(1e3 * b, 2) for b in blocks]}
@@ -307,7 +308,7 @@ def method_line(args, dev, method):
     engine_line = None
     if method == "dff":       # the clip engine (fgfa.DffClipEngine): one FlowNetS pass per key-frame interval, two graphs / streams
         from mega.pytorch_amd import fgfa as fgfa_mod
-        eng = fgfa_mod.DffClipEngine(model, interval=10, lookahead=8, lanes=args.lanes or 2)
+        eng = fgfa_mod.DffClipEngine(model, interval=10, lookahead=8, lanes=args.lanes or 2, batch_head=args.batch_head != 0)
         if os.environ.get("MEGA_NO_FORK_SELECT") == "0":      # (experiments: the forked selection on several lanes)
             eng.fork_select = True
         eng.run(video, first=0, last=80)
@@ -322,8 +323,9 @@ def method_line(args, dev, method):
         em = sorted(eb)[len(eb) // 2]
         engine_line = {"fps": round(40 / em, 2), "ms_per_frame": round(1e3 * em / 40, 3), "blocks_of_40_frames_ms": [round(1e3 * b, 2) for b in eb[:8]],
                        "driver": "fgfa.DffClipEngine: backbone of 8 upcoming key frames per launch, FlowNetS on the 10 pairs of a key-frame "
-                                 "interval in one pass, the box head's hipGraph per frame on a second stream (identical detections to the "
-                                 "per-call path: tests/test_e2e_gpu.py::test_dff_engine_equals_model)", "graph_replays": eng.replays}
+                                 "interval in one pass (graph A), RPN + box head + post-processing of the interval's 10 frames as one "
+                                 "batched launch chain (graph B) on a second stream (identical detections to the per-call path: "
+                                 "tests/test_e2e_gpu.py::test_dff_engine_equals_model)", "graph_replays": eng.replays}
     what = {"rdn": "GeneralizedRCNNRDN R-101-C4 (relation distillation: base stage over 300 key + 37 x 75 reference proposals, "
                    "advanced stage on the distilled 20 %), one model(images) call per frame (SURVEY 8f row 3)",
             "dff": "GeneralizedRCNNDFF R-101-C4: the backbone on every 10th frame, FlowNetS (1 pair) + warp x scale on the others, "
@@ -347,6 +349,7 @@ def main():
     ap.add_argument("--fgfa-group", type=int, default=2, help="config 5: key frames per FlowNetS pass (FgfaClipEngine group)")
     ap.add_argument("--fgfa-no-pipeline", action="store_true", help="config 5: both graphs of a key frame on one stream")
     ap.add_argument("--lanes", type=int, default=0, help="config 5 / --method dff: box-head graph lanes (0: the engine's default)")
+    ap.add_argument("--batch-head", type=int, default=-1, help="clip engines: the box head of a group as one batched graph (1) or per frame (0); -1: the engine's default")
     ap.add_argument("--skip-call-convention", action="store_true", help="config 5: do not time the reference call convention")
     ap.add_argument("--f32-conv", default="exact", choices=["exact", "bf16x3"],
                     help="config 2: exact-f32 MFMA, or the split-precision mode (cfg.F32_CONV) -- fp32 arithmetic from three bf16 "
