@@ -123,17 +123,20 @@ def frame_feed(cfg, frames, idx):
 def compute_on_dataset(model, index, img_dir, device, videos=None, steps_per_batch=10, seed=0, timer=None,
                        source_kwargs=None, engine_kwargs=None):
     """inference.py:17-47: -> {dataset index: BoxList on the host}, for every MODEL.VID.METHOD of the reference:
-      mega         ClipEngine on the video's FrameSource.  The engine runs with reuse_records=True unless engine_kwargs says
-                   otherwise: every frame of a video goes through the frame stage once and serves both its local-window and
-                   its global-pool role (bit-identical detections on the GPU, ~half the backbone work);
+      mega / rdn   ClipEngine on the video's FrameSource (RDN is the MEGA detector without memory / global pools: rdn.py).  The
+                   engine runs with reuse_records=True unless engine_kwargs says otherwise: every frame of a video goes
+                   through the frame stage once and serves both its local-window and its global-pool role (bit-identical
+                   detections on the GPU, ~half the backbone work); engine_kwargs={"per_frame": True}: RDN frame by frame;
       fgfa / dff / base   fgfa.FgfaClipEngine / DffClipEngine / BaseClipEngine on the resident video (engine_kwargs: lookahead,
                    graphs, pipeline, group / interval, lanes); engine_kwargs={"per_frame": True} runs the reference's call
                    convention instead;
-      rdn          the detector frame by frame on the reference's own test feed (frame_feed)."""
+      (per_frame)  the detector frame by frame on the reference's own test feed (frame_feed)."""
     model.eval()
     results = {}
     videos = index.videos if videos is None else videos
     method = model.cfg.MODEL.VID.METHOD
+    if method == "rdn" and not (engine_kwargs or {}).get("per_frame"):
+        method = "mega"
     if method != "mega":
         ek = dict(engine_kwargs or {})
         per_frame = bool(ek.pop("per_frame", False)) or method not in ("fgfa", "dff", "base")
@@ -168,8 +171,9 @@ def compute_on_dataset(model, index, img_dir, device, videos=None, steps_per_bat
                 results[v["start"] + i] = det.to("cpu")
             src.close()
         return results
-    ek = dict(reuse_records=True)
+    ek = dict(reuse_records=model.cfg.MODEL.VID.METHOD == "mega")      # (RDN: a frame has one role, the local window)
     ek.update(engine_kwargs or {})
+    ek.pop("per_frame", None)
     eng = _engine.ClipEngine(model, steps_per_batch=steps_per_batch, **ek)
     gsize = model.cfg.MODEL.VID.MEGA.GLOBAL.SIZE
     for vi, v in enumerate(videos):

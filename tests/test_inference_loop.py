@@ -190,7 +190,7 @@ def test_video_partition_equals_reference_sampler():
             assert len(covered) == len(set(covered))
 
 
-@pytest.mark.parametrize("method", ["fgfa", "base", "dff", "rdn"])
+@pytest.mark.parametrize("method", ["fgfa", "base", "dff", "rdn", "rdn_engine"])
 def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_path, method):
     """engine/inference.py:17-47 for MODEL.VID.METHOD fgfa / base / dff: compute_on_dataset feeds every video through
     feed.FrameSource -> resident preprocessed frames -> FgfaClipEngine (fgfa) or the detector frame by frame on the
@@ -202,6 +202,8 @@ def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_pat
     import mega.pytorch_amd.fgfa  # noqa: F401
     import mega.pytorch_amd.rdn  # noqa: F401
     img_dir, idx, clips = _make_dataset(str(tmp_path))
+    via_engine = method == "rdn_engine"            # RDN through ClipEngine (the default) instead of frame by frame
+    method = "rdn" if via_engine else method
     cfg = config.get_cfg("R-50", method)
     cfg.MODEL.DEVICE = "cpu"
     cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = MIN_S, MAX_S
@@ -222,9 +224,12 @@ def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_pat
         m = modeling.build_detection_model(cfg)
         m.load_state_dict(sd)
         return m
-    ek = {"graphs": False, "lookahead": 3} if method in ("fgfa", "dff") else ({"graphs": False, "group": 3} if method == "base" else None)
+    ek = {"graphs": False, "lookahead": 3} if method in ("fgfa", "dff") else ({"graphs": False, "group": 3} if method == "base" else
+                                                                                {"per_frame": True})
+    if via_engine:
+        ek = {"overlap": False, "graphs": False}
     preds = inference.inference(cfg, build(), img_dir, idx, output_folder=str(tmp_path / "out"), engine_kwargs=ek,
-                                source_kwargs={"workers": 2})
+                                source_kwargs={"workers": 2}, **({"steps_per_batch": 3} if via_engine else {}))
     assert len(preds) == 12 and all(p.size == (MAX_S, MIN_S) for p in preds)
     # by hand: the same detector in the reference's call convention on the pre-resized, preprocessed clip
     model = build()
@@ -237,7 +242,7 @@ def test_inference_loop_drives_the_other_meta_architectures(monkeypatch, tmp_pat
                 out = model(inference.frame_feed(cfg, frames, i))
             ref = out[0] if isinstance(out, (list, tuple)) else out
             p = preds[start + i]
-            if method in ("fgfa", "dff", "base"):      # (the engines batch the backbone / FlowNetS: MKL is not batch-invariant on
+            if method in ("fgfa", "dff", "base") or via_engine:      # (the engines batch the backbone / FlowNetS: MKL is not batch-invariant on
                 assert abs(len(p) - len(ref)) <= 2, (name, i, len(p), len(ref))      # the CPU; the GPU test is bit-exact)
             else:
                 assert torch.equal(p.bbox, ref.bbox) and torch.equal(p.get_field("scores"), ref.get_field("scores"))

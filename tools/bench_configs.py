@@ -306,6 +306,24 @@ def method_line(args, dev, method):
     med, blocks = timed(step, args.steps, min_seconds=1.0, max_blocks=25)
     fam, _ = families(ops, lambda: [step(0) for _ in range(10)], 10)
     engine_line = None
+    if method == "rdn":       # ClipEngine drives this detector too (rdn.py: MEGA's frame stage, no memory / global pools)
+        from mega.pytorch_amd import engine as eng_mod
+        runner = eng_mod.ClipEngine(model, steps_per_batch=20)
+        u8 = clip[torch.arange(L, device=dev) % Tc].contiguous()
+        runner.run(u8, L, first=0, last=81)
+        eb, pos = [], 81
+        while pos + 40 <= L and sum(eb) < 1.5:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            runner.run(u8, L, first=pos, last=pos + 40)
+            torch.cuda.synchronize()
+            eb.append(time.perf_counter() - t0)
+            pos += 40
+        em = sorted(eb)[len(eb) // 2]
+        engine_line = {"fps": round(40 / em, 2), "ms_per_frame": round(1e3 * em / 40, 3), "blocks_of_40_frames_ms": [round(1e3 * b, 2) for b in eb[:8]],
+                       "driver": "engine.ClipEngine(steps_per_batch=20): the batched, graph-captured frame stage of the MEGA path on the "
+                                 "new local frame of every step + the relation stages per key frame (parity: "
+                                 "tests/test_e2e_gpu.py::test_rdn_f32_end_to_end_vs_reference_fixture)"}
     if method == "dff":       # the clip engine (fgfa.DffClipEngine): one FlowNetS pass per key-frame interval, two graphs / streams
         from mega.pytorch_amd import fgfa as fgfa_mod
         eng = fgfa_mod.DffClipEngine(model, interval=10, lookahead=8, lanes=args.lanes or 2, batch_head=args.batch_head != 0)
