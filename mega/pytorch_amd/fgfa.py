@@ -554,9 +554,11 @@ class FgfaClipEngine(object):
         last frame at the end), i.e. a row of a device index table (`order[b]` = [slot of the key frame, slot of window
         position t ...]); FlowNetS takes a key frame's pairs in slot order over the whole ring and the warp kernel visits the
         window in window order through the table (mega_fgfa_warp_aggregate_ring) -- the bits of the contiguous call;
-      * `group` consecutive key frames share ONE FlowNetS pass over exactly their group x T pairs (its coarse levels have
-        840-12 768 GEMM rows at 21 pairs and leave half the chip idle: 1.05 ms per key frame at 21 pairs, 0.84 at 42, 0.77
-        at 84); the flow fields come out in window order per key frame (mega_fgfa_warp_aggregate_ring_pos);
+      * `group` consecutive key frames (default 10) share ONE FlowNetS pass over exactly their group x T pairs (its coarse
+        levels have 840-12 768 GEMM rows at 21 pairs and leave half the chip idle: 1.05 ms per key frame at 21 pairs, 0.84 at
+        42, 0.77 at 84) and ONE batched box-head pass; the flow fields come out in window order per key frame
+        (mega_fgfa_warp_aggregate_ring_pos).  Same box, batched head: group 1 / 2 / 4 / 5 / 10 / 20 = 518 / 595 / 630 / 638 /
+        665 / 669 FPS (with the box head replayed per key frame the optimum was 2: profiles/r06_c5_group_ab.txt);
       * the key frame is TWO hipGraphs on two streams: A = FlowNetS + warp of a group, B = RPN selection, res5 + ROIAlign +
         fc6 / fc7, predictor, post-processing (fixed 300 proposal rows per frame, the device-side proposal counts go to the
         post-processor) of the group's key frames as ONE batched launch chain (batch_head; or one replay per key frame);
@@ -569,7 +571,7 @@ class FgfaClipEngine(object):
     fork_select = True   # graph B forks the one-block proposal selection to a side stream beside res5
     batch_head = False   # graph B on all maps of a group in ONE batched replay (_body_bb) instead of one replay per map
 
-    def __init__(self, model, lookahead=20, graphs=True, pipeline=True, group=2, lanes=1, batch_head=True):
+    def __init__(self, model, lookahead=20, graphs=True, pipeline=True, group=10, lanes=1, batch_head=True):
         self.m = model
         self.batch_head = bool(batch_head)
         self.lanes = max(1, int(lanes))

@@ -209,7 +209,7 @@ def config5(args, dev):
                                    "FlowNetS on 21 image pairs (refinement levels as sub-pixel GEMMs), fused warp + aggregation, RPN "
                                    "+ conv5 box head",
                        "driver": "fgfa.FgfaClipEngine: backbone + EmbedNet + the per-frame halves of FlowNetS's first conv for 20 "
-                                 "upcoming frames per launch, the window in rings addressed through a device index table, two key "
+                                 "upcoming frames per launch, the window in rings addressed through a device index table, ten key "
                                  "frames per FlowNetS pass, two hipGraphs on two streams (the batched box head of a group beside "
                                  "FlowNetS of the next; identical detections to the per-call path)",
                        "reference_call_convention_fps": round(args.steps / med_call, 2),
@@ -364,7 +364,7 @@ def main():
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fgfa-group", type=int, default=2, help="config 5: key frames per FlowNetS pass (FgfaClipEngine group)")
+    ap.add_argument("--fgfa-group", type=int, default=10, help="config 5: key frames per FlowNetS pass (FgfaClipEngine group)")
     ap.add_argument("--fgfa-no-pipeline", action="store_true", help="config 5: both graphs of a key frame on one stream")
     ap.add_argument("--lanes", type=int, default=0, help="config 5 / --method dff: box-head graph lanes (0: the engine's default)")
     ap.add_argument("--batch-head", type=int, default=-1, help="clip engines: the box head of a group as one batched graph (1) or per frame (0); -1: the engine's default")
