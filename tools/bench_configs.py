@@ -174,7 +174,7 @@ def config5(args, dev):
     L = 64 + 40 * args.steps
     frames = torch.cat([frame(i)[None] for i in range(Tc)], dim=0)
     video = frames[torch.arange(L, device=dev) % Tc].contiguous()
-    engine = fgfa_mod.FgfaClipEngine(model, lookahead=20, group=args.fgfa_group, pipeline=not args.fgfa_no_pipeline,
+    engine = fgfa_mod.FgfaClipEngine(model, lookahead=args.fgfa_lookahead, group=args.fgfa_group, pipeline=not args.fgfa_no_pipeline,
                                      lanes=args.lanes or 1, batch_head=args.batch_head != 0)
     engine.run(video, first=0, last=1 + 3 * 20)            # cold start + the eager / capture / replay warm-up
     pos = [1 + 3 * 20]
@@ -366,6 +366,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fgfa-group", type=int, default=10, help="config 5: key frames per FlowNetS pass (FgfaClipEngine group)")
     ap.add_argument("--fgfa-no-pipeline", action="store_true", help="config 5: both graphs of a key frame on one stream")
+    ap.add_argument("--fgfa-lookahead", type=int, default=20, help="config 5: frames per backbone + EmbedNet batch")
     ap.add_argument("--lanes", type=int, default=0, help="config 5 / --method dff: box-head graph lanes (0: the engine's default)")
     ap.add_argument("--batch-head", type=int, default=-1, help="clip engines: the box head of a group as one batched graph (1) or per frame (0); -1: the engine's default")
     ap.add_argument("--skip-call-convention", action="store_true", help="config 5: do not time the reference call convention")
