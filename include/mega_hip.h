@@ -450,6 +450,11 @@ int mega_flow_conv1_combine(const float* ab, const float* bias, const int* order
  * the exact pairs of several key frames (mega_flow_conv1_combine with nwin > 0) hands to the warp. */
 int mega_fgfa_warp_aggregate_ring_pos(const void* feats, const float* flow, void* out, float* weights_out, int T, int H,
                                       int W, int Cf, int Ce, const int* order, int key_pos, int dtype, void* stream);
+/* ... for G key frames in one launch: order [G][1 + T], flow [G][T][2][H][W], out [G][H][W][Cf], weights_out [G][T][H][W] or
+ * NULL; the feature ring `feats` is shared.  Same bits per key frame as G separate calls. */
+int mega_fgfa_warp_aggregate_ring_pos_batched(const void* feats, const float* flow, void* out, float* weights_out, int T,
+                                              int H, int W, int Cf, int Ce, const int* order, int key_pos, int G, int dtype,
+                                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,7 @@ SIGNATURES = {
     "mega_flow_pred_finish": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p] + [c_int] * 4 + [c_void_p]),
     "mega_flow_conv1_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),
     "mega_fgfa_warp_aggregate_ring_pos": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_int, c_int, c_void_p]),
+    "mega_fgfa_warp_aggregate_ring_pos_batched": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_int, c_int, c_int, c_void_p]),
     "mega_last_error_string": (ctypes.c_char_p, []),
 }
 

@@ -136,6 +136,15 @@ __global__ __launch_bounds__(256) void fgfa2_kernel(const T* __restrict__ feats,
   // frame at window position t.  Frames are visited in window order whatever their slots, so the sums have the bits of
   // the contiguous (deque-ordered) call; flow is indexed by slot like feats (flow_key_pos < 0) or by WINDOW POSITION
   // (flow_key_pos >= 0 = the key frame's position: flow [NT][2][H][W] holds exactly the window's pairs, in window order).
+  // blockIdx.y = key frame of a batch (mega_fgfa_warp_aggregate_ring_pos with G > 1): its own index-table row, its own T flow
+  // fields (window order), its own output map; the feature ring is shared
+  if (gridDim.y > 1) {
+    const size_t gb = blockIdx.y;
+    order += gb * (size_t)(NT + 1);
+    flow += gb * (size_t)NT * 2 * H * W;
+    out += gb * (size_t)H * W * Cf;
+    if (weights_out) weights_out += gb * (size_t)NT * H * W;
+  }
   auto slot_of = [&](int t) { return order ? order[1 + t] : t; };
   auto flow_of = [&](int t, int slot) { return flow_key_pos >= 0 ? t : slot; };
   const int key_flow = (order && flow_key_pos >= 0) ? flow_key_pos : (order ? order[0] : key);
@@ -421,7 +430,7 @@ extern "C" int mega_dff_warp_scale(const void* feats, const float* flow, const v
 }
 
 static int fgfa_impl(const void* feats, const float* flow, void* out, float* weights_out, int T, int H, int W, int Cf,
-                     int Ce, int key, const int* order, int dtype, void* stream, int flow_key_pos = -1);
+                     int Ce, int key, const int* order, int dtype, void* stream, int flow_key_pos = -1, int G = 1);
 
 extern "C" int mega_fgfa_warp_aggregate(const void* feats, const float* flow, void* out, float* weights_out, int T,
                                         int H, int W, int Cf, int Ce, int key, int dtype, void* stream) {
@@ -446,8 +455,18 @@ extern "C" int mega_fgfa_warp_aggregate_ring_pos(const void* feats, const float*
   return fgfa_impl(feats, flow, out, weights_out, T, H, W, Cf, Ce, 0, order, dtype, stream, key_pos);
 }
 
+// ... for G key frames in ONE launch (the engine's group): order [G][1 + T], flow [G][T][2][H][W], out [G][H][W][Cf]
+// (weights_out [G][T][H][W] or NULL); the feature ring is shared.  One key frame is 2394 blocks on 256 CUs x 8 resident
+// blocks = 1.17 rounds; G of them in one grid run without the per-launch tail.  Same bits per key frame.
+extern "C" int mega_fgfa_warp_aggregate_ring_pos_batched(const void* feats, const float* flow, void* out, float* weights_out,
+                                                         int T, int H, int W, int Cf, int Ce, const int* order, int key_pos,
+                                                         int G, int dtype, void* stream) {
+  if (!order || key_pos < 0 || key_pos >= T || G < 1 || G > 65535) return MEGA_ERR_ARG;
+  return fgfa_impl(feats, flow, out, weights_out, T, H, W, Cf, Ce, 0, order, dtype, stream, key_pos, G);
+}
+
 static int fgfa_impl(const void* feats, const float* flow, void* out, float* weights_out, int T, int H, int W, int Cf,
-                     int Ce, int key, const int* order, int dtype, void* stream, int flow_key_pos) {
+                     int Ce, int key, const int* order, int dtype, void* stream, int flow_key_pos, int G) {
   mega_clear_error();
   if (!feats || !flow || !out || T <= 0 || T > 64 || H <= 1 || W <= 1 || Cf <= 0 || Ce <= 0 || key < 0 || key >= T)
     return MEGA_ERR_ARG;
@@ -459,16 +478,16 @@ static int fgfa_impl(const void* feats, const float* flow, void* out, float* wei
   if (!legacy && fvec <= 256 && 256 % fvec == 0 && T < 63 && (size_t)H * W * (Cf + Ce) < 0x7FFFFFFFull) {
     const size_t smem2 = ((size_t)Ce + (size_t)(256 / fvec - 1) * Cf) * sizeof(float);
     if (dtype == MEGA_BF16)
-      hipLaunchKernelGGL((fgfa2_kernel<bf16_t>), dim3(H * W), dim3(256), smem2, st, (const bf16_t*)feats, flow,
+      hipLaunchKernelGGL((fgfa2_kernel<bf16_t>), dim3(H * W, G), dim3(256), smem2, st, (const bf16_t*)feats, flow,
                          (bf16_t*)out, weights_out, T, H, W, Cf, Ce, key, order, flow_key_pos);
     else if (dtype == MEGA_F32)
-      hipLaunchKernelGGL((fgfa2_kernel<float>), dim3(H * W), dim3(256), smem2, st, (const float*)feats, flow,
+      hipLaunchKernelGGL((fgfa2_kernel<float>), dim3(H * W, G), dim3(256), smem2, st, (const float*)feats, flow,
                          (float*)out, weights_out, T, H, W, Cf, Ce, key, order, flow_key_pos);
     else
       return MEGA_ERR_ARG;
     return mega_check_launch();
   }
-  if (order) return MEGA_ERR_ARG;          // the ring form exists for the two-pass kernel only
+  if (order || G != 1) return MEGA_ERR_ARG;          // the ring / batched forms exist for the two-pass kernel only
   const size_t smem = ((size_t)Ce + (size_t)T * Cf) * sizeof(float);
   if (smem > 150 * 1024) return MEGA_ERR_ARG;
   if (dtype == MEGA_BF16) {

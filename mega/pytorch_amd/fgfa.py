@@ -627,6 +627,8 @@ class FgfaClipEngine(object):
         if self.parts:                  # key frame b = ring slot order[b][0]; ONE trunk pass over exactly the G x T pairs
             flow = m.flownet.run_parts_multi(self.ab_ring, m.dtype, self.order)
             flows = [flow[b * T:(b + 1) * T] for b in range(G)]
+            if not self.keep_intermediates:     # the group's warps in ONE launch (a key frame alone is 1.17 rounds of blocks)
+                return ops.fgfa_warp_aggregate_group(self.feat_ring, flow, nfeat, self.order, self.key)
             aggs = [ops.fgfa_warp_aggregate(self.feat_ring, flows[b], nfeat, 0, order=self.order[b], flow_pos=self.key)
                     for b in range(G)]
         else:                           # (exact-f32 mode: the generic pair path, a key frame's pairs in slot order over the ring)

@@ -1206,6 +1206,25 @@ def fgfa_warp_aggregate(feats, flow, Cf, key, want_weights=False, order=None, fl
     return (out, wts) if want_weights else out
 
 
+def fgfa_warp_aggregate_group(feats, flow, Cf, orders, key_pos):
+    """fgfa_warp_aggregate(..., order=orders[g], flow_pos=key_pos) for the G key frames of a group in ONE launch: feats ring
+    [S,H,W,Cf+Ce], flow f32 [G*T,2,H,W] (window order per key frame), orders i32 [G,1+T] -> [G,H,W,Cf]; same bits per key frame."""
+    _gpu(feats, flow, orders)
+    lib = _lib.load()
+    S, H, W, C = feats.shape
+    G, T1 = orders.shape
+    T = T1 - 1
+    assert feats.is_contiguous() and flow.is_contiguous() and flow.dtype == torch.float32 and tuple(flow.shape) == (G * T, 2, H, W)
+    assert orders.dtype == torch.int32 and orders.is_contiguous()
+    out = torch.empty((G, H, W, Cf), dtype=feats.dtype, device=feats.device)
+    _tok = _pb("fgfa_warp", 0.0, 4.0 * G * T * H * W * C * feats.element_size())
+    rc = lib.mega_fgfa_warp_aggregate_ring_pos_batched(_ptr(feats), _ptr(flow), _ptr(out), None, T, H, W, Cf, C - Cf, _ptr(orders),
+                                                       int(key_pos), G, _dt(feats), _stream())
+    _pe(_tok)
+    _lib.check(rc, "mega_fgfa_warp_aggregate_ring_pos_batched")
+    return out
+
+
 def fgfa_pair_taps(refs, cur=None, order=None, dtype=torch.bfloat16):
     """FlowNetS's first-conv operand from the f32 NCHW frames in one kernel (mega_fgfa_pair_taps): refs [T,3,H,W] f32, the
     key frame `cur` [1,3,H,W] (one for all pairs) or [T,3,H,W] (one per pair), or cur=None with `order` (i32 on the device):

@@ -398,6 +398,11 @@ def flow_conv1_combine(ab, bias, dtype, key=None, order=None, T=None, out=None, 
     return y
 
 
+def fgfa_warp_aggregate_group(feats, flow, Cf, orders, key_pos):
+    G, T = orders.shape[0], orders.shape[1] - 1
+    return torch.stack([fgfa_warp_aggregate(feats, flow[g * T:(g + 1) * T], Cf, 0, order=orders[g], flow_pos=key_pos) for g in range(G)], 0)
+
+
 def flow_pred_finish(z, bias, scale, out_dtype):
     N, H, W, _ = z.shape
     zp = F.pad(z, (0, 0, 1, 1, 1, 1))
@@ -408,4 +413,4 @@ def flow_pred_finish(z, bias, scale, out_dtype):
     return (acc * scale + bias.view(1, 1, 1, 2)).to(out_dtype)
 
 
-ALL += ["deconv4x4s2_into", "flow_level_assemble", "flow_pred_finish", "flow_conv1_combine"]
+ALL += ["deconv4x4s2_into", "flow_level_assemble", "flow_pred_finish", "flow_conv1_combine", "fgfa_warp_aggregate_group"]

@@ -37,6 +37,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.mega_flow_pred_finish(None, 64, None, 1.0, None, 1, 4, 4, 1, None) == 1
     assert lib.mega_flow_conv1_combine(None, None, None, 0, None, 1, 16, 0, 1, None) == 1
     assert lib.mega_fgfa_warp_aggregate_ring_pos(None, None, None, None, 3, 4, 4, 8, 8, None, 1, 1, None) == 1
+    assert lib.mega_fgfa_warp_aggregate_ring_pos_batched(None, None, None, None, 3, 4, 4, 8, 8, None, 1, 2, 1, None) == 1
     assert lib.mega_conv2d_nhwc_ks_workspace_bytes(10, 8, 64 * 4, 1, 1) == 0           # one range: no workspace
     assert lib.mega_conv2d_nhwc_ks_workspace_bytes(10, 8, 64 * 4, 1, 3) == 2 * 10 * 8 * 4   # 4 K-tiles in 3 ranges of 2 -> 2 ranges
     assert lib.mega_conv2d_nhwc_ks_workspace_bytes(10, 8, 64 * 4, 1, 100) == 4 * 10 * 8 * 4   # never more ranges than K-tiles
