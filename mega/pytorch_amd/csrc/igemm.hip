@@ -786,6 +786,13 @@ extern "C" int mega_conv2d_nhwc_subpixel(const void* in, const void* w4, const f
   const long b128 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 128) * p.ksplit, b12864 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 64) * p.ksplit;
   // (the sub-pixel read-out is the tiles' vector path: whole tiles of columns only)
   if (p.Cout % 64 != 0) return MEGA_ERR_ARG;
+  // large launches on the LDS-DMA tiles (igemm8.hip, ABL = 6 = the same read-out there): choose_tile's rule -- Cout a multiple of
+  // 256 and at least half a round of tiles; same K order, same MFMA: the same bits as the register-staged tiles
+  if (dtype != MEGA_F32 && p.ksplit == 1 && p.Cout % 256 == 0 && !getenv("MEGA_IGEMM_TILE") && mega_igemm8_supports(p)) {
+    const long t256 = (long)cdiv(p.M, 256) * (p.Cout / 256), t192 = (long)cdiv(p.M, 192) * (p.Cout / 256);
+    const long c256 = cdiv((int)t256, 256) * 256L * 8, c192 = cdiv((int)t192, 256) * 192L * 9;
+    if (t256 >= 128 || t192 >= 128) return mega_igemm8_launch(p, c192 < c256 ? 192 : 256, 0, dtype, st);
+  }
   const int tile = (b128 >= 384 && p.Cout % 128 == 0) ? 0 : (b12864 >= 384 ? 1 : 2);     // (choose_tile's rule for the register-staged tiles)
   auto go = [&](auto tag) -> int {
     typedef decltype(tag) T;

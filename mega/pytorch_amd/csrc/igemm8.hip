@@ -439,17 +439,31 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
   //      residual / output planes; they have no other epilogue (launch8 refuses what does not qualify), except the raw
   //      partial sums of a split-K launch.
   const int oplanes = SP && p.split_out ? 2 : 1;       // planes of Cout columns behind each other in an output row
+  // ABL == 6 (a product instantiation, not an ablation): the sub-pixel read-out of mega_conv2d_nhwc_subpixel -- GEMM row
+  // (t, mh, mw), column (a, b, co) of a transposed conv's four phases goes to pixel (2 mh + a - crop, 2 mw + b - crop), channel
+  // ps_coff + co of an NHWC tensor [N][ps_H][ps_W][ldo] (igemm_params.h); the launcher admits only what this path serves
+  constexpr bool PS = ABL == 6;
+  const size_t out_elems = PS ? (size_t)p.N * p.ps_H * p.ps_W * p.ldo : (size_t)(p.M - 1) * p.ldo + (size_t)oplanes * p.Cout;
   const bool fast = vec_ok && p.ksplit == 1 && (SP ? p.Cout % OVE == 0 : n0 + BN <= p.Cout) && (res == nullptr || sizeof(OT) == 2 || SP) &&
-                    ((size_t)(p.M - 1) * p.ldo + (size_t)oplanes * p.Cout) * sizeof(OT) < 0x7FF00000ull &&
+                    out_elems * sizeof(OT) < 0x7FF00000ull &&
                     (res == nullptr || ((size_t)(p.M - 1) * p.ldr + (size_t)(SP ? 2 : 1) * p.Cout) * 2 < 0x7FF00000ull);
   if (fast) {
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        p.out, 0, (int)(((size_t)(p.M - 1) * p.ldo + (size_t)oplanes * p.Cout) * sizeof(OT)), 0x00020000);
+        p.out, 0, (int)(out_elems * sizeof(OT)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.res ? p.res : p.out), 0, res ? (int)(((size_t)(p.M - 1) * p.ldr + (size_t)(SP ? 2 : 1) * p.Cout) * 2) : 0, 0x00020000);
     constexpr int RSTEP = NT8 / VPR;                   // slab rows between a thread's consecutive vectors
     const int row0 = tid / VPR, ncol = n0 + (tid % VPR) * OVE;
     const unsigned cmask = SP && ncol >= p.Cout ? OOB : 0u;      // (SP) this thread's columns do not exist: loads give 0, stores are dropped
+    const int ps_q = PS ? ncol / p.ps_C : 0;                     // (PS) this thread's phase (a, b) and channel inside it
+    const int ps_col = PS ? p.ps_coff + (ncol - ps_q * p.ps_C) : 0;
+    auto ps_off = [&](int m) -> unsigned {
+      const int t = fast_div(m, p.mg_howo, p.sh_howo), rem = m - t * (p.Ho * p.Wo);
+      const int mh = fast_div(rem, p.mg_wo, p.sh_wo), mw = rem - mh * p.Wo;
+      const int y = 2 * mh + (ps_q >> 1) - p.ps_crop, x = 2 * mw + (ps_q & 1) - p.ps_crop;
+      const bool ok = m < p.M && (unsigned)y < (unsigned)p.ps_H && (unsigned)x < (unsigned)p.ps_W;
+      return ok ? (unsigned)(((t * p.ps_H + y) * p.ps_W + x) * p.ldo + ps_col) * (unsigned)sizeof(OT) : OOB;
+    };
     // (row0 < RSTEP and RSTEP divides 32: the slab row row0 + it * RSTEP splits into a per-thread part and a
     // compile-time part -- one add per vector instead of the shift / mask / multiply chain)
     auto slab_m = [&](int i, int f, int it) {
@@ -570,7 +584,7 @@ __global__ __launch_bounds__(NT8, 2) void igemm8_kernel(ConvParams p) {
                 }
               }
             }
-            const unsigned ooff = ((unsigned)(slab_m(i, f, it) * p.ldo + ncol) * (unsigned)sizeof(OT)) | cmask;
+            const unsigned ooff = PS ? ps_off(slab_m(i, f, it)) : (((unsigned)(slab_m(i, f, it) * p.ldo + ncol) * (unsigned)sizeof(OT)) | cmask);
             u32x4_t o;                                 // packed explicitly (no type-punned stores into o)
             if constexpr (SPLIT_OUT) {                 // hi = bf16(x), lo = bf16(x - hi) of x = act(v), both planes
               u32x4_t ol;
@@ -787,6 +801,14 @@ int mega_igemm8_launch(const ConvParams& p, int bm, int out_f32, int half_dtype,
     if (bm == 192 && streamf) return out_f32 ? launch8<float, 1, 1, 0, 1, f16_t>(p, st) : launch8<f16_t, 1, 1, 0, 1, f16_t>(p, st);
     if (bm == 256) return out_f32 ? launch8<float, 2, 0, 0, 1, f16_t>(p, st) : launch8<f16_t, 2, 0, 0, 1, f16_t>(p, st);
     if (bm == 192) return out_f32 ? launch8<float, 1, 0, 0, 1, f16_t>(p, st) : launch8<f16_t, 1, 0, 0, 1, f16_t>(p, st);
+    return MEGA_ERR_ARG;
+  }
+  if (p.ps) {                          // sub-pixel read-out (mega_conv2d_nhwc_subpixel): 16-bit in / out, no residual, no split-K
+    if (p.sp || out_f32 || p.res || p.ksplit != 1 || p.Cout % 256 != 0 || p.ps_C % 8 != 0 || p.ldo % 8 != 0 || p.ps_coff % 8 != 0 ||
+        (size_t)p.N * p.ps_H * p.ps_W * p.ldo * 2 >= 0x7FF00000ull)
+      return MEGA_ERR_ARG;
+    if (half_dtype == MEGA_F16) return bm == 192 ? launch8<f16_t, 1, 0, 6, 0, f16_t>(p, st) : launch8<f16_t, 2, 0, 6, 0, f16_t>(p, st);
+    if (half_dtype == MEGA_BF16) return bm == 192 ? launch8<bf16_t, 1, 0, 6>(p, st) : launch8<bf16_t, 2, 0, 6>(p, st);
     return MEGA_ERR_ARG;
   }
   if (half_dtype == MEGA_F16) {        // IEEE half operands (same tiles, same launch classes)

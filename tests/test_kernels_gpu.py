@@ -1235,6 +1235,8 @@ DECONV_CASES = [
     (2, 7, 9, 770, 128, 13, 17, 256, 3),         # odd x odd target, split-K
     (1, 4, 6, 386, 64, 10, 14, 128, 1),          # target = the full (2H+2) x (2W+2) map: crop_like keeps everything
     (21, 5, 8, 1024, 512, 10, 16, 512, 4),       # the 21-pair window, split-K
+    (21, 38, 63, 386, 64, 75, 125, 128, 1),      # deconv2 of a 21-pair key frame: 205 igemm8 tiles -> the LDS-DMA kernel's read-out
+    (40, 19, 32, 770, 128, 38, 63, 256, 1),      # igemm8, 192-row tiles, two column tiles
 ]
 
 
@@ -1274,6 +1276,16 @@ def test_deconv_subpixel_and_level_assemble_vs_torch(dev, case, dtype):
     for name, a, r in (("deconv", got[..., Cs:Cs + C], dec), ("flow up-sampling", got[..., Cs + C:Cs + C + 2], up)):
         err = (a - r).abs().max().item()
         assert err <= eps * r.abs().max().item(), "%s: max |d| %.3g against scale %.3g" % (name, err, r.abs().max().item())
+    if dtype != torch.float32 and ks == 1 and (4 * C) % 256 == 0 and N * (H + 1) * (W + 1) >= 128 * 192:
+        # this launch ran on igemm8 (LDS-DMA tiles, ABL = 6 read-out): the register-staged tiles give the same bits
+        import os
+        os.environ["MEGA_IGEMM_TILE"] = "128x128"
+        try:
+            out2 = torch.full((N, H2, W2, ldo), float("nan"), dtype=dtype, device=dev)
+            ops.deconv4x4s2_into(xp.to(dev), w4.to(dev), b.repeat(4).to(dev), out2, Cs, relu=2, ksplit=1)
+        finally:
+            del os.environ["MEGA_IGEMM_TILE"]
+        assert torch.equal(out2[..., Cs:Cs + C].view(torch.int16), out[..., Cs:Cs + C].view(torch.int16)), "igemm8 vs igemm tiles"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
