@@ -826,8 +826,9 @@ class FgfaClipEngine(object):
 
     @torch.no_grad()
     def run(self, frames, first=0, last=None, sync_every=16):
-        """frames: preprocessed f32 [L,3,H,W] on the device (the whole video, or a FrameSource-like object with
-        __getitem__ over index tensors).  Key frames first..last-1 (first = 0 starts a new video).  -> list[BoxList]."""
+        """frames: preprocessed f32 [L,3,H,W] on the device (the whole video: inference.resident_video builds it from a
+        feed.FrameSource).  Key frames first..last-1 (first = 0 starts a new video; first > 0 continues the previous call's video
+        on the ring state).  -> list[BoxList]."""
         L = frames.shape[0]
         last = L if last is None else last
         H, W = frames.shape[-2:]
