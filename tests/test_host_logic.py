@@ -226,7 +226,7 @@ def test_subpixel_deconv_packing_equals_conv_transpose(shape):
     assert (out[..., Cs:Cs + C] - full).abs().max().item() < 1e-4 and (out[..., Cs + C:Cs + C + 2] - up).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("group", [1, 2, 3])
+@pytest.mark.parametrize("group", [1, 3])
 def test_fgfa_clip_engine_equals_model_on_cpu_twins(monkeypatch, group):
     """fgfa.FgfaClipEngine's host logic -- features of upcoming frames in look-ahead batches, the window in rings with a
     rotating slot table, the cold-start fill, the end-of-video clamp, restart on a second video -- against
