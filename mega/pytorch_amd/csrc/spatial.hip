@@ -368,12 +368,37 @@ __device__ __forceinline__ void roi_patch_accumulate(const T* __restrict__ base,
   }
 }
 
-template <typename T, int NSLICE>
+// PLANES (T = float, round 6): the pooled values leave as split-precision planes [hi | lo] of PT (bf16 / f16), as in
+// roi_align_nhwc_vec_kernel<float, ., true>: the split-precision mode's ROIAlign in the separable form (the exact-term-order
+// kernel it replaces there was 3.5x the bf16 kernel's time; the separable sums differ from it at f32 round-off, ~1e-7 relative).
+template <typename T, int NSLICE, bool PLANES = false, typename PT = bf16_t>
 __global__ __launch_bounds__(256, 4) void roi_align_nhwc_sep_kernel(const T* __restrict__ feat,
                                                                  const float* __restrict__ rois, T* __restrict__ out,
                                                                  int K, int C, int H, int W, float spatial_scale,
                                                                  int PH, int PW) {
+  static_assert(!PLANES || sizeof(T) == 4, "planes output: f32 features");
   constexpr int VE = Elem<T>::VE;
+  // one pooled 16-byte vector -> out (plain rows, or the hi / lo planes of ROI k's row)
+  auto store = [&](int k_, int bin, int cv, const float (&acc)[Elem<T>::VE], float inv_count) {
+    if constexpr (PLANES) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[e] * inv_count;
+      const unsigned h0 = Half16<PT>::pack2(v[0], v[1]), h1 = Half16<PT>::pack2(v[2], v[3]);
+      const unsigned l0 = Half16<PT>::pack2(v[0] - Half16<PT>::lo(h0), v[1] - Half16<PT>::hi(h0));
+      const unsigned l1 = Half16<PT>::pack2(v[2] - Half16<PT>::lo(h1), v[3] - Half16<PT>::hi(h1));
+      const size_t plane = (size_t)PH * PW * C;
+      unsigned short* row = reinterpret_cast<unsigned short*>(out) + (size_t)k_ * 2 * plane + (size_t)bin * C + (size_t)cv * 4;
+      *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(row + plane) = make_uint2(l0, l1);
+    } else {
+      uint4 o;
+      T* oe = reinterpret_cast<T*>(&o);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] * inv_count);
+      *reinterpret_cast<uint4*>(out + ((size_t)k_ * PH * PW + bin) * C + (size_t)cv * VE) = o;
+    }
+  };
   __shared__ float s_wy[RS_MAXPW][RS_MAXP + 2];   // (+2: the two-row unroll reads one slot past an odd row count)
   __shared__ float s_wx[RS_MAXPW][RS_MAXP];
   __shared__ int s_y[RS_MAXPW][2];          // per bin row: first patch row, number of rows
@@ -478,11 +503,7 @@ __global__ __launch_bounds__(256, 4) void roi_align_nhwc_sep_kernel(const T* __r
             }
         }
       }
-      uint4 o;
-      T* oe = reinterpret_cast<T*>(&o);
-#pragma unroll
-      for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] * inv_count);
-      *reinterpret_cast<uint4*>(out + ((size_t)k * PH * PW + bin) * C + (size_t)cv * VE) = o;
+      store(k, bin, cv, acc, inv_count);
     }
     return;
   }
@@ -498,11 +519,7 @@ __global__ __launch_bounds__(256, 4) void roi_align_nhwc_sep_kernel(const T* __r
     else if (NCm <= 4) roi_patch_accumulate<T, 4, 2>(base, W, H, C, y0, x0, NR, s_wy[ph], s_wx[pw], acc);
     else if (NCm <= 6) roi_patch_accumulate<T, 6, 2>(base, W, H, C, y0, x0, NR, s_wy[ph], s_wx[pw], acc);
     else roi_patch_accumulate<T, RS_MAXP, 1>(base, W, H, C, y0, x0, NR, s_wy[ph], s_wx[pw], acc);
-    uint4 o;
-    T* oe = reinterpret_cast<T*>(&o);
-#pragma unroll
-    for (int e = 0; e < VE; ++e) Elem<T>::st(oe + e, acc[e] * inv_count);
-    *reinterpret_cast<uint4*>(out + ((size_t)k * PH * PW + bin) * C + (size_t)cv * VE) = o;
+    store(k, bin, cv, acc, inv_count);
   }
 }
 
@@ -1018,6 +1035,18 @@ extern "C" int mega_roi_align_fwd_planes_dt(const float* feat, const float* rois
   if (nb > 131072) nb = 131072;
   dim3 vgrid((unsigned)(sliced ? nb * 8 : nb));
   hipStream_t st = (hipStream_t)stream;
+  // the separable per-ROI form (adaptive grid, one block per ROI x XCD channel slice), as the 16-bit kernels: the sums differ
+  // from the exact-term-order kernel at f32 round-off (~1e-7 relative); MEGA_ROI_NO_SEPARABLE=1 keeps the latter
+  static const bool no_sep = getenv("MEGA_ROI_NO_SEPARABLE") != nullptr;
+  if (!no_sep && sliced && sampling_ratio <= 0 && pooled_w <= RS_MAXPW && pooled_h <= RS_MAXPW) {
+    if (dtype == MEGA_F16)
+      hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<float, 8, true, f16_t>), dim3((unsigned)(K * 8)), dim3(256), 0, st, feat, rois,
+                         (float*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w);
+    else
+      hipLaunchKernelGGL((roi_align_nhwc_sep_kernel<float, 8, true, bf16_t>), dim3((unsigned)(K * 8)), dim3(256), 0, st, feat, rois,
+                         (float*)out, K, C, H, W, spatial_scale, pooled_h, pooled_w);
+    return mega_check_launch();
+  }
   if (dtype == MEGA_F16) {
     if (sliced)
       hipLaunchKernelGGL((roi_align_nhwc_vec_kernel<float, true, true, f16_t>), vgrid, dim3(256), 0, st, feat, rois, (float*)out, K, C,

@@ -472,7 +472,9 @@ def roi_align(feat, rois, spatial_scale, pooled, sampling_ratio, in_nhwc=True, o
 
 def roi_align_planes(feat, rois, spatial_scale, pooled, sampling_ratio, dtype=torch.bfloat16):
     """roi_align on f32 NHWC features, the pooled rows as split-precision planes: -> Planes [K, ph*pw*C] (t = bf16 / f16
-    [K, 2*ph*pw*C]); equals split_planes(roi_align(...).view(K, -1)) bit for bit, without the f32 tensor in between."""
+    [K, 2*ph*pw*C]), without the f32 tensor in between.  Large launches (C / 4 a multiple of 8 channel vectors, adaptive grid) run
+    the separable per-ROI form of the 16-bit kernels: split_planes(roi_align(...)) to f32 round-off; small ones the
+    exact-term-order kernel: bit for bit (MEGA_ROI_NO_SEPARABLE=1: always)."""
     _gpu(feat, rois)
     lib = _lib.load()
     B, H, W, C = feat.shape
