@@ -360,4 +360,11 @@ def test_h2_linear_sp_split_k_and_roi_align_planes(dev):
         f32 = ops.roi_align(feat, rois, 1.0 / 16, (7, 7), 0)
         want = ops.split_planes(f32.view(Kr, -1).contiguous(), H16)
         got = ops.roi_align_planes(feat, rois, 1.0 / 16, (7, 7), 0, H16)
-        assert got.C == want.C and got.t.dtype == H16 and torch.equal(got.t.view(torch.int16), want.t.view(torch.int16))
+        assert got.C == want.C and got.t.dtype == H16
+        if C == 2048:     # the XCD-sliced hot shape runs the separable form (round 6): f32 round-off, far below the planes' own
+            n = got.C     # rounding (fp16 [hi | lo]: ~2^-22 relative; the small lo values leave fp16's normal range: 2^-24 absolute)
+            a = got.t[:, :n].float() + got.t[:, n:].float()
+            scale = f32.abs().max().item()
+            assert (a - f32.view(Kr, -1)).abs().max().item() <= 4e-6 * scale
+        else:             # (small shapes keep the exact-term-order kernel: bit for bit)
+            assert torch.equal(got.t.view(torch.int16), want.t.view(torch.int16))
